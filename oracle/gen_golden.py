@@ -1,0 +1,427 @@
+#!/usr/bin/env python3
+"""Golden-vector generator: runs the REFERENCE (imported read-only from /root/reference) under
+the shared NoiseStream and writes small fixtures to tests/golden/.  Container-only — the GPU box
+has no reference; nothing under tests/ or the product imports this file.
+
+Harness recipe = SURVEY.md Appendix C: stub modules for gymnasium / lz4 / wandb (imported at
+package import time, never used by the path), a FakeEnv with Box-like spaces, latent_dim == obs_dim
+(reference defect D1), a callable re-class of the decoder ModuleList (defect D2), `total_steps`
+pinned to 1 (defect D3), and a replay-mode RNG tape that serves every torch/numpy draw from
+`oracle.noise.NoiseStream` in call order.
+
+While generating, every vector is also compared against `oracle.aid_oracle` (this is what "pins"
+the oracle); a mismatch aborts.  Usage:  python oracle/gen_golden.py [--out tests/golden]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import aid_oracle as orc  # noqa: E402
+from oracle.noise import NoiseStream  # noqa: E402
+from oracle.weights import draw_params, param_specs  # noqa: E402
+
+REF = "/root/reference"
+
+
+# ------------------------------------------------------------------ stubs (Appendix C.1)
+def install_stubs():
+    gym = types.ModuleType("gymnasium")
+
+    class Env:  # noqa: D401
+        pass
+
+    class Wrapper(Env):
+        def __init__(self, env=None):
+            self.env = env
+
+    class ObservationWrapper(Wrapper):
+        pass
+
+    class Space:
+        pass
+
+    class Box(Space):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+    spaces = types.ModuleType("gymnasium.spaces")
+    spaces.Box, spaces.Space = Box, Space
+    gym.Env, gym.Wrapper, gym.ObservationWrapper, gym.Space, gym.spaces = Env, Wrapper, ObservationWrapper, Space, spaces
+    gym.wrappers = types.ModuleType("gymnasium.wrappers")
+    gym.make = lambda *a, **k: (_ for _ in ()).throw(RuntimeError("stub"))
+    sys.modules.update({"gymnasium": gym, "gymnasium.spaces": spaces, "gymnasium.wrappers": gym.wrappers})
+    lz4 = types.ModuleType("lz4"); lz4.frame = types.ModuleType("lz4.frame")
+    sys.modules.update({"lz4": lz4, "lz4.frame": lz4.frame, "wandb": types.ModuleType("wandb")})
+    for m in ("mujoco", "cv2", "imageio"):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    return Box
+
+
+# ------------------------------------------------------------------ RNG tape (Appendix C.6)
+class Tape:
+    """Replay-mode shim: every draw of the reference is served from a NoiseStream."""
+
+    def __init__(self):
+        self.ns = None
+        self.train_dropout = True
+        self._orig = {}
+
+    def install(self):
+        import torch.distributions.normal as tdn
+        import torch.nn.functional as Fn
+        o = self._orig
+        o["randn"], o["randn_like"], o["rand"] = torch.randn, torch.randn_like, torch.rand
+        o["randperm"], o["multinomial"] = torch.randperm, torch.multinomial
+        o["std_normal"], o["dropout"], o["np_randint"] = tdn._standard_normal, Fn.dropout, np.random.randint
+        T = self
+
+        def randn(*size, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            return torch.from_numpy(T.ns.randn(*size)).to(kw.get("dtype") or torch.float32)
+
+        def randn_like(x, **kw):
+            return torch.from_numpy(T.ns.randn(*x.shape)).to(x.dtype)
+
+        def rand(*size, **kw):
+            if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)):
+                size = tuple(size[0])
+            return torch.from_numpy(T.ns.rand(*size))
+
+        def randperm(n, **kw):
+            return torch.from_numpy(T.ns.randperm(n))
+
+        def multinomial(probs, n, replacement=False, **kw):
+            assert replacement
+            return torch.from_numpy(T.ns.multinomial(probs.detach().numpy(), n))
+
+        def std_normal(shape, dtype, device):
+            return torch.from_numpy(T.ns.randn(*shape)).to(dtype)
+
+        def dropout(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            return x * torch.from_numpy(T.ns.dropout_mask(tuple(x.shape), p)).to(x.dtype)
+
+        def np_randint(low, high=None, size=None, **kw):
+            return T.ns.randint(low, high, size)
+
+        torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
+        torch.randperm, torch.multinomial = randperm, multinomial
+        tdn._standard_normal, Fn.dropout, np.random.randint = std_normal, dropout, np_randint
+
+    def use(self, key):
+        self.ns = NoiseStream(key)
+        return self.ns
+
+
+def close(a, b, rtol, atol, what):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    if not np.allclose(a, b, rtol=rtol, atol=atol):
+        err = np.max(np.abs(a - b)); ref = np.max(np.abs(b))
+        raise SystemExit(f"ORACLE MISMATCH {what}: max abs err {err:.3e} (ref max {ref:.3e})")
+    return float(np.max(np.abs(a - b))) if a.size else 0.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    os.makedirs(args.out, exist_ok=True)
+    torch.set_num_threads(1)
+    Box = install_stubs()
+    sys.path.insert(0, REF)
+    tape = Tape(); tape.install()
+    import torch.nn as nn
+    import active_inference_diffusion as aid
+    from active_inference_diffusion.core.belief_dynamics import BeliefDynamics
+    from active_inference_diffusion.core.free_energy import FreeEnergyComputation
+    from active_inference_diffusion.agents.base_agent import RunningMeanStd as RefRMS
+
+    class FakeEnv:
+        def __init__(self, O, A):
+            self.observation_space = Box(-np.inf, np.inf, (O,))
+            self.action_space = Box(-1, 1, (A,))
+
+    def build(O, A, D, N, H, B, key):
+        cfg = aid.ActiveInferenceConfig(device="cpu", batch_size=B, efe_horizon=H, latent_dim=O, hidden_dim=D)
+        cfg.diffusion = aid.DiffusionConfig(num_diffusion_steps=N)
+        tape.use(999)  # constructor draws (orthogonal init etc. use torch's own RNG; harmless)
+        agent = aid.DiffusionStateAgent(FakeEnv(O, A), cfg, aid.TrainingConfig(buffer_size=64))
+        ai = agent.active_inference
+
+        class CallableDecoder(nn.ModuleList):  # Appendix C.4 (defect D2)
+            def forward(self, h):
+                h1 = self[0](h); h2 = self[1](h1); h2 = h2 + h1
+                return self[3](self[2](h2))
+        ai.observation_decoder.__class__ = CallableDecoder
+        sd = ai.state_dict()
+        names = [k for k in sd if not k.startswith("epistemic_estimator.decoder.")]
+        specs = param_specs(O, A, O, D, N)
+        assert [n for n, _ in specs] == names, "param_specs order/names differ from the reference"
+        for (n, s) in specs:
+            assert tuple(sd[n].shape) == s, (n, tuple(sd[n].shape), s)
+        params = draw_params(specs, key, orc.schedule_tables(N))
+        for n in names:  # schedule buffers must equal the reference's own
+            if n.startswith("latent_diffusion.") and sd[n].shape == (N,):
+                close(params[n], sd[n], 0, 0, f"schedule {n}")
+        ai.load_state_dict({**params, **{k: params[k.replace("epistemic_estimator.decoder.", "observation_decoder.")]
+                                         for k in sd if k.startswith("epistemic_estimator.decoder.")}}, strict=True)
+        # score EMA shadow must restart from the loaded weights
+        agent.score_ema = aid.core.EMAModel(ai.latent_score_network, decay=0.9999, device="cpu")
+        return agent, ai, specs, params
+
+    report = {}
+    # ============================================================== per-function goldens
+    for tag, (O, A) in {"hc": (17, 6), "hop": (11, 3)}.items():
+        D, N, H, B, KEY = 64, 4, 2, 8, 1234 + O
+        agent, ai, specs, params = build(O, A, D, N, H, B, KEY)
+        L = O
+        g = {"O": O, "A": A, "L": L, "D": D, "N": N, "H": H, "B": B, "weights_key": KEY}
+        inp = NoiseStream(77 + O)
+        obs = inp.randn(B, O); z = inp.randn(B, L); act = np.tanh(inp.randn(B, A)).astype(np.float32)
+        rew = inp.randn(B); t_cont = inp.rand(B); nobs = inp.randn(B, O)
+        g.update(obs=obs, z=z, act=act, rew=rew, t_cont=t_cont, nobs=nobs)
+        T = torch.from_numpy
+        p = {k: v.clone() for k, v in params.items()}
+        tab = orc.schedule_tables(N)
+
+        # ---- A1 score forward: continuous, discrete (t>=2), t=0, t=1; eval and train
+        ai.eval()
+        for nm, tt in (("cont", T(t_cont)), ("disc", torch.full((B,), 3.0)), ("t0", torch.zeros(B)), ("t1", torch.ones(B))):
+            with torch.no_grad():
+                ref = ai.latent_score_network(T(z), tt, T(obs))
+            mine = orc.score_forward(p, T(z), tt, T(obs))
+            report[f"{tag}/score_{nm}"] = close(mine, ref, 1e-5, 1e-7, f"score {nm}")
+            g[f"score_{nm}"] = ref.numpy()
+        ai.train()
+        tape.use(5); ref = ai.latent_score_network(T(z), T(t_cont), T(obs)).detach()
+        mine = orc.score_forward(p, T(z), T(t_cont), T(obs), NoiseStream(5), True)
+        report[f"{tag}/score_train"] = close(mine, ref, 1e-5, 1e-7, "score train")
+        g["score_train"] = ref.numpy(); g["score_train_key"] = 5
+
+        # ---- A3/A4 reverse loop + belief update (train mode, masks)
+        tape.use(6)
+        with torch.no_grad():
+            bi = ai.update_belief_via_diffusion(T(obs))
+        mine = orc.update_belief_via_diffusion(p, tab, T(obs), NoiseStream(6), True)
+        report[f"{tag}/belief"] = close(mine["latent"], bi["latent"], 1e-4, 1e-6, "belief latent")
+        close(mine["reconstruction_error"], bi["reconstruction_error"], 1e-4, 1e-6, "belief rec")
+        close(mine["latent_std"], bi["latent_std"], 1e-4, 1e-6, "belief std")
+        g.update(belief_key=6, belief_latent=bi["latent"].numpy(), belief_rec=bi["reconstruction_error"].numpy(),
+                 belief_mean=bi["latent_mean"].numpy(), belief_std=bi["latent_std"].numpy())
+        traj_ref = [x.numpy() for x in ai.latent_trajectory]
+        g["belief_traj"] = np.stack(traj_ref)
+        ai.eval(); tape.use(7)
+        with torch.no_grad():
+            bi = ai.update_belief_via_diffusion(T(obs))
+        mine = orc.update_belief_via_diffusion(p, tab, T(obs), NoiseStream(7), False)
+        report[f"{tag}/belief_eval"] = close(mine["latent"], bi["latent"], 1e-4, 1e-6, "belief eval")
+        g.update(belief_eval_key=7, belief_eval_latent=bi["latent"].numpy())
+        ai.train()
+
+        # ---- A9 small nets
+        with torch.no_grad():
+            tape.use(8); a_ref, lp_ref, dist = ai.policy_network(T(z))
+            ent_ref = dist.entropy().sum(-1)
+            v_ref = ai.value_network(T(z), torch.full((B,), 2.0))
+            nm_ref, nlv_ref = ai.predict_next_latent(T(z), T(act))
+            r_ref = ai.reward_predictor(T(z))
+            ai.eval(); dec_ref = ai.decode_observation(T(z)); ai.train()
+        a_m, lp_m, ent_m, _, _ = orc.policy_forward(p, T(z), T(NoiseStream(8).randn(B, A)))
+        close(a_m, a_ref, 1e-5, 1e-6, "policy action"); close(lp_m, lp_ref, 1e-5, 1e-5, "policy logp")
+        close(ent_m, ent_ref, 1e-5, 1e-6, "policy entropy")
+        close(orc.value_forward(p, T(z), torch.full((B,), 2.0)), v_ref, 1e-5, 1e-6, "value")
+        close(orc.predict_next_latent(p, T(z), T(act))[0], nm_ref, 1e-5, 1e-6, "dynamics")
+        close(orc.reward_predict(p, T(z)), r_ref, 1e-5, 1e-6, "reward")
+        close(orc.decode_observation(p, T(z)), dec_ref, 1e-5, 1e-6, "decoder")
+        g.update(policy_key=8, policy_action=a_ref.numpy(), policy_logp=lp_ref.numpy(), policy_entropy=ent_ref.numpy(),
+                 value_t2=v_ref.numpy(), dyn_next_mean=nm_ref.numpy(), reward_out=r_ref.numpy(), decoder_eval=dec_ref.numpy())
+
+        # ---- A7 ELBO loss + gradients (first call: uniform t; second: importance sampled)
+        names = orc.group_names(p, "score")
+        for call in (1, 2):
+            for n in p:
+                p[n].requires_grad_(orc.is_param(n))
+            key = 20 + call
+            tape.use(key); ai.zero_grad()
+            loss_ref, info_ref = ai.compute_diffusion_elbo(T(obs), T(rew), T(z))
+            loss_ref.backward()
+            tiw_before = None if call == 1 else tiw_mine
+            loss_m, info_m, t_m, per_m = orc.diffusion_elbo(p, T(obs), T(rew), T(z), NoiseStream(key), tiw_before, True)
+            gr = torch.autograd.grad(loss_m, [p[n] for n in names], allow_unused=True)
+            report[f"{tag}/elbo{call}"] = close(loss_m, loss_ref, 1e-5, 1e-6, "elbo loss")
+            for kk in ("reconstruction_loss", "kl_loss", "score_matching_loss", "reward_loss", "grad_penalty", "mean_time", "loss_weight_mean"):
+                close(info_m[kk], info_ref[kk], 1e-4, 1e-6, f"elbo info {kk}")
+                g[f"elbo{call}_{kk}"] = np.float32(info_ref[kk])
+            refg = dict(ai.named_parameters())
+            gn = 0.0
+            for n, gm in zip(names, gr):
+                gref = refg[n].grad
+                if gref is None:
+                    assert gm is None or float(gm.abs().max()) == 0, n
+                    continue
+                close(gm, gref, 2e-3, 1e-6 * max(1.0, float(gref.abs().max())), f"elbo grad {n}")
+                gn += float((gref ** 2).sum())
+            g[f"elbo{call}_key"] = key; g[f"elbo{call}_loss"] = loss_ref.detach().numpy()
+            g[f"elbo{call}_gradnorm"] = np.float32(np.sqrt(gn))
+            for n in ("latent_score_network.output_proj.2.weight", "latent_score_network.latent_proj.weight",
+                      "latent_score_network.transformer_blocks.3.mlp.0.weight",
+                      "latent_score_network.transformer_blocks.0.norm1.adaLN_modulation.1.weight",
+                      "latent_score_network.obs_encoder.0.weight", "latent_score_network.time_embed.1.weight",
+                      "latent_score_network.time_scale", "latent_diffusion.log_snr_min", "latent_diffusion.log_snr_max",
+                      "latent_diffusion.latent_prior_mean", "latent_diffusion.latent_prior_log_std",
+                      "latent_score_network.output_multiplier", "latent_score_network.time_embed.0.freq_scale"):
+                g[f"elbo{call}_grad/{n}"] = refg[n].grad.numpy().copy()
+            tiw_mine = orc.update_time_importance(torch.ones(100) if tiw_before is None else tiw_before, t_m, per_m)
+            close(tiw_mine, ai.time_importance_weights, 1e-6, 1e-7, "time importance")
+            g[f"elbo{call}_tiw"] = ai.time_importance_weights.numpy().copy()
+        del ai.time_importance_weights
+        for n in p:
+            p[n].requires_grad_(False)
+
+        # ---- A8/A10 EFE (K=2,S=2) value + policy gradient
+        for n in p:
+            p[n].requires_grad_(orc.is_param(n))
+        tape.use(30); ai.zero_grad(); ai.epistemic_estimator.running_mean = torch.tensor(0.0)
+        efe_ref, einfo_ref = ai.compute_expected_free_energy_diffusion(T(z), horizon=H, num_trajectories=2, num_ambiguity_samples=2)
+        efe_ref.mean().backward()
+        efe_m, einfo_m, rm_m = orc.expected_free_energy(p, T(z), NoiseStream(30), 0.0, H, 2, 2, True)
+        report[f"{tag}/efe"] = close(efe_m, efe_ref, 1e-4, 1e-5, "efe")
+        close(rm_m, ai.epistemic_estimator.running_mean, 1e-5, 1e-7, "running mean")
+        pnames = orc.group_names(p, "policy")
+        gr = torch.autograd.grad(efe_m.mean(), [p[n] for n in pnames])
+        refg = dict(ai.named_parameters())
+        for n, gm in zip(pnames, gr):
+            close(gm, refg[n].grad, 2e-3, 1e-6 * max(1.0, float(refg[n].grad.abs().max())), f"efe grad {n}")
+        g.update(efe_key=30, efe=efe_ref.detach().numpy(), efe_running_mean=np.float32(ai.epistemic_estimator.running_mean),
+                 efe_epistemic_mean=np.float32(float(einfo_ref["epistemic_mean"].detach())), efe_pragmatic_mean=np.float32(float(einfo_ref["pragmatic_mean"].detach())),
+                 efe_consistency_mean=np.float32(float(einfo_ref["consistency_mean"].detach())), efe_mi=np.float32(float(einfo_ref["epistemic/mi_estimate"])))
+        for n in ("policy_network.latent_encoder.0.weight", "policy_network.trunk.3.weight", "policy_network.mean_head.2.weight",
+                  "policy_network.log_std_head.2.bias", "policy_network.trunk.4.weight"):
+            g[f"efe_grad/{n}"] = refg[n].grad.numpy().copy()
+        for n in p:
+            p[n].requires_grad_(False)
+
+        # ---- A11 lambda returns (with dones)
+        dn = np.zeros(B, dtype=bool); dn[2] = True; dn[B - 2] = True
+        nv = NoiseStream(40).randn(B)
+        lr_ref = ai.compute_lambda_returns(T(rew), T(rew), T(nv), T(dn))
+        close(orc.lambda_returns(rew, nv, dn), lr_ref, 1e-6, 1e-7, "lambda returns")
+        g.update(lam_next_values=nv, lam_dones=dn, lam_returns=lr_ref.numpy())
+        # longer case
+        ls = NoiseStream(41); r64 = ls.randn(64); v64 = ls.randn(64); d64 = ls.rand(64) < 0.1
+        lr_ref = ai.compute_lambda_returns(T(r64), T(r64), T(v64), T(d64))
+        close(orc.lambda_returns(r64, v64, d64), lr_ref, 1e-6, 1e-7, "lambda returns 64")
+        g.update(lam64_r=r64, lam64_v=v64, lam64_d=d64, lam64_returns=lr_ref.numpy())
+
+        # ---- A15 free-energy loss
+        fe = FreeEnergyComputation(); ai.eval()
+        with torch.no_grad():
+            fe_ref, _ = fe.compute_loss(T(z), T(obs), T(act), ai.latent_score_network, current_time=0.5)
+        fe_m, _ = orc.free_energy_loss(p, T(z), T(obs), fe.log_precision.detach(), 0.5)
+        close(fe_m, fe_ref, 1e-5, 1e-6, "free energy"); g["free_energy_t05"] = fe_ref.numpy(); ai.train()
+
+        # ============================================================== full train_step x2
+        agent, ai, specs, params = build(O, A, D, N, H, B, KEY)
+        bs = NoiseStream(50 + O)
+        cap = 32
+        store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32),
+                 "rewards": bs.randn(cap), "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+        for i in range(cap):
+            agent.replay_buffer.add(store["observations"][i], store["actions"][i], float(store["rewards"][i]),
+                                    store["next_observations"][i], bool(store["dones"][i]))
+        st = orc.OracleAgentState(params, N)
+        for step in (1, 2):
+            key = 60 + step
+            tape.use(key); agent.total_steps = 1
+            m_ref = agent.train_step()
+            ns = NoiseStream(key)
+            batch = orc.replay_sample(store, cap, B, ns)
+            m_m = orc.train_step(st, batch, ns, horizon=H)
+            for kk, vv in m_ref.items():
+                if kk in m_m and isinstance(vv, float):
+                    close(np.float32(m_m[kk]), np.float32(vv), 2e-3, 1e-5, f"train_step{step} metric {kk}")
+            sd = ai.state_dict()
+            worst = 0.0
+            for n, _ in specs:
+                if n == "epistemic_estimator.running_mean":
+                    close(np.float32(st.running_mean), sd[n], 1e-5, 1e-7, "rm"); continue
+                worst = max(worst, close(st.p[n], sd[n], 1e-4, 2e-7, f"train_step{step} param {n}"))
+            report[f"{tag}/train_step{step}"] = worst
+            g[f"ts{step}_key"] = key
+            for kk, vv in m_ref.items():
+                if isinstance(vv, (float, int)):
+                    g[f"ts{step}_metric/{kk}"] = np.float32(vv)
+            for n in ("latent_score_network.output_proj.2.weight", "latent_score_network.transformer_blocks.2.mlp.2.weight",
+                      "latent_score_network.transformer_blocks.5.attention.in_proj_weight", "latent_diffusion.latent_prior_mean",
+                      "latent_diffusion.log_snr_max", "policy_network.trunk.0.weight", "policy_network.mean_head.2.weight",
+                      "value_network.network.3.weight", "value_network.network.9.weight", "latent_dynamics.network.0.weight",
+                      "latent_dynamics.network.9.weight", "observation_decoder.3.weight", "reward_predictor.5.weight"):
+                g[f"ts{step}_param/{n}"] = sd[n].numpy().copy()
+            g[f"ts{step}_ema/latent_score_network.output_proj.2.weight"] = agent.score_ema.shadow["output_proj.2.weight"].numpy().copy()
+            close(st.ema["latent_score_network.output_proj.2.weight"], agent.score_ema.shadow["output_proj.2.weight"], 1e-5, 1e-7, "ema")
+            # a checksum over *every* parameter so that the GPU test covers all of them
+            g[f"ts{step}_checksum"] = np.array([float(sd[n].double().sum()) for n, _ in specs], dtype=np.float64)
+            g[f"ts{step}_abssum"] = np.array([float(sd[n].double().abs().sum()) for n, _ in specs], dtype=np.float64)
+        g["store_key"] = 50 + O; g["store_cap"] = cap
+        np.savez_compressed(os.path.join(args.out, f"state_{tag}.npz"), **g)
+
+    # ============================================================== misc goldens
+    m = {}
+    for N in (10, 25, 50, 100):
+        for kind in ("cosine", "linear"):
+            cfg = aid.DiffusionConfig(num_diffusion_steps=N, beta_schedule=kind)
+            ld = aid.LatentDiffusionProcess(cfg, latent_dim=4)
+            tab = orc.schedule_tables(N, kind)
+            for k, v in tab.items():
+                close(v, getattr(ld, k), 0, 0, f"schedule {kind}{N} {k}")
+            m[f"sched_{kind}_{N}"] = torch.stack([getattr(ld, k) for k in sorted(tab)]).numpy()
+            # p_sample check on random inputs
+            zz = torch.from_numpy(NoiseStream(N).randn(3, 4)); ss = torch.from_numpy(NoiseStream(N + 1).randn(3, 4))
+            for t in (0, 1, N - 1):
+                tape.use(3)
+                ref = ld.p_sample(zz, torch.full((3,), t, dtype=torch.long), ss)
+                eps = None if t == 0 else torch.from_numpy(NoiseStream(3).randn(3, 4))
+                close(orc.p_sample(tab, zz, t, ss, eps), ref, 1e-6, 1e-7, "p_sample")
+    m["sched_keys"] = np.array(sorted(orc.schedule_tables(4)))
+    # RunningMeanStd sequence
+    rr, mm = RefRMS(shape=()), orc.RunningMeanStd()
+    seq = []
+    for i in range(4):
+        x = NoiseStream(90 + i).randn(16) * (i + 1) + i
+        rr.update(x); mm.update(x)
+        close(mm.normalize(x), rr.normalize(x), 1e-12, 1e-12, "rms")
+        seq.append(np.array([rr.mean, rr.var, rr.count]))
+    m["rms_seq"] = np.stack(seq)
+    # BeliefDynamics sub-functions (whole update() raises in the reference: defect D4)
+    bcfg = aid.BeliefDynamicsConfig()
+    bd = BeliefDynamics(6, bcfg)
+    mu = torch.from_numpy(NoiseStream(95).randn(6)).double(); ob = torch.from_numpy(NoiseStream(96).randn(6)).double()
+    sc = torch.from_numpy(NoiseStream(97).randn(6)).double()
+    gref = bd._compute_free_energy_gradient_autodiff(mu, ob, sc, None)
+    ns2 = bcfg.noise_scale ** 2
+    gmine = -(mu - ob) / ns2 - mu + sc
+    close(gmine, gref, 1e-12, 1e-12, "FP gradient")
+    m.update(fp_mu=mu.numpy(), fp_obs=ob.numpy(), fp_score=sc.numpy(), fp_grad=gref.detach().numpy())
+    bd.variance = torch.from_numpy(np.abs(NoiseStream(98).randn(6)).astype(np.float64) + 0.5)
+    m["fp_entropy_var"] = bd.variance.numpy().copy(); m["fp_entropy"] = np.float64(bd.entropy())
+    close(orc.gaussian_entropy_diag(bd.variance.numpy()), m["fp_entropy"], 1e-12, 1e-12, "entropy")
+    np.savez_compressed(os.path.join(args.out, "misc.npz"), **m)
+    for k, v in report.items():
+        print(f"{k:28s} max|oracle-ref| = {v:.3e}")
+    print("golden vectors written to", args.out)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,146 @@
+"""CPU: the oracle (oracle/aid_oracle.py) against the committed golden vectors that
+oracle/gen_golden.py produced by running the reference itself.  No reference, no GPU needed."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import aid_oracle as orc
+from oracle.noise import NoiseStream
+from oracle.weights import draw_params, param_specs
+
+T = torch.from_numpy
+
+
+def _load(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"state_{tag}.npz"))
+    O, A, L, D, N = (int(g[k]) for k in ("O", "A", "L", "D", "N"))
+    specs = param_specs(O, A, L, D, N)
+    p = draw_params(specs, int(g["weights_key"]), orc.schedule_tables(N))
+    return g, specs, p, orc.schedule_tables(N)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_score_forward_all_branches(golden_dir, tag):
+    g, _, p, _ = _load(golden_dir, tag)
+    B = int(g["B"])
+    for nm, tt in (("cont", T(g["t_cont"])), ("disc", torch.full((B,), 3.0)), ("t0", torch.zeros(B)), ("t1", torch.ones(B))):
+        out = orc.score_forward(p, T(g["z"]), tt, T(g["obs"]))
+        np.testing.assert_allclose(out.numpy(), g[f"score_{nm}"], rtol=1e-5, atol=1e-7)
+    out = orc.score_forward(p, T(g["z"]), T(g["t_cont"]), T(g["obs"]), NoiseStream(int(g["score_train_key"])), True)
+    np.testing.assert_allclose(out.numpy(), g["score_train"], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_belief_update_and_trajectory(golden_dir, tag):
+    g, _, p, tab = _load(golden_dir, tag)
+    out = orc.update_belief_via_diffusion(p, tab, T(g["obs"]), NoiseStream(int(g["belief_key"])), True)
+    np.testing.assert_allclose(out["latent"].numpy(), g["belief_latent"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(out["reconstruction_error"].numpy(), g["belief_rec"], rtol=1e-4)
+    np.testing.assert_allclose(out["latent_std"].numpy(), g["belief_std"], rtol=1e-4, atol=1e-6)
+    z, traj = orc.generate_latent_trajectory(p, tab, T(g["obs"]), NoiseStream(int(g["belief_key"])), True, keep=True)
+    np.testing.assert_allclose(np.stack([x.numpy() for x in traj]), g["belief_traj"], rtol=1e-4, atol=1e-6)
+    out = orc.update_belief_via_diffusion(p, tab, T(g["obs"]), NoiseStream(int(g["belief_eval_key"])), False)
+    np.testing.assert_allclose(out["latent"].numpy(), g["belief_eval_latent"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_small_nets(golden_dir, tag):
+    g, _, p, _ = _load(golden_dir, tag)
+    B, A = int(g["B"]), int(g["A"])
+    z = T(g["z"])
+    a, lp, ent, _, _ = orc.policy_forward(p, z, T(NoiseStream(int(g["policy_key"])).randn(B, A)))
+    np.testing.assert_allclose(a.numpy(), g["policy_action"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(lp.numpy(), g["policy_logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(ent.numpy(), g["policy_entropy"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(orc.value_forward(p, z, torch.full((B,), 2.0)).numpy(), g["value_t2"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(orc.predict_next_latent(p, z, T(g["act"]))[0].numpy(), g["dyn_next_mean"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(orc.reward_predict(p, z).numpy(), g["reward_out"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(orc.decode_observation(p, z).numpy(), g["decoder_eval"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_elbo_loss_grads_and_time_importance(golden_dir, tag):
+    g, _, p, _ = _load(golden_dir, tag)
+    names = orc.group_names(p, "score")
+    tiw = None
+    for call in (1, 2):
+        for n in p:
+            p[n].requires_grad_(orc.is_param(n))
+        loss, info, t, per = orc.diffusion_elbo(p, T(g["obs"]), T(g["rew"]), T(g["z"]), NoiseStream(int(g[f"elbo{call}_key"])), tiw, True)
+        np.testing.assert_allclose(loss.item(), g[f"elbo{call}_loss"], rtol=1e-5)
+        for kk in ("reconstruction_loss", "kl_loss", "score_matching_loss", "reward_loss", "grad_penalty", "mean_time"):
+            np.testing.assert_allclose(float(info[kk].detach()), g[f"elbo{call}_{kk}"], rtol=1e-4, atol=1e-6)
+        grads = dict(zip(names, torch.autograd.grad(loss, [p[n] for n in names], allow_unused=True)))
+        gn = np.sqrt(sum(float((v ** 2).sum()) for v in grads.values() if v is not None))
+        np.testing.assert_allclose(gn, g[f"elbo{call}_gradnorm"], rtol=1e-4)
+        for k in g.files:
+            if k.startswith(f"elbo{call}_grad/"):
+                ref = g[k]
+                np.testing.assert_allclose(grads[k.split("/", 1)[1]].numpy(), ref, rtol=2e-3, atol=1e-6 * max(1.0, np.abs(ref).max()))
+        tiw = orc.update_time_importance(torch.ones(100) if tiw is None else tiw, t, per)
+        np.testing.assert_allclose(tiw.numpy(), g[f"elbo{call}_tiw"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_efe_value_and_policy_grads(golden_dir, tag):
+    g, _, p, _ = _load(golden_dir, tag)
+    for n in p:
+        p[n].requires_grad_(orc.is_param(n))
+    efe, info, rm = orc.expected_free_energy(p, T(g["z"]), NoiseStream(int(g["efe_key"])), 0.0, int(g["H"]), 2, 2, True)
+    np.testing.assert_allclose(efe.detach().numpy(), g["efe"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rm, g["efe_running_mean"], rtol=1e-5)
+    np.testing.assert_allclose(float(info["epistemic/mi_estimate"]), g["efe_mi"], rtol=1e-4, atol=1e-6)
+    names = orc.group_names(p, "policy")
+    grads = dict(zip(names, torch.autograd.grad(efe.mean(), [p[n] for n in names])))
+    for k in g.files:
+        if k.startswith("efe_grad/"):
+            ref = g[k]
+            np.testing.assert_allclose(grads[k.split("/", 1)[1]].numpy(), ref, rtol=2e-3, atol=1e-6 * max(1.0, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_lambda_returns(golden_dir, tag):
+    g, _, _, _ = _load(golden_dir, tag)
+    np.testing.assert_allclose(orc.lambda_returns(g["rew"], g["lam_next_values"], g["lam_dones"]), g["lam_returns"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(orc.lambda_returns(g["lam64_r"], g["lam64_v"], g["lam64_d"]), g["lam64_returns"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_full_train_steps(golden_dir, tag):
+    """Two complete reference train_steps (K=10, S=10): every parameter's checksum + spot tensors."""
+    g, specs, p, _ = _load(golden_dir, tag)
+    O, A, B, N, H = (int(g[k]) for k in ("O", "A", "B", "N", "H"))
+    bs = NoiseStream(int(g["store_key"])); cap = int(g["store_cap"])
+    store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32),
+             "rewards": bs.randn(cap), "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+    st = orc.OracleAgentState(p, N)
+    for step in (1, 2):
+        ns = NoiseStream(int(g[f"ts{step}_key"]))
+        m = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
+        for k in g.files:
+            if k.startswith(f"ts{step}_metric/") and k.split("/", 1)[1] in m:
+                np.testing.assert_allclose(m[k.split("/", 1)[1]], g[k], rtol=2e-3, atol=1e-5, err_msg=k)
+            if k.startswith(f"ts{step}_param/"):
+                np.testing.assert_allclose(st.p[k.split("/", 1)[1]].detach().numpy(), g[k], rtol=1e-4, atol=2e-7, err_msg=k)
+        st.p["epistemic_estimator.running_mean"] = torch.tensor(st.running_mean)  # a buffer, kept on the state
+        cs = np.array([float(st.p[n].double().sum()) for n, _ in specs])
+        bad = np.abs(cs - g[f"ts{step}_checksum"]) > 2e-6 * g[f"ts{step}_abssum"] + 1e-6
+        assert not bad.any(), [specs[i][0] for i in np.nonzero(bad)[0]]
+
+
+def test_misc_goldens(golden_dir):
+    m = np.load(os.path.join(golden_dir, "misc.npz"))
+    keys = list(m["sched_keys"])
+    for N in (10, 25, 50, 100):
+        for kind in ("cosine", "linear"):
+            tab = orc.schedule_tables(N, kind)
+            np.testing.assert_array_equal(torch.stack([tab[k] for k in keys]).numpy(), m[f"sched_{kind}_{N}"])
+    rms = orc.RunningMeanStd()
+    for i in range(4):
+        rms.update(NoiseStream(90 + i).randn(16) * (i + 1) + i)
+        np.testing.assert_allclose([rms.mean, rms.var, rms.count], m["rms_seq"][i], rtol=1e-12)
+    mu, ob, sc = m["fp_mu"], m["fp_obs"], m["fp_score"]
+    np.testing.assert_allclose(-(mu - ob) / 0.01 ** 2 - mu + sc, m["fp_grad"], rtol=1e-12)
+    np.testing.assert_allclose(orc.gaussian_entropy_diag(m["fp_entropy_var"]), m["fp_entropy"], rtol=1e-12)

@@ -124,7 +124,9 @@ def test_full_train_steps(golden_dir, tag):
                 np.testing.assert_allclose(m[k.split("/", 1)[1]], g[k], rtol=2e-3, atol=1e-5, err_msg=k)
             if k.startswith(f"ts{step}_param/"):
                 np.testing.assert_allclose(st.p[k.split("/", 1)[1]].detach().numpy(), g[k], rtol=1e-4, atol=2e-7, err_msg=k)
-        st.p["epistemic_estimator.running_mean"] = torch.tensor(st.running_mean)  # a buffer, kept on the state
+        i_rm = [n for n, _ in specs].index("epistemic_estimator.running_mean")  # buffer kept on the state
+        np.testing.assert_allclose(st.running_mean, g[f"ts{step}_checksum"][i_rm], rtol=1e-4)
+        st.p["epistemic_estimator.running_mean"] = torch.tensor(g[f"ts{step}_checksum"][i_rm])
         cs = np.array([float(st.p[n].double().sum()) for n, _ in specs])
         bad = np.abs(cs - g[f"ts{step}_checksum"]) > 2e-6 * g[f"ts{step}_abssum"] + 1e-6
         assert not bad.any(), [specs[i][0] for i in np.nonzero(bad)[0]]

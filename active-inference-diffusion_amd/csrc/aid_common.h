@@ -1,0 +1,130 @@
+// Internal helpers shared by every translation unit of libaid_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <stdio.h>
+#include <string.h>
+#include "../../include/aid_hip.h"
+
+namespace aid {
+
+// ---- error plumbing (never throw / abort across the C ABI) -------------------------------------
+void set_error(const char* fmt, ...);
+#define AID_CHECK_HIP(expr)                                                                  \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ::aid::set_error("%s:%d HIP error %d (%s) in `%s`", __FILE__, __LINE__, (int)_e, \
+                             hipGetErrorString(_e), #expr);                                  \
+            return AID_E_HIP;                                                                \
+        }                                                                                    \
+    } while (0)
+#define AID_REQUIRE(cond, code, ...)         \
+    do {                                     \
+        if (!(cond)) {                       \
+            ::aid::set_error(__VA_ARGS__);   \
+            return (code);                   \
+        }                                    \
+    } while (0)
+#define AID_TRY(expr)              \
+    do {                           \
+        int _r = (expr);           \
+        if (_r != AID_OK) return _r; \
+    } while (0)
+#define AID_LAUNCH_CHECK() AID_CHECK_HIP(hipGetLastError())
+
+// ---- caller-owned workspace: bump allocator, 256-B aligned carve-outs -------------------------
+struct Workspace {
+    char* base; size_t bytes; size_t off; bool overflow;
+    Workspace(void* p, size_t n) : base((char*)p), bytes(n), off(0), overflow(false) {}
+    float* f32(size_t n) { return (float*)raw(n * sizeof(float)); }
+    double* f64(size_t n) { return (double*)raw(n * sizeof(double)); }
+    void* raw(size_t n) {
+        size_t a = (off + 255) & ~(size_t)255;
+        if (base == nullptr || a + n > bytes) { overflow = true; off = a + n; return nullptr; }
+        off = a + n; return base + a;
+    }
+    size_t mark() const { return off; }
+    void release(size_t m) { off = m; }
+};
+#define AID_WS_OK(ws)                                                                        \
+    AID_REQUIRE(!(ws).overflow, AID_E_WORKSPACE, "workspace too small: need >= %zu bytes, have %zu", \
+                (ws).off, (ws).bytes)
+
+// ---- activation ids (GEMM epilogue + row-wise kernels) -----------------------------------------
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3 };
+
+// ---- GEMM:  C[M,N] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) (+ residual) (+ beta*C) ---------
+// a_kmajor = 0: A stored [M][K] (k contiguous, lda = row stride);  1: stored [K][M] (m contiguous)
+// b_kmajor = 0: B stored [N][K] (torch Linear weight);             1: stored [K][N]
+struct GemmArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K; int lda, ldb, ldc;
+    int a_kmajor, b_kmajor;
+    const float* bias;       // [N] or null
+    const float* residual;   // [M,N], row stride ldr, or null (added after the activation)
+    int ldr;
+    float* preact;           // optional second output: value before the activation (row stride ldc)
+    int act;                 // Act
+    float alpha;             // scale of the product
+    int accumulate;          // 1: C += result (act must be NONE)
+    const float* mask;       // optional [M,N] multiplicative mask applied after act (dropout), stride ldc
+};
+inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
+    GemmArgs g; memset(&g, 0, sizeof(g));
+    g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = 1.f;
+    return g;
+}
+int gemm_f32(const GemmArgs& g, hipStream_t s);
+// y = x W^T + b with optional activation: the torch.nn.Linear forward.
+inline int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
+                      int act, hipStream_t s, float* preact = nullptr, const float* residual = nullptr, int ldr = 0,
+                      const float* mask = nullptr) {
+    GemmArgs g = gemm_args(x, ldx, W, K, y, ldy, M, N, K);
+    g.bias = b; g.act = act; g.preact = preact; g.residual = residual; g.ldr = ldr; g.mask = mask;
+    return gemm_f32(g, s);
+}
+// dX[M,K] (+)= dY[M,N] W[N,K]
+inline int linear_bwd_data(const float* dy, int lddy, const float* W, int K, float* dx, int lddx, int M, int N,
+                           hipStream_t s, int accumulate = 0) {
+    GemmArgs g = gemm_args(dy, lddy, W, K, dx, lddx, M, K, N);
+    g.b_kmajor = 1; g.accumulate = accumulate;
+    return gemm_f32(g, s);
+}
+// dW[N,K] (+)= dY[M,N]^T X[M,K]
+inline int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx, float* dW, int M, int N, int K,
+                             hipStream_t s, int accumulate = 1) {
+    GemmArgs g = gemm_args(dy, lddy, x, ldx, dW, K, N, K, M);
+    g.a_kmajor = 1; g.b_kmajor = 1; g.accumulate = accumulate;
+    return gemm_f32(g, s);
+}
+
+// ---- profiling hooks (bench.py reads them through aid_prof_*) ---------------------------------
+enum ProfKernel : int { PROF_GEMM = 0, PROF_ROWWISE = 1, PROF_OPTIM = 2, PROF_COUNT = 3 };
+struct ProfScope {
+    int id; hipStream_t s; bool on; hipEvent_t e0, e1; double flops, bytes;
+    ProfScope(int id, hipStream_t s, double flops, double bytes);
+    ~ProfScope();
+};
+
+__device__ __forceinline__ float act_apply(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_SILU: return x / (1.f + __expf(-x));
+        case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        default: return x;
+    }
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace aid

@@ -1,0 +1,311 @@
+// fp32-in / fp32-accumulate MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32), with fused epilogues.
+//
+//   C[M,N] = act(alpha * sum_k A(m,k) * B(n,k) + bias[n]) * mask + residual   (+ C if accumulate)
+//
+// This one kernel family replaces every dense contraction of the hot path: nn.Linear forward
+// (A=[M][K] activations, B=[N][K] weight), its data gradient (B read k-major) and its weight
+// gradient (both operands read k-major); reference call sites: aid/models/score_networks.py:41-99,
+// policy_networks.py:42-71, value_networks.py:24-45, dynamics_models.py:28-45,
+// core/active_inference.py:111-171,886-919.
+//
+// Design (MI355X): exact-f32 MFMA runs at the f32 vector peak (157 TFLOP/s) and needs ONE f32 per
+// lane per operand per instruction, so LDS traffic is light; what matters is (a) keeping global
+// loads wide and coalesced along whichever dimension is contiguous in memory and (b) exposing
+// enough workgroups for batch-256 problems.  Each operand has two LDS images chosen by its memory
+// layout: k-contiguous operands are staged as [row][BK+4] (b128 writes, b128 fragment reads,
+// conflict-free by the +4 pad) and k-major operands as [k][rows+4] (b128 writes, b32 fragment
+// reads across consecutive lanes).  Because a b128 fragment read hands a lane four consecutive k,
+// the k order inside an 8-deep group is permuted identically for both operands (the reduction is
+// order-free): MFMA j of group g contracts k = {8g+j, 8g+4+j}.
+//
+// Tiles: 128x128 (4 waves as 2x2, 64x64 per wave) for large M, 64x64 (32x32 per wave) and
+// 32x32 + 4-way in-workgroup split-K for the batch<=512 layers where the grid would otherwise
+// leave most of the 256 CUs idle.  Register-staged double buffering: tile t+1's global loads are
+// in flight while tile t is contracted.
+#include "aid_common.h"
+
+namespace aid {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 32;
+
+template <int ROWS, bool KMAJOR>
+struct Tile {  // LDS image of one operand tile (ROWS = BM or BN)
+    static constexpr int LD = KMAJOR ? (ROWS + 4) : (BK + 4);
+    static constexpr int NROW = KMAJOR ? BK : ROWS;
+    static constexpr int FLOATS = LD * NROW;
+    static constexpr int F4 = ROWS * BK / 4;  // float4 per tile
+};
+
+// global -> registers for one operand tile. P = float4 per thread.
+template <int ROWS, bool KMAJOR, bool VEC, int NT, int P>
+__device__ __forceinline__ void load_tile(const float* __restrict__ G, int ld, int r0, int k0, int R, int K,
+                                          int tid, f32x4 (&regs)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int f = tid + NT * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f < Tile<ROWS, KMAJOR>::F4) {
+            if (!KMAJOR) {
+                const int row = f / (BK / 4), kq = f % (BK / 4);
+                const int gr = r0 + row, gk = k0 + 4 * kq;
+                if (gr < R) {
+                    const float* p = G + (size_t)gr * ld + gk;
+                    if (VEC) { if (gk < K) v = *reinterpret_cast<const f32x4*>(p); }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gk + j < K) v[j] = p[j];
+                    }
+                }
+            } else {
+                const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+                const int gk = k0 + k, gr = r0 + 4 * rq;
+                if (gk < K) {
+                    const float* p = G + (size_t)gk * ld + gr;
+                    if (VEC) { if (gr < R) v = *reinterpret_cast<const f32x4*>(p); }
+                    else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (gr + j < R) v[j] = p[j];
+                    }
+                }
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <int ROWS, bool KMAJOR, int NT, int P>
+__device__ __forceinline__ void store_tile(float* __restrict__ S, int tid, const f32x4 (&regs)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int f = tid + NT * i;
+        if (f < Tile<ROWS, KMAJOR>::F4) {
+            int off;
+            if (!KMAJOR) { const int row = f / (BK / 4), kq = f % (BK / 4); off = row * Tile<ROWS, KMAJOR>::LD + 4 * kq; }
+            else { const int k = f / (ROWS / 4), rq = f % (ROWS / 4); off = k * Tile<ROWS, KMAJOR>::LD + 4 * rq; }
+            *reinterpret_cast<f32x4*>(S + off) = regs[i];
+        }
+    }
+}
+
+// fragment of 4 k-values (group g8, this lane's half h) for row `r` of the tile
+template <int ROWS, bool KMAJOR>
+__device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int r, int g8, int h) {
+    if (!KMAJOR) return *reinterpret_cast<const f32x4*>(S + r * Tile<ROWS, KMAJOR>::LD + 8 * g8 + 4 * h);
+    f32x4 v;
+    const float* p = S + (8 * g8 + 4 * h) * Tile<ROWS, KMAJOR>::LD + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = p[j * Tile<ROWS, KMAJOR>::LD];
+    return v;
+}
+
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, float v) {
+    if (row >= g.M || col >= g.N) return;
+    v *= g.alpha;
+    if (g.bias) v += g.bias[col];
+    const size_t o = (size_t)row * g.ldc + col;
+    if (g.preact) g.preact[o] = v;
+    v = act_apply(v, g.act);
+    if (g.mask) v *= g.mask[o];
+    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+    if (g.accumulate) v += g.C[o];
+    g.C[o] = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Main kernel: BMxBN tile, 4 waves as 2x2, each wave (BM/2)x(BN/2) = TMxTN MFMA tiles of 32x32.
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool AKM, bool BKM, bool VEC>
+__global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n) {
+    constexpr int NT = 256;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    using TA = Tile<BM, AKM>; using TB = Tile<BN, BKM>;
+    constexpr int PA = (TA::F4 + NT - 1) / NT, PB = (TB::F4 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                       // 2 stages
+    float* Bs = smem + 2 * TA::FLOATS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[PA], rb[PB];
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
+    load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    store_tile<BM, AKM, NT, PA>(As, tid, ra);
+    store_tile<BN, BKM, NT, PB>(Bs, tid, rb);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
+            load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
+        }
+        const float* a_s = As + cur * TA::FLOATS;
+        const float* b_s = Bs + cur * TB::FLOATS;
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = read_frag<BM, AKM>(a_s, wm + 32 * i + li, g8, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = read_frag<BN, BKM>(b_s, wn + 32 * j + li, g8, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            store_tile<BM, AKM, NT, PA>(As + (cur ^ 1) * TA::FLOATS, tid, ra);
+            store_tile<BN, BKM, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, tid, rb);
+        }
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = n0 + wn + 32 * j + li;
+                epilogue_store(g, row, col, acc[i][j][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small-M kernel: 32x32 output tile per workgroup, the 4 waves split every 32-deep K tile four
+// ways (8 k each = 4 MFMAs) and reduce through LDS.  4x more workgroups than the 64x64 tiling and
+// a 4x shorter dependent MFMA chain per wave: this is the batch-256 configuration.
+// ------------------------------------------------------------------------------------------------
+template <bool AKM, bool BKM, bool VEC>
+__global__ void __launch_bounds__(256) gemm_splitk_kernel(GemmArgs g, int tiles_n) {
+    constexpr int NT = 256, BM = 32, BN = 32;
+    using TA = Tile<BM, AKM>; using TB = Tile<BN, BKM>;
+    constexpr int PA = (TA::F4 + NT - 1) / NT, PB = (TB::F4 + NT - 1) / NT;  // = 1
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * TA::FLOATS;
+    float* red = smem + 2 * TA::FLOATS + 2 * TB::FLOATS;  // [3][16][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 ra[PA], rb[PB];
+    const int nk = (g.K + BK - 1) / BK;
+    load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
+    load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    store_tile<BM, AKM, NT, PA>(As, tid, ra);
+    store_tile<BN, BKM, NT, PB>(Bs, tid, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
+            load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
+        }
+        const f32x4 av = read_frag<BM, AKM>(As + cur * TA::FLOATS, li, wave, h);
+        const f32x4 bv = read_frag<BN, BKM>(Bs + cur * TB::FLOATS, li, wave, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        if (kt + 1 < nk) {
+            store_tile<BM, AKM, NT, PA>(As + (cur ^ 1) * TA::FLOATS, tid, ra);
+            store_tile<BN, BKM, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, tid, rb);
+        }
+        __syncthreads();
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r] + red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane];
+            const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            epilogue_store(g, row, n0 + li, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool AKM, bool BKM>
+static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * (Tile<BM, AKM>::FLOATS + Tile<BN, BKM>::FLOATS);
+    if (lds > 65536) {  // opt in to >64 KiB dynamic LDS once per instantiation
+        static bool done = false;
+        if (!done) {
+            AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, AKM, BKM, true>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_tile_kernel<BM, BN, AKM, BKM, false>,
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            done = true;
+        }
+    }
+    if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, true>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    else     hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, false>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    return AID_OK;
+}
+template <bool AKM, bool BKM>
+static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    const size_t lds = sizeof(float) * (2 * (Tile<32, AKM>::FLOATS + Tile<32, BKM>::FLOATS) + 3 * 16 * 64);
+    if (vec) hipLaunchKernelGGL((gemm_splitk_kernel<AKM, BKM, true>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    else     hipLaunchKernelGGL((gemm_splitk_kernel<AKM, BKM, false>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    return AID_OK;
+}
+template <bool AKM, bool BKM>
+static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
+    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
+    const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (t128 >= 384) return launch_tile<128, 128, AKM, BKM>(g, vec, s);
+    if (t64 >= 256 || g.K <= 64) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+    return launch_splitk<AKM, BKM>(g, vec, s);
+}
+
+static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+int gemm_f32(const GemmArgs& g, hipStream_t s) {
+    AID_REQUIRE(g.A && g.B && g.C, AID_E_NULL, "gemm_f32: null operand");
+    AID_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0, AID_E_SHAPE, "gemm_f32: negative dim");
+    AID_REQUIRE(!(g.accumulate && g.act != ACT_NONE), AID_E_SHAPE, "gemm_f32: accumulate with activation");
+    if (g.M == 0 || g.N == 0) return AID_OK;
+    // vector (16-B) global loads need every row start 16-B aligned along the contiguous dim
+    bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);
+    vec = vec && (g.a_kmajor ? (g.M % 4 == 0) : (g.K % 4 == 0)) && (g.b_kmajor ? (g.N % 4 == 0) : (g.K % 4 == 0));
+    ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    int r;
+    if (!g.a_kmajor && !g.b_kmajor) r = dispatch<false, false>(g, vec, s);
+    else if (!g.a_kmajor && g.b_kmajor) r = dispatch<false, true>(g, vec, s);
+    else if (g.a_kmajor && g.b_kmajor) r = dispatch<true, true>(g, vec, s);
+    else r = dispatch<true, false>(g, vec, s);
+    if (r != AID_OK) return r;
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+}  // namespace aid

@@ -1,0 +1,43 @@
+// Row-wise (one wavefront per row) kernels: LayerNorm family, adaLN modulation, time embeddings,
+// score head / p_sample, pointwise losses.  All HBM/L2-bound; rows are 0.5-8 KB so a 64-lane wave
+// holds a row in registers and reduces with DPP shuffles (no LDS, no atomics).
+#pragma once
+#include "aid_common.h"
+
+namespace aid {
+
+// out[M,dim] = [sin(t*f), cos(t*f)], f_i = freq_scale * exp(-i ln(1e4)/(half-1)); t scaled by
+// `tmul` where the row is on the continuous branch (score_networks.py:126,282-291).
+// mode: AID_T_DISCRETE / AID_T_CONTINUOUS / 2 = per-row by value (t<=1 -> continuous).
+int sinusoid_embed(const float* t, const float* freq_scale, float tmul, int mode, float* out, int M, int dim, hipStream_t s);
+
+// y = act(LN(x)*gamma+beta) * mask.  gamma/beta may be null (non-affine). stats (optional): [M,2] = mean, rstd.
+int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
+           float* stats, int M, int D, hipStream_t s);
+
+// cond = LN(x)*gamma+beta + temb[row*ld_temb + c] ; sc = silu(cond).   (score_networks.py:145-153 + adaLN's SiLU)
+int ln_cond(const float* x, int ldx, const float* gamma, const float* beta, const float* temb, int ld_temb, float* cond,
+            float* sc, float* stats, int M, int D, hipStream_t s);
+
+// y = LN(x)*(1+scale)+shift, scale = mod[row*ldmod + c], shift = mod[row*ldmod + D + c]  (score_networks.py:257-270)
+int adaln(const float* x, int ldx, const float* mod, int ldmod, float* y, int ldy, float* stats, int M, int D, hipStream_t s);
+
+// temb = t_sin + time_scale * c  on continuous rows, t_sin elsewhere (score_networks.py:134)
+int temb_combine(const float* t_sin, const float* c, const float* time_scale, const float* t, int mode, float* out, int M,
+                 int D, hipStream_t s);
+// cte input: out[M] = 2t-1 (score_networks.py:130)
+int affine1(const float* t, float a, float b, float* out, int M, hipStream_t s);
+
+// score = clamp(raw,-10,10) * mult * (continuous ? sqrt(1/(1e-5+t)) : 1)     (score_networks.py:166-170)
+int score_head(const float* raw, const float* mult, const float* t, int mode, float* score, int M, int L, hipStream_t s);
+
+// fused head + p_sample (diffusion.py:208-255) for one reverse step; coef = coefs + 5*step (device)
+//   s = clamp(raw)*mult*tw ; z0 = (z + c0*s)*c1 ; mean = c2*z0 + c3*z ; z' = mean + (step>0 ? c4*eps : 0)
+int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
+                  const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
+
+int fill_const(float* p, float v, size_t n, hipStream_t s);
+int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s);
+int copy_f32(const float* a, float* out, size_t n, hipStream_t s);
+
+}  // namespace aid

@@ -1,0 +1,189 @@
+#include "rowwise.h"
+
+namespace aid {
+
+constexpr int ROWS_PER_BLOCK = 4;  // 4 waves per 256-thread workgroup, one row per wave
+
+__device__ __forceinline__ void row_stats(const float* __restrict__ x, int D, int lane, float& mean, float& rstd) {
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += x[c];
+    mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = x[c] - mean; v += d * d; }
+    const float var = wave_sum(v) / (float)D;
+    rstd = 1.0f / sqrtf(var + 1e-5f);
+}
+
+__global__ void sinusoid_kernel(const float* __restrict__ t, const float* __restrict__ fs, float tmul, int mode,
+                                float* __restrict__ out, int M, int dim) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= M * half) return;
+    const int row = i / half, k = i % half;
+    float tv = t[row];
+    const bool cont = mode == 1 || (mode == 2 && tv <= 1.0f);
+    if (cont) tv = tv * tmul;
+    const float negc = -(float)(9.210340371976184 / (double)(half - 1));  // -ln(1e4)/(half-1)
+    const float f = expf((float)k * negc) * fs[0];
+    const float a = tv * f;
+    out[(size_t)row * dim + k] = sinf(a);
+    out[(size_t)row * dim + half + k] = cosf(a);
+}
+int sinusoid_embed(const float* t, const float* fs, float tmul, int mode, float* out, int M, int dim, hipStream_t s) {
+    const int n = M * (dim / 2);
+    hipLaunchKernelGGL(sinusoid_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t, fs, tmul, mode, out, M, dim);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void ln_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                              const float* __restrict__ beta, int act, const float* __restrict__ mask,
+                              float* __restrict__ y, int ldy, float* __restrict__ stats, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float mean, rstd; row_stats(xr, D, lane, mean, rstd);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    for (int c = lane; c < D; c += 64) {
+        float v = (xr[c] - mean) * rstd;
+        if (gamma) v = v * gamma[c] + beta[c];
+        v = act_apply(v, act);
+        if (mask) v *= mask[(size_t)row * D + c];
+        y[(size_t)row * ldy + c] = v;
+    }
+}
+int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
+           float* stats, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_act_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, gamma, beta,
+                       act, mask, y, ldy, stats, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void ln_cond_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
+                               const float* __restrict__ beta, const float* __restrict__ temb, int ld_temb,
+                               float* __restrict__ cond, float* __restrict__ sc, float* __restrict__ stats, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    float mean, rstd; row_stats(xr, D, lane, mean, rstd);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    for (int c = lane; c < D; c += 64) {
+        const float o = (xr[c] - mean) * rstd * gamma[c] + beta[c];
+        const float v = temb[(size_t)row * ld_temb + c] + o;
+        if (cond) cond[(size_t)row * D + c] = v;
+        sc[(size_t)row * D + c] = act_apply(v, ACT_SILU);
+    }
+}
+int ln_cond(const float* x, int ldx, const float* gamma, const float* beta, const float* temb, int ld_temb, float* cond,
+            float* sc, float* stats, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_cond_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, gamma, beta,
+                       temb, ld_temb, cond, sc, stats, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void adaln_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mod, int ldmod,
+                             float* __restrict__ y, int ldy, float* __restrict__ stats, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * ldx;
+    const float* mr = mod + (size_t)row * ldmod;
+    float mean, rstd; row_stats(xr, D, lane, mean, rstd);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    for (int c = lane; c < D; c += 64)
+        y[(size_t)row * ldy + c] = (xr[c] - mean) * rstd * (1.0f + mr[c]) + mr[D + c];
+}
+int adaln(const float* x, int ldx, const float* mod, int ldmod, float* y, int ldy, float* stats, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(adaln_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, mod, ldmod, y,
+                       ldy, stats, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void temb_combine_kernel(const float* __restrict__ ts, const float* __restrict__ c, const float* __restrict__ tscale,
+                                    const float* __restrict__ t, int mode, float* __restrict__ out, int M, int D) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)M * D) return;
+    const int row = i / D;
+    const bool cont = mode == 1 || (mode == 2 && t[row] <= 1.0f);
+    out[i] = cont ? ts[i] + tscale[0] * c[i] : ts[i];
+}
+int temb_combine(const float* t_sin, const float* c, const float* time_scale, const float* t, int mode, float* out, int M,
+                 int D, hipStream_t s) {
+    const size_t n = (size_t)M * D;
+    hipLaunchKernelGGL(temb_combine_kernel, dim3((n + 255) / 256), dim3(256), 0, s, t_sin, c, time_scale, t, mode, out, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void affine1_kernel(const float* __restrict__ t, float a, float b, float* __restrict__ out, int M) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = a * t[i] + b;
+}
+int affine1(const float* t, float a, float b, float* out, int M, hipStream_t s) {
+    hipLaunchKernelGGL(affine1_kernel, dim3((M + 255) / 256), dim3(256), 0, s, t, a, b, out, M);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void score_head_kernel(const float* __restrict__ raw, const float* __restrict__ mult, const float* __restrict__ t,
+                                  int mode, float* __restrict__ score, int M, int L) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * L) return;
+    const int row = i / L;
+    float v = fminf(fmaxf(raw[i], -10.f), 10.f) * mult[0];
+    const bool cont = mode == 1 || (mode == 2 && t[row] <= 1.0f);
+    if (cont) v *= sqrtf(1.0f / (1e-5f + t[row]));
+    score[i] = v;
+}
+int score_head(const float* raw, const float* mult, const float* t, int mode, float* score, int M, int L, hipStream_t s) {
+    hipLaunchKernelGGL(score_head_kernel, dim3((M * L + 255) / 256), dim3(256), 0, s, raw, mult, t, mode, score, M, L);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void head_p_sample_kernel(const float* __restrict__ raw, const float* __restrict__ mult, float tv, int cont,
+                                     const float* __restrict__ coef, int step, const float* __restrict__ z,
+                                     const float* __restrict__ eps, float* __restrict__ zo, float* __restrict__ traj, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sc = fminf(fmaxf(raw[i], -10.f), 10.f) * mult[0];
+    if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
+    const float zt = z[i];
+    const float z0 = (zt + coef[0] * sc) * coef[1];
+    float v = coef[2] * z0 + coef[3] * zt;
+    if (step > 0) v += coef[4] * eps[i];
+    zo[i] = v;
+    if (traj) traj[i] = v;
+}
+int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
+                  const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s) {
+    const int n = M * L;
+    hipLaunchKernelGGL(head_p_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, s, raw, mult, t_value, continuous, coef, step,
+                       z, eps, z_out, traj_out, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void fill_kernel(float* p, float v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+int fill_const(float* p, float v, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(256), 0, s, p, v, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+__global__ void mul_kernel(const float* a, const float* b, float* o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) o[i] = a[i] * b[i];
+}
+int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, s, a, b, out, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+int copy_f32(const float* a, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    AID_CHECK_HIP(hipMemcpyAsync(out, a, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    return AID_OK;
+}
+
+}  // namespace aid

@@ -1,0 +1,272 @@
+// LatentScoreNetwork forward + reverse-diffusion loop (host orchestration of gfx950 kernels).
+// Reference: aid/models/score_networks.py:101-171 (forward), :214-235 (DiTBlock), :257-270 (adaLN);
+// aid/core/diffusion.py:176-255 (generate_latent_trajectory / p_sample).
+//
+// MI355X-first restructuring (results unchanged):
+//   * the single-token MultiheadAttention degenerates to out_proj(V_proj(x)); Q/K are never read;
+//   * the discarded first time embedding (score_networks.py:119) is not computed;
+//   * all 13 adaLN modulations share their input SiLU(cond), so they are ONE [B,D]x[D,26D] GEMM
+//     (fills the chip at batch 256) instead of 13 thin ones, when the weights are contiguous;
+//   * inside the reverse loop the time embedding depends only on the step index: the [N,D] table is
+//     built once per loop (one M=N GEMM chain) and a row is broadcast per step; the mask-independent
+//     head of the obs encoder is hoisted out of the loop; the time-branch (`0<=t<=1`, a host sync in
+//     the reference) is decided from the step index; head + p_sample are one kernel.
+#include "score_net.h"
+
+namespace aid {
+
+static inline int n_ada(const AidScoreNet& n) { return 2 * n.n_blocks + 1; }
+
+bool score_ada_contiguous(const AidScoreNet& n) {
+    const size_t wsz = (size_t)2 * n.D * n.D, bsz = (size_t)2 * n.D;
+    const float* w = n.blk[0].ada1_w; const float* b = n.blk[0].ada1_b;
+    for (int i = 0; i < n.n_blocks; ++i) {
+        if (n.blk[i].ada1_w != w + (size_t)(2 * i) * wsz || n.blk[i].ada2_w != w + (size_t)(2 * i + 1) * wsz) return false;
+        if (n.blk[i].ada1_b != b + (size_t)(2 * i) * bsz || n.blk[i].ada2_b != b + (size_t)(2 * i + 1) * bsz) return false;
+    }
+    return n.adaf_w == w + (size_t)(2 * n.n_blocks) * wsz && n.adaf_b == b + (size_t)(2 * n.n_blocks) * bsz;
+}
+
+int score_validate(const AidScoreNet* n) {
+    AID_REQUIRE(n, AID_E_NULL, "score net table is null");
+    AID_REQUIRE(n->L > 0 && n->O > 0 && n->D > 0 && n->D % 8 == 0 && n->TE >= 4 && n->TE % 2 == 0, AID_E_SHAPE,
+                "score net: bad dims L=%d O=%d D=%d TE=%d", n->L, n->O, n->D, n->TE);
+    AID_REQUIRE(n->n_blocks >= 0 && n->n_blocks <= AID_MAX_BLOCKS, AID_E_SHAPE, "score net: n_blocks=%d", n->n_blocks);
+    const void* req[] = {n->time_scale, n->output_multiplier, n->te_freq_scale, n->te1_w, n->te1_b, n->te3_w, n->te3_b,
+                         n->oe0_w, n->oe0_b, n->oe1_g, n->oe1_b, n->oe4_w, n->oe4_b, n->oe5_g, n->oe5_b, n->oe7_w, n->oe7_b,
+                         n->oe8_g, n->oe8_b, n->cte0_w, n->cte0_b, n->cte2_w, n->cte2_b, n->cte4_w, n->cte4_b, n->lp_w,
+                         n->lp_b, n->adaf_w, n->adaf_b, n->op0_w, n->op0_b, n->op2_w};
+    for (const void* p : req) AID_REQUIRE(p, AID_E_NULL, "score net: null parameter pointer");
+    for (int i = 0; i < n->n_blocks; ++i) {
+        const AidDiTBlock& b = n->blk[i];
+        AID_REQUIRE(b.ada1_w && b.ada1_b && b.ada2_w && b.ada2_b && b.in_proj_w && b.in_proj_b && b.out_proj_w &&
+                        b.out_proj_b && b.mlp0_w && b.mlp0_b && b.mlp2_w && b.mlp2_b,
+                    AID_E_NULL, "score net: null parameter pointer in block %d", i);
+    }
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void acts_layout(const AidScoreNet& n, int B, bool keep, Workspace& ws, ScoreActs& a) {
+    const size_t D = n.D, TE = n.TE, L = n.L;
+    a.B = B;
+    a.sin_e = ws.f32(B * TE); a.te1_pre = ws.f32(B * 2 * D); a.te1 = ws.f32(B * 2 * D); a.t_sin = ws.f32(B * D);
+    a.cin = ws.f32(B); a.c0_pre = ws.f32(B * TE); a.c0 = ws.f32(B * TE); a.c1_pre = ws.f32(B * TE); a.c1 = ws.f32(B * TE);
+    a.c2 = ws.f32(B * D); a.temb = ws.f32(B * D);
+    a.o0 = ws.f32(B * D); a.st_o0 = ws.f32(B * 2); a.x1n = ws.f32(B * D); a.x1 = ws.f32(B * D);
+    a.o1 = ws.f32(B * D); a.st_o1 = ws.f32(B * 2); a.x2 = ws.f32(B * D); a.o2 = ws.f32(B * D); a.st_o2 = ws.f32(B * 2);
+    a.cond = ws.f32(B * D); a.sc = ws.f32(B * D); a.mod = ws.f32((size_t)B * n_ada(n) * 2 * D);
+    const int nb = n.n_blocks;
+    float* hs[AID_MAX_BLOCKS + 1];
+    if (keep) { for (int i = 0; i <= nb; ++i) hs[i] = ws.f32(B * D); }
+    else { float* hA = ws.f32(B * D); float* hB = ws.f32(B * D); for (int i = 0; i <= nb; ++i) hs[i] = (i & 1) ? hB : hA; }
+    a.h0 = hs[0]; a.h_last = hs[nb];
+    ScoreBlockActs shared{};
+    for (int i = 0; i < nb; ++i) {
+        ScoreBlockActs& b = a.blk[i];
+        if (keep || i == 0) {
+            b.st1 = ws.f32(B * 2); b.nx1 = ws.f32(B * D); b.v = ws.f32(B * D); b.h_mid = ws.f32(B * D); b.st2 = ws.f32(B * 2);
+            b.nx2 = ws.f32(B * D); b.a1 = keep ? ws.f32(B * 4 * D) : nullptr; b.u = ws.f32(B * 4 * D);
+            if (i == 0) shared = b;
+        } else b = shared;
+        b.h_in = hs[i];
+    }
+    a.st_f = ws.f32(B * 2); a.nxf = ws.f32(B * D); a.p0_pre = ws.f32(B * (D / 2)); a.p0 = ws.f32(B * (D / 2));
+    a.raw = ws.f32(B * L);
+}
+size_t score_acts_bytes(const AidScoreNet& n, int B, bool keep) {
+    Workspace ws(nullptr, 0); ScoreActs a; acts_layout(n, B, keep, ws, a); return ws.off + 256;
+}
+int score_acts_alloc(const AidScoreNet& n, int B, bool keep, Workspace& ws, ScoreActs& a) {
+    acts_layout(n, B, keep, ws, a); AID_WS_OK(ws); return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+int score_time_embed(const AidScoreNet& n, int M, const float* t, int mode, ScoreActs& a, hipStream_t s) {
+    const int D = n.D, TE = n.TE;
+    AID_TRY(sinusoid_embed(t, n.te_freq_scale, 999.0f, mode, a.sin_e, M, TE, s));
+    AID_TRY(linear_fwd(a.sin_e, TE, n.te1_w, n.te1_b, a.te1, 2 * D, M, 2 * D, TE, ACT_SILU, s, a.te1_pre));
+    AID_TRY(linear_fwd(a.te1, 2 * D, n.te3_w, n.te3_b, a.t_sin, D, M, D, 2 * D, ACT_NONE, s));
+    if (mode == AID_T_DISCRETE) { AID_TRY(copy_f32(a.t_sin, a.temb, (size_t)M * D, s)); return AID_OK; }
+    AID_TRY(affine1(t, 2.0f, -1.0f, a.cin, M, s));
+    AID_TRY(linear_fwd(a.cin, 1, n.cte0_w, n.cte0_b, a.c0, TE, M, TE, 1, ACT_SILU, s, a.c0_pre));
+    AID_TRY(linear_fwd(a.c0, TE, n.cte2_w, n.cte2_b, a.c1, TE, M, TE, TE, ACT_SILU, s, a.c1_pre));
+    AID_TRY(linear_fwd(a.c1, TE, n.cte4_w, n.cte4_b, a.c2, D, M, D, TE, ACT_NONE, s));
+    AID_TRY(temb_combine(a.t_sin, a.c2, n.time_scale, t, mode, a.temb, M, D, s));
+    return AID_OK;
+}
+
+int score_obs_stage0(const AidScoreNet& n, int B, const float* obs, ScoreActs& a, hipStream_t s) {
+    AID_TRY(linear_fwd(obs, n.O, n.oe0_w, n.oe0_b, a.o0, n.D, B, n.D, n.O, ACT_NONE, s));
+    AID_TRY(ln_act(a.o0, n.D, n.oe1_g, n.oe1_b, ACT_SILU, nullptr, a.x1n, n.D, a.st_o0, B, n.D, s));
+    return AID_OK;
+}
+
+static int score_obs_stage1(const AidScoreNet& n, int B, const float* drop_mask, ScoreActs& a, hipStream_t s) {
+    const int D = n.D;
+    const float* x1 = a.x1n;
+    if (drop_mask) { AID_TRY(mul_elem(a.x1n, drop_mask, a.x1, (size_t)B * D, s)); x1 = a.x1; }
+    else AID_TRY(copy_f32(a.x1n, a.x1, (size_t)B * D, s));
+    AID_TRY(linear_fwd(x1, D, n.oe4_w, n.oe4_b, a.o1, D, B, D, D, ACT_NONE, s));
+    AID_TRY(ln_act(a.o1, D, n.oe5_g, n.oe5_b, ACT_SILU, nullptr, a.x2, D, a.st_o1, B, D, s));
+    AID_TRY(linear_fwd(a.x2, D, n.oe7_w, n.oe7_b, a.o2, D, B, D, D, ACT_NONE, s));
+    return AID_OK;
+}
+
+static int score_cond_mod(const AidScoreNet& n, int B, const float* temb, int ld_temb, ScoreActs& a, hipStream_t s) {
+    const int D = n.D, NA = n_ada(n), ldmod = NA * 2 * D;
+    AID_TRY(ln_cond(a.o2, D, n.oe8_g, n.oe8_b, temb, ld_temb, a.cond, a.sc, a.st_o2, B, D, s));
+    if (score_ada_contiguous(n)) {
+        AID_TRY(linear_fwd(a.sc, D, n.blk[0].ada1_w, n.blk[0].ada1_b, a.mod, ldmod, B, ldmod, D, ACT_NONE, s));
+    } else {
+        for (int i = 0; i < NA; ++i) {
+            const float* w = i == NA - 1 ? n.adaf_w : ((i & 1) ? n.blk[i / 2].ada2_w : n.blk[i / 2].ada1_w);
+            const float* b = i == NA - 1 ? n.adaf_b : ((i & 1) ? n.blk[i / 2].ada2_b : n.blk[i / 2].ada1_b);
+            AID_TRY(linear_fwd(a.sc, D, w, b, a.mod + (size_t)i * 2 * D, ldmod, B, 2 * D, D, ACT_NONE, s));
+        }
+    }
+    return AID_OK;
+}
+
+int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float* temb, int ld_temb, ScoreActs& a, hipStream_t s) {
+    AID_TRY(score_obs_stage1(n, B, drop_mask, a, s));
+    return score_cond_mod(n, B, temb, ld_temb, a, s);
+}
+
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s) {
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
+    AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
+    for (int i = 0; i < n.n_blocks; ++i) {
+        const AidDiTBlock& w = n.blk[i];
+        ScoreBlockActs& b = a.blk[i];
+        float* h_out = (i + 1 < n.n_blocks) ? a.blk[i + 1].h_in : a.h_last;
+        AID_TRY(adaln(b.h_in, D, a.mod + (size_t)(2 * i) * 2 * D, ldmod, b.nx1, D, b.st1, B, D, s));
+        AID_TRY(linear_fwd(b.nx1, D, w.in_proj_w + (size_t)2 * D * D, w.in_proj_b + 2 * D, b.v, D, B, D, D, ACT_NONE, s));
+        AID_TRY(linear_fwd(b.v, D, w.out_proj_w, w.out_proj_b, b.h_mid, D, B, D, D, ACT_NONE, s, nullptr, b.h_in, D));
+        AID_TRY(adaln(b.h_mid, D, a.mod + (size_t)(2 * i + 1) * 2 * D, ldmod, b.nx2, D, b.st2, B, D, s));
+        AID_TRY(linear_fwd(b.nx2, D, w.mlp0_w, w.mlp0_b, b.u, 4 * D, B, 4 * D, D, ACT_GELU, s, keep ? b.a1 : nullptr));
+        AID_TRY(linear_fwd(b.u, 4 * D, w.mlp2_w, w.mlp2_b, h_out, D, B, D, 4 * D, ACT_NONE, s, nullptr, b.h_mid, D));
+    }
+    AID_TRY(adaln(a.h_last, D, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.nxf, D, a.st_f, B, D, s));
+    AID_TRY(linear_fwd(a.nxf, D, n.op0_w, n.op0_b, a.p0, D / 2, B, D / 2, D, ACT_SILU, s, a.p0_pre));
+    AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
+    return AID_OK;
+}
+
+__global__ void iota_kernel(float* t, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = (float)i;
+}
+
+}  // namespace aid
+
+using namespace aid;
+
+extern "C" {
+
+size_t aid_score_forward_workspace(const AidScoreNet* net, int B) {
+    if (!net || B <= 0) return 0;
+    return score_acts_bytes(*net, B, false) + 1024;
+}
+
+int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const float* t, int t_mode, const float* obs,
+                      const float* drop_mask, float* score, void* wsp, size_t ws_bytes, void* stream) {
+    AID_TRY(score_validate(net));
+    AID_REQUIRE(z_t && t && obs && score, AID_E_NULL, "aid_score_forward: null tensor");
+    AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_score_forward: B=%d", B);
+    AID_REQUIRE(t_mode == AID_T_DISCRETE || t_mode == AID_T_CONTINUOUS, AID_E_SHAPE, "aid_score_forward: t_mode=%d", t_mode);
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    ScoreActs a;
+    AID_TRY(score_acts_alloc(*net, B, false, ws, a));
+    AID_TRY(score_time_embed(*net, B, t, t_mode, a, s));
+    AID_TRY(score_obs_stage0(*net, B, obs, a, s));
+    AID_TRY(score_cond(*net, B, drop_mask, a.temb, net->D, a, s));
+    AID_TRY(score_trunk(*net, B, z_t, a, false, s));
+    AID_TRY(score_head(a.raw, net->output_multiplier, t, t_mode, score, B, net->L, s));
+    return AID_OK;
+}
+
+size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
+    if (!net || B <= 0 || n_steps <= 0) return 0;
+    const int R = B > n_steps ? B : n_steps;
+    return score_acts_bytes(*net, R, false) + sizeof(float) * ((size_t)n_steps * (net->D + 1) + (size_t)B * (3 * net->L + net->D)) + 8192;
+}
+
+int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, const float* obs, const float* z_init,
+                     const float* step_noise, const float* drop_masks, int train, uint64_t seed, uint64_t offset,
+                     float* z_out, float* traj, void* wsp, size_t ws_bytes, void* stream) {
+    AID_TRY(score_validate(net));
+    AID_REQUIRE(coefs && obs && z_out, AID_E_NULL, "aid_denoise_loop: null tensor");
+    AID_REQUIRE(B > 0 && N > 0, AID_E_SHAPE, "aid_denoise_loop: B=%d N=%d", B, N);
+    hipStream_t s = (hipStream_t)stream;
+    const AidScoreNet& n = *net;
+    const int D = n.D, L = n.L;
+    Workspace ws(wsp, ws_bytes);
+    float* times = ws.f32(N);
+    float* temb_table = ws.f32((size_t)N * D);
+    float* zA = ws.f32((size_t)B * L);
+    float* zB = ws.f32((size_t)B * L);
+    float* eps_buf = ws.f32((size_t)B * L);
+    float* mask_buf = ws.f32((size_t)B * D);
+    ScoreActs a;
+    const int R = B > N ? B : N;
+    AID_TRY(score_acts_alloc(n, R, false, ws, a));
+
+    // per-loop invariants: [N,D] time-embedding table (steps 0,1 on the continuous branch), obs head
+    hipLaunchKernelGGL(iota_kernel, dim3((N + 255) / 256), dim3(256), 0, s, times, N);
+    AID_LAUNCH_CHECK();
+    AID_TRY(score_time_embed(n, N, times, 2, a, s));
+    AID_TRY(copy_f32(a.temb, temb_table, (size_t)N * D, s));
+    AID_TRY(score_obs_stage0(n, B, obs, a, s));
+    if (!train) AID_TRY(score_cond(n, B, nullptr, temb_table, 0, a, s));  // fills o2 once; cond redone per step
+
+    uint64_t ctr = offset;
+    if (z_init) AID_TRY(copy_f32(z_init, zA, (size_t)B * L, s));
+    else { AID_TRY(philox_fill(zA, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; }
+    if (traj) AID_TRY(copy_f32(zA, traj, (size_t)B * L, s));
+    float* z = zA; float* zn = zB;
+    for (int t = N - 1; t >= 0; --t) {
+        const float* temb = temb_table + (size_t)t * D;
+        if (train) {
+            const float* mask = drop_masks ? drop_masks + (size_t)t * B * D : nullptr;
+            if (!mask) { AID_TRY(philox_fill(mask_buf, (size_t)B * D, 2, 0.1f, seed, ctr, s)); ctr += ((size_t)B * D + 3) / 4; mask = mask_buf; }
+            AID_TRY(score_cond(n, B, mask, temb, 0, a, s));
+        } else {
+            AID_TRY(score_cond_mod(n, B, temb, 0, a, s));
+        }
+        AID_TRY(score_trunk(n, B, z, a, false, s));
+        const float* eps = nullptr;
+        if (t > 0) {
+            eps = step_noise ? step_noise + (size_t)t * B * L : nullptr;
+            if (!eps) { AID_TRY(philox_fill(eps_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; eps = eps_buf; }
+        }
+        float* dst = (t == 0) ? z_out : zn;
+        AID_TRY(head_p_sample(a.raw, n.output_multiplier, (float)t, t <= 1, coefs + 5 * t, t, z, eps, dst,
+                              traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
+        float* tmp = z; z = zn; zn = tmp;
+    }
+    return AID_OK;
+}
+
+int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M,
+                 int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha, int accumulate,
+                 void* stream) {
+    GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K);
+    g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor; g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
+    g.alpha = alpha; g.accumulate = accumulate;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+int aid_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    return philox_fill(out, n, 0, 0.f, seed, offset, (hipStream_t)stream);
+}
+int aid_fill_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+    return philox_fill(out, n, 1, 0.f, seed, offset, (hipStream_t)stream);
+}
+int aid_fill_dropout_mask(float* out, size_t n, float p, uint64_t seed, uint64_t offset, void* stream) {
+    AID_REQUIRE(p >= 0.f && p < 1.f, AID_E_SHAPE, "dropout p=%f", p);
+    return philox_fill(out, n, 2, p, seed, offset, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,159 @@
+"""GPU parity: HIP kernels (through the C ABI) against the oracle / float64 numpy on the same inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import aid_oracle as orc
+from oracle.noise import NoiseStream
+from oracle.weights import draw_params, param_specs
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from aid_amd import _native
+    _native.lib()
+    return _native
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).cuda().contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 512, 512), (256, 2048, 512), (256, 512, 2048), (8, 17, 64), (256, 13312, 512),
+                                   (2560, 512, 384), (33, 70, 145), (1, 1024, 128), (300, 1, 512), (4096, 1024, 1024)])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_layouts(nat, M, N, K, layout):
+    rng = np.random.default_rng(M * 7 + N * 3 + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    Bm = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T
+    akm = 1 if layout == "tn" else 0
+    bkm = 0 if layout == "nt" else 1
+    Ad = dev(A.T if akm else A); Bd = dev(Bm.T if bkm else Bm)
+    out = torch.zeros(M, N, device="cuda")
+    nat.gemm(Ad, Bd, out, M, N, K, Ad.shape[1], Bd.shape[1], N, akm, bkm, bias=dev(bias))
+    got = out.cpu().numpy().astype(np.float64)
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64).T + 1.0
+    assert np.max(np.abs(got - (ref + bias)) / scale) < 2e-6
+
+
+@pytest.mark.parametrize("act", ["relu", "silu", "gelu"])
+def test_gemm_epilogues(nat, act):
+    rng = np.random.default_rng(5)
+    M, N, K = 96, 200, 72
+    A = rng.standard_normal((M, K)).astype(np.float32); W = rng.standard_normal((N, K)).astype(np.float32) / 8
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32)
+    x = torch.from_numpy(A) @ torch.from_numpy(W).T + torch.from_numpy(b)
+    ref = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu}[act](x) + torch.from_numpy(R)
+    out = torch.zeros(M, N, device="cuda")
+    nat.gemm(dev(A), dev(W), out, M, N, K, K, K, N, bias=dev(b), act=act, residual=dev(R), ldr=N)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-5)
+    # accumulate + alpha
+    base = rng.standard_normal((M, N)).astype(np.float32)
+    out = dev(base)
+    nat.gemm(dev(A), dev(W), out, M, N, K, K, K, N, alpha=0.5, accumulate=1)
+    np.testing.assert_allclose(out.cpu().numpy(), base + 0.5 * (A @ W.T), rtol=1e-5, atol=1e-5)
+
+
+def _golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"state_{tag}.npz"))
+    O, A, L, D, N = (int(g[k]) for k in ("O", "A", "L", "D", "N"))
+    specs = param_specs(O, A, L, D, N)
+    p = draw_params(specs, int(g["weights_key"]), orc.schedule_tables(N))
+    return g, p, {k: v.cuda().contiguous() for k, v in p.items()}
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_score_forward_golden(nat, golden_dir, tag):
+    """All four time branches of the reference forward (golden = reference outputs), eval + train."""
+    g, p, pd = _golden(golden_dir, tag)
+    L, D, B = int(g["L"]), int(g["D"]), int(g["B"])
+    tab = nat.score_net_table(pd, "latent_score_network.", L, L, D)
+    z, obs = dev(g["z"]), dev(g["obs"])
+    for nm, tt, cont in (("cont", g["t_cont"], True), ("disc", np.full(B, 3.0), False), ("t0", np.zeros(B), True), ("t1", np.ones(B), True)):
+        out = nat.score_forward(tab, z, dev(tt), obs, cont)
+        np.testing.assert_allclose(out.cpu().numpy(), g[f"score_{nm}"], rtol=1e-4, atol=1e-6, err_msg=nm)
+    mask = NoiseStream(int(g["score_train_key"])).dropout_mask((B, D), 0.1)
+    out = nat.score_forward(tab, z, dev(g["t_cont"]), obs, True, drop_mask=dev(mask))
+    np.testing.assert_allclose(out.cpu().numpy(), g["score_train"], rtol=1e-4, atol=1e-6)
+
+
+def _loop_noise(key, B, L, D, N, train):
+    ns = NoiseStream(key)
+    z0 = ns.randn(B, L)
+    eps = np.zeros((N, B, L), np.float32); masks = np.ones((N, B, D), np.float32)
+    for t in reversed(range(N)):
+        if train:
+            masks[t] = ns.dropout_mask((B, D), 0.1)
+        if t > 0:
+            eps[t] = ns.randn(B, L)
+    return z0, eps, masks
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_denoise_loop_golden(nat, golden_dir, tag):
+    """Reverse-diffusion trajectory against the reference's own trajectory (train + eval mode)."""
+    g, p, pd = _golden(golden_dir, tag)
+    L, D, B, N = int(g["L"]), int(g["D"]), int(g["B"]), int(g["N"])
+    tab = nat.score_net_table(pd, "latent_score_network.", L, L, D)
+    coefs = orc.p_sample_coefs(orc.schedule_tables(N)).cuda().contiguous()
+    z0, eps, masks = _loop_noise(int(g["belief_key"]), B, L, D, N, True)
+    out, traj = nat.denoise_loop(tab, coefs, dev(g["obs"]), N, dev(z0), dev(eps), dev(masks), train=True, keep_traj=True)
+    np.testing.assert_allclose(traj.cpu().numpy(), g["belief_traj"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(out.cpu().numpy(), g["belief_latent"], rtol=1e-3, atol=1e-5)
+    z0, eps, _ = _loop_noise(int(g["belief_eval_key"]), B, L, D, N, False)
+    out = nat.denoise_loop(tab, coefs, dev(g["obs"]), N, dev(z0), dev(eps), None, train=False)
+    np.testing.assert_allclose(out.cpu().numpy(), g["belief_eval_latent"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("O,A,B,N", [(17, 6, 256, 50), (11, 3, 1024, 10)])
+def test_score_and_loop_full_size_vs_oracle(nat, O, A, B, N):
+    """BASELINE configs 2/3 shapes (D=512): HIP vs the oracle on the same seeded inputs."""
+    D, L = 512, O
+    specs = param_specs(O, A, L, D, N)
+    p = draw_params(specs, 4242 + O, orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    tab = nat.score_net_table(pd, "latent_score_network.", L, L, D)
+    ns = NoiseStream(99)
+    z, obs, t = ns.randn(B, L), ns.randn(B, O), ns.rand(B)
+    T = torch.from_numpy
+    ref = orc.score_forward(p, T(z), T(t), T(obs))
+    out = nat.score_forward(tab, dev(z), dev(t), dev(obs), True)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    ref = orc.score_forward(p, T(z), torch.full((B,), 7.0), T(obs))
+    out = nat.score_forward(tab, dev(z), dev(np.full(B, 7.0)), dev(obs), False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    if B <= 256:
+        nsteps = 10  # oracle on CPU: keep it to seconds
+        tabs = orc.schedule_tables(nsteps)
+        coefs = orc.p_sample_coefs(tabs).cuda().contiguous()
+        z0, eps, masks = _loop_noise(123, B, L, D, nsteps, True)
+        ref = orc.generate_latent_trajectory(p, tabs, T(obs), NoiseStream(123), True)
+        out = nat.denoise_loop(tab, coefs, dev(obs), nsteps, dev(z0), dev(eps), dev(masks), train=True)
+        np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5)
+
+
+def test_philox_fills_statistics(nat):
+    n = 1 << 20
+    x = torch.empty(n, device="cuda")
+    nat.fill_normal(x, 7, 0)
+    assert abs(float(x.mean())) < 5e-3 and abs(float(x.std()) - 1) < 5e-3
+    y = torch.empty(n, device="cuda"); nat.fill_normal(y, 7, 0)
+    assert torch.equal(x, y)  # counter-based: same (seed, offset) -> same stream
+    nat.fill_normal(y, 7, n // 4)
+    assert not torch.equal(x, y)
+    nat.fill_uniform(x, 3, 0)
+    assert 0 <= float(x.min()) and float(x.max()) < 1 and abs(float(x.mean()) - 0.5) < 2e-3
+    nat.fill_dropout_mask(x, 0.1, 3, 0)
+    assert abs(float((x == 0).float().mean()) - 0.1) < 2e-3 and abs(float(x.max()) - 1 / 0.9) < 1e-6
+
+
+def test_errors_are_reported_not_thrown(nat):
+    import ctypes as C
+    rc = nat.lib().aid_gemm_f32(None, 1, 0, None, 1, 0, None, 1, 4, 4, 4, None, 0, None, 0, C.c_float(1.0), 0, None)
+    assert rc == -1 and b"null" in nat.lib().aid_last_error()

@@ -62,6 +62,137 @@ BLOCK_KEYMAP = {
     "mlp.0.weight": "mlp0_w", "mlp.0.bias": "mlp0_b", "mlp.2.weight": "mlp2_w", "mlp.2.bias": "mlp2_b",
 }
 
+
+class AidLinear(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("b", C.c_void_p), ("in_", C.c_int32), ("out", C.c_int32)]
+
+
+class AidLN(C.Structure):
+    _fields_ = [("g", C.c_void_p), ("b", C.c_void_p)]
+
+
+class AidPolicyNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("A", C.c_int32), ("D", C.c_int32), ("_pad", C.c_int32),
+                ("enc0", AidLinear), ("enc_ln", AidLN), ("enc3", AidLinear), ("trunk", AidLinear * 3), ("trunk_ln", AidLN * 3),
+                ("mean0", AidLinear), ("mean2", AidLinear), ("lstd0", AidLinear), ("lstd2", AidLinear)]
+
+
+class AidValueNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("D", C.c_int32), ("TE", C.c_int32), ("_pad", C.c_int32), ("freq_scale", C.c_void_p),
+                ("te1", AidLinear), ("net", AidLinear * 3), ("ln", AidLN * 3), ("out", AidLinear)]
+
+
+class AidDynamicsNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("A", C.c_int32), ("D", C.c_int32), ("_pad", C.c_int32),
+                ("net", AidLinear * 3), ("ln", AidLN * 3), ("out", AidLinear)]
+
+
+class AidRewardNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("D", C.c_int32), ("l0", AidLinear), ("ln", AidLN), ("l3", AidLinear), ("l5", AidLinear)]
+
+
+class AidDecoderNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("O", C.c_int32), ("D", C.c_int32), ("_pad", C.c_int32),
+                ("s", AidLinear * 3), ("ln", AidLN * 3), ("out", AidLinear)]
+
+
+class AidEpistemicNet(C.Structure):
+    _fields_ = [("L", C.c_int32), ("O", C.c_int32), ("perturbation_scale", C.c_void_p),
+                ("fe0", AidLinear), ("fe2", AidLinear), ("fe4", AidLinear), ("jp0", AidLinear), ("jp_ln", AidLN), ("jp4", AidLinear),
+                ("lp0", AidLinear), ("lp2", AidLinear), ("mn0", AidLinear), ("mn3", AidLinear), ("mn6", AidLinear)]
+
+
+class AidDiffusionParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("prior_mean", "prior_log_std", "log_snr_min", "log_snr_max")]
+
+
+class AidElboNoise(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2")]
+
+
+class AidElboCfg(C.Structure):
+    _fields_ = [("kl_weight", C.c_float), ("diffusion_weight", C.c_float), ("reward_weight", C.c_float), ("gp_weight", C.c_float),
+                ("train", C.c_int32), ("first_call", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
+def _lin(params, name) -> AidLinear:
+    w = params[name + ".weight"]; b = params.get(name + ".bias")
+    l = AidLinear(); l.w = _ptr(w).value; l.b = _ptr(b).value if b is not None else None
+    l.in_, l.out = w.shape[1], w.shape[0]
+    return l
+
+
+def _ln(params, name) -> AidLN:
+    n = AidLN(); n.g = _ptr(params[name + ".weight"]).value; n.b = _ptr(params[name + ".bias"]).value
+    return n
+
+
+def policy_table(params, prefix="policy_network.") -> AidPolicyNet:
+    t = AidPolicyNet()
+    t.L = params[prefix + "latent_encoder.0.weight"].shape[1]; t.D = params[prefix + "latent_encoder.0.weight"].shape[0]
+    t.A = params[prefix + "mean_head.2.weight"].shape[0]
+    t.enc0 = _lin(params, prefix + "latent_encoder.0"); t.enc_ln = _ln(params, prefix + "latent_encoder.1"); t.enc3 = _lin(params, prefix + "latent_encoder.3")
+    for i, k in enumerate((0, 3, 6)):
+        t.trunk[i] = _lin(params, prefix + f"trunk.{k}"); t.trunk_ln[i] = _ln(params, prefix + f"trunk.{k + 1}")
+    t.mean0 = _lin(params, prefix + "mean_head.0"); t.mean2 = _lin(params, prefix + "mean_head.2")
+    t.lstd0 = _lin(params, prefix + "log_std_head.0"); t.lstd2 = _lin(params, prefix + "log_std_head.2")
+    return t
+
+
+def value_table(params, prefix="value_network.") -> AidValueNet:
+    t = AidValueNet()
+    t.TE = params[prefix + "time_embed.1.weight"].shape[0]; t.D = params[prefix + "network.0.weight"].shape[0]
+    t.L = params[prefix + "network.0.weight"].shape[1] - t.TE
+    t.freq_scale = _ptr(params[prefix + "time_embed.0.freq_scale"]).value
+    t.te1 = _lin(params, prefix + "time_embed.1")
+    for i, k in enumerate((0, 3, 6)):
+        t.net[i] = _lin(params, prefix + f"network.{k}"); t.ln[i] = _ln(params, prefix + f"network.{k + 1}")
+    t.out = _lin(params, prefix + "network.9")
+    return t
+
+
+def dynamics_table(params, A: int, prefix="latent_dynamics.") -> AidDynamicsNet:
+    t = AidDynamicsNet()
+    t.D = params[prefix + "network.0.weight"].shape[0]; t.A = A; t.L = params[prefix + "network.0.weight"].shape[1] - A
+    for i, k in enumerate((0, 3, 6)):
+        t.net[i] = _lin(params, prefix + f"network.{k}"); t.ln[i] = _ln(params, prefix + f"network.{k + 1}")
+    t.out = _lin(params, prefix + "network.9")
+    return t
+
+
+def reward_table(params, prefix="reward_predictor.") -> AidRewardNet:
+    t = AidRewardNet()
+    t.L = params[prefix + "0.weight"].shape[1]; t.D = params[prefix + "0.weight"].shape[0]
+    t.l0 = _lin(params, prefix + "0"); t.ln = _ln(params, prefix + "1"); t.l3 = _lin(params, prefix + "3"); t.l5 = _lin(params, prefix + "5")
+    return t
+
+
+def decoder_table(params, prefix="observation_decoder.") -> AidDecoderNet:
+    t = AidDecoderNet()
+    t.L = params[prefix + "0.0.weight"].shape[1]; t.O = params[prefix + "3.weight"].shape[0]; t.D = params[prefix + "3.weight"].shape[1]
+    for i in range(3):
+        t.s[i] = _lin(params, prefix + f"{i}.0"); t.ln[i] = _ln(params, prefix + f"{i}.1")
+    t.out = _lin(params, prefix + "3")
+    return t
+
+
+def epistemic_table(params, prefix="epistemic_estimator.") -> AidEpistemicNet:
+    t = AidEpistemicNet()
+    t.L = params[prefix + "latent_processor.0.weight"].shape[1]; t.O = params[prefix + "feature_extractor.0.weight"].shape[1]
+    t.perturbation_scale = _ptr(params[prefix + "perturbation_scale"]).value
+    t.fe0, t.fe2, t.fe4 = (_lin(params, prefix + f"feature_extractor.{k}") for k in (0, 2, 4))
+    t.jp0 = _lin(params, prefix + "jacobian_projector.0"); t.jp_ln = _ln(params, prefix + "jacobian_projector.1"); t.jp4 = _lin(params, prefix + "jacobian_projector.4")
+    t.lp0, t.lp2 = _lin(params, prefix + "latent_processor.0"), _lin(params, prefix + "latent_processor.2")
+    t.mn0, t.mn3, t.mn6 = (_lin(params, prefix + f"mine_network.{k}") for k in (0, 3, 6))
+    return t
+
+
+def diffusion_table(params, prefix="latent_diffusion.") -> AidDiffusionParams:
+    t = AidDiffusionParams()
+    t.prior_mean = _ptr(params[prefix + "latent_prior_mean"]).value; t.prior_log_std = _ptr(params[prefix + "latent_prior_log_std"]).value
+    t.log_snr_min = _ptr(params[prefix + "log_snr_min"]).value; t.log_snr_max = _ptr(params[prefix + "log_snr_max"]).value
+    return t
+
 _lib = None
 
 
@@ -77,7 +208,8 @@ def lib() -> C.CDLL:
     L = C.CDLL(LIB_PATH)
     L.aid_last_error.restype = C.c_char_p
     L.aid_version.restype = C.c_int
-    for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace"):
+    for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
+                 "aid_elbo_step_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -186,3 +318,61 @@ def prof_read(kernel_id: int):
     out = (C.c_double * 4)()
     check(lib().aid_prof_read(kernel_id, out), "aid_prof_read")
     return {"launches": int(out[0]), "ms": out[1], "flops": out[2], "bytes": out[3]}
+
+
+def decode_observation(dec: AidDecoderNet, z, masks=None, ws: Workspace = None):
+    B = z.shape[0]
+    out = torch.empty(B, dec.O, device=z.device, dtype=torch.float32)
+    ws = ws or Workspace(z.device)
+    buf = ws.get(lib().aid_decode_workspace(C.byref(dec), B))
+    m = masks or (None, None, None)
+    check(lib().aid_decode_observation(C.byref(dec), B, _ptr(z), _ptr(m[0]), _ptr(m[1]), _ptr(m[2]), _ptr(out), C.c_void_p(buf.data_ptr()),
+                                       C.c_size_t(buf.numel()), _stream()), "aid_decode_observation")
+    return out
+
+
+def belief_update(table: AidScoreNet, dec: AidDecoderNet, coefs, obs, n_steps, z_init=None, step_noise=None, drop_masks=None,
+                  dec_masks=None, train=True, seed=0, offset=0, ws: Workspace = None):
+    """-> (latent [B,L], stats [2L+1] = mean, std, reconstruction error)"""
+    B = obs.shape[0]
+    out = torch.empty(B, table.L, device=obs.device, dtype=torch.float32)
+    stats = torch.empty(2 * table.L + 1, device=obs.device, dtype=torch.float32)
+    ws = ws or Workspace(obs.device)
+    buf = ws.get(lib().aid_belief_update_workspace(C.byref(table), C.byref(dec), B, n_steps))
+    dm = (C.c_void_p * 3)(*[_ptr(m).value for m in dec_masks]) if dec_masks is not None else None
+    check(lib().aid_belief_update(C.byref(table), C.byref(dec), B, n_steps, _ptr(coefs), _ptr(obs), _ptr(z_init), _ptr(step_noise),
+                                  _ptr(drop_masks), dm, int(bool(train)), C.c_uint64(seed), C.c_uint64(offset), _ptr(out), _ptr(stats),
+                                  C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_belief_update")
+    return out, stats
+
+
+ELBO_METRICS = ("reconstruction_loss", "kl_loss", "score_matching_loss", "elbo", "reward_loss", "grad_penalty", "mean_time",
+                "loss_weight_mean", "loss")
+
+
+def elbo_step(net: AidScoreNet, grads: AidScoreNet, dp: AidDiffusionParams, dgrads: AidDiffusionParams, dec: AidDecoderNet,
+              rew: AidRewardNet, obs, rewards, latents, time_importance, first_call: bool, noise: dict = None, train=True,
+              kl_weight=0.1, diffusion_weight=1.0, reward_weight=0.5, gp_weight=0.1, seed=0, offset=0, ws: Workspace = None):
+    """compute_diffusion_elbo forward+backward; gradients accumulate into the `grads`/`dgrads` tables.
+    -> (metrics [16] device tensor, t [B], per_sample_losses [B])"""
+    B = obs.shape[0]
+    nz = AidElboNoise()
+    noise = noise or {}
+    for k, _ in AidElboNoise._fields_:
+        setattr(nz, k, _ptr(noise.get(k)).value)
+    cfg = AidElboCfg(kl_weight, diffusion_weight, reward_weight, gp_weight, int(bool(train)), int(bool(first_call)), seed, offset)
+    metrics = torch.zeros(16, device=obs.device, dtype=torch.float32)
+    t_out = torch.empty(B, device=obs.device, dtype=torch.float32)
+    per = torch.empty(B, device=obs.device, dtype=torch.float32)
+    ws = ws or Workspace(obs.device)
+    buf = ws.get(lib().aid_elbo_step_workspace(C.byref(net), C.byref(dec), B))
+    check(lib().aid_elbo_step(C.byref(net), C.byref(grads), C.byref(dp), C.byref(dgrads), C.byref(dec), C.byref(rew), B, _ptr(obs),
+                              _ptr(rewards), _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(time_importance), _ptr(t_out), _ptr(per),
+                              _ptr(metrics), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_elbo_step")
+    return metrics, t_out, per
+
+
+def adamw_step(p, g, m, v, ema, lr, weight_decay, step, clip_norm, scratch, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.9999):
+    check(lib().aid_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay),
+                               C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), C.c_float(ema_decay),
+                               _ptr(scratch), _stream()), "aid_adamw_step")

@@ -70,6 +70,8 @@ struct GemmArgs {
     float alpha;             // scale of the product
     int accumulate;          // 1: C += result (act must be NONE)
     const float* mask;       // optional [M,N] multiplicative mask applied after act (dropout), stride ldc
+    const float* dact_pre;   // optional [M,N] (stride ldc): multiply by act'(dact_pre) of kind `dact` (tangent /
+    int dact;                //   backward through an activation whose pre-activation was saved)
 };
 inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
     GemmArgs g; memset(&g, 0, sizeof(g));
@@ -111,9 +113,26 @@ struct ProfScope {
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case ACT_RELU: return x > 0.f ? x : 0.f;
-        case ACT_SILU: return x / (1.f + __expf(-x));
+        case ACT_SILU: return x / (1.f + expf(-x));
         case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
         default: return x;
+    }
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+// first / second derivative of the activations (SiLU, exact-erf GELU, ReLU)
+__device__ __forceinline__ float act_grad(float x, int act) {
+    switch (act) {
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_SILU: { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
+        case ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+        default: return 1.f;
+    }
+}
+__device__ __forceinline__ float act_grad2(float x, int act) {
+    switch (act) {
+        case ACT_SILU: { const float s = sigmoidf_(x); const float ds = s * (1.f - s); return ds * (2.f + x * (1.f - 2.f * s)); }
+        case ACT_GELU: return expf(-0.5f * x * x) * 0.3989422804014327f * (2.f - x * x);
+        default: return 0.f;
     }
 }
 __device__ __forceinline__ float wave_sum(float v) {

@@ -108,6 +108,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
     const size_t o = (size_t)row * g.ldc + col;
     if (g.preact) g.preact[o] = v;
     v = act_apply(v, g.act);
+    if (g.dact_pre) v *= act_grad(g.dact_pre[o], g.dact);
     if (g.mask) v *= g.mask[o];
     if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
     if (g.accumulate) v += g.C[o];
@@ -252,6 +253,137 @@ __global__ void __launch_bounds__(256) gemm_splitk_kernel(GemmArgs g, int tiles_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Panel kernel (the batch<=512 workhorse): 32x32 output tile, K streamed in 256-deep stages through a
+// 2-slot LDS ring by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, every byte fetched once per
+// workgroup in whole 128-B lines).  All of a stage's DMA is issued at once, so a K=512 layer has its
+// entire working set in flight before the first MFMA; deeper K keeps one stage (32 MFMAs per wave)
+// ahead.  The 4 waves split each stage's K four ways (one wave per SIMD) and reduce through LDS.
+// Synchronisation follows the CDNA4 rules for LDS-DMA: counted s_waitcnt vmcnt(N) by the issuing wave,
+// then a raw s_barrier before any wave reads the slot; a slot is re-filled only after a barrier that
+// every reader has passed.  One workgroup per CU (133 KB LDS) - these grids have <= ~4 tiles per CU.
+// Requirements (checked by the dispatcher): K % 256 == 0, 16-B aligned rows; k-major operands need
+// rows % 32 == 0.  k-contiguous operands clamp out-of-range rows (results discarded in the epilogue).
+// ------------------------------------------------------------------------------------------------
+constexpr int KS = 256;                      // k per stage
+typedef __attribute__((address_space(3))) void* lds_vptr;
+typedef const __attribute__((address_space(1))) void* gbl_vptr;
+
+template <bool KMAJOR>
+struct Panel {  // LDS image of one 32-row operand stage
+    static constexpr int LD = KMAJOR ? 32 : (KS + 4);
+    static constexpr int FLOATS = KMAJOR ? KS * 32 : 32 * (KS + 4);
+    static constexpr int DMA_PER_WAVE = 8;  // wave-instructions per stage per wave (32 total)
+};
+
+// issue this wave's share of one operand stage: 8 x global_load_lds_dwordx4 (1 KiB each)
+template <bool KMAJOR>
+__device__ __forceinline__ void panel_dma(const float* __restrict__ G, int ld, int r0, int R, int k0, float* slot,
+                                          int wave, int lane) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float* src; float* dst;
+        if (!KMAJOR) {  // one row (256 floats = 1 KiB) per instruction
+            const int r = wave * 8 + j;
+            int gr = r0 + r; gr = gr < R ? gr : R - 1;
+            src = G + (size_t)gr * ld + k0 + 4 * lane;
+            dst = slot + r * Panel<false>::LD;
+        } else {        // 8 k-rows x 128 B per instruction
+            const int kb = (wave * 8 + j) * 8;
+            src = G + (size_t)(k0 + kb + (lane >> 3)) * ld + r0 + 4 * (lane & 7);
+            dst = slot + kb * 32;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)dst, 16, 0, 0);
+    }
+}
+
+template <bool KMAJOR>
+__device__ __forceinline__ f32x4 panel_frag(const float* __restrict__ slot, int li, int k, int h) {
+    if (!KMAJOR) return *reinterpret_cast<const f32x4*>(slot + li * Panel<false>::LD + k + 4 * h);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = slot[(k + 4 * h + q) * 32 + li];
+    return v;
+}
+
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int FA = Panel<AKM>::FLOATS, FB = Panel<BKM>::FLOATS;
+    float* As = smem;             // 2 slots
+    float* Bs = smem + 2 * FA;    // 2 slots
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
+    const int ns = g.K / KS;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // prologue: up to two stages in flight
+    panel_dma<AKM>(g.A, g.lda, m0, g.M, 0, As, wave, lane);
+    panel_dma<BKM>(g.B, g.ldb, n0, g.N, 0, Bs, wave, lane);
+    if (ns > 1) {
+        panel_dma<AKM>(g.A, g.lda, m0, g.M, KS, As + FA, wave, lane);
+        panel_dma<BKM>(g.B, g.ldb, n0, g.N, KS, Bs + FB, wave, lane);
+    }
+    for (int st = 0; st < ns; ++st) {
+        const int cur = st & 1;
+        // retire stage `st` (older than anything issued after it): leave the younger stage in flight
+        if (st + 1 < ns) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* a_s = As + cur * FA;
+        const float* b_s = Bs + cur * FB;
+        const int kw = wave * (KS / 4);
+#pragma unroll
+        for (int g8 = 0; g8 < KS / 32; ++g8) {
+            const f32x4 av = panel_frag<AKM>(a_s, li, kw + 8 * g8, h);
+            const f32x4 bv = panel_frag<BKM>(b_s, li, kw + 8 * g8, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+        if (st + 2 < ns) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // every wave finished reading slot `cur`
+            panel_dma<AKM>(g.A, g.lda, m0, g.M, (st + 2) * KS, As + cur * FA, wave, lane);
+            panel_dma<BKM>(g.B, g.ldb, n0, g.N, (st + 2) * KS, Bs + cur * FB, wave, lane);
+        }
+    }
+    // cross-wave reduction through LDS (slot memory is dead after this barrier)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = smem;
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane];
+            epilogue_store(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v);
+        }
+    }
+}
+
+template <bool AKM, bool BKM>
+static int launch_panel(const GemmArgs& g, hipStream_t s) {
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    const size_t lds = sizeof(float) * 2 * (Panel<AKM>::FLOATS + Panel<BKM>::FLOATS);
+    static bool done = false;
+    if (!done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_panel_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_panel_kernel<AKM, BKM>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool AKM, bool BKM>
 static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -280,6 +412,10 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
 }
 template <bool AKM, bool BKM>
 static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
+    const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+    const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
+                          (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0) && t32 <= 1536;
+    if (panel_ok) return launch_panel<AKM, BKM>(g, s);
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     if (t128 >= 384) return launch_tile<128, 128, AKM, BKM>(g, vec, s);

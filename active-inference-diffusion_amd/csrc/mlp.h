@@ -1,0 +1,64 @@
+// MLP building blocks with saved activations (forward + hand-written backward) and the small networks
+// of the hot path: policy, value, dynamics, reward predictor, observation decoder.
+#pragma once
+#include "aid_common.h"
+#include "rowwise.h"
+#include "rowwise_bwd.h"
+
+namespace aid {
+
+int copy_cols(const float* src, int lds, float* dst, int ldd, int M, int nc, hipStream_t s);   // lds==0 broadcasts a row
+int axpby_cols(const float* a, int lda, float alpha, const float* b, int ldb, float beta, float* dst, int ldd, int M, int nc, hipStream_t s);
+
+// y = act(LN(x W^T + b)) * mask      (Linear -> LayerNorm -> activation [-> dropout])
+struct LlaSave { float *lin, *stats, *y; };
+int lla_alloc(int M, int out, Workspace& ws, LlaSave& sv);
+int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, const float* x, int ldx, int M, LlaSave& sv, hipStream_t s);
+// dy: gradient wrt sv.y [M,out].  Writes dx (optional, row stride lddx) ; accumulates parameter grads when gl/gln given.
+int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
+            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s);
+
+// y = act(x W^T + b) * mask            (Linear -> activation), pre-activation saved
+struct LaSave { float *pre, *y; };
+int la_alloc(int M, int out, bool need_pre, Workspace& ws, LaSave& sv);
+int la_fwd(const AidLinear& l, int act, const float* mask, const float* x, int ldx, int M, LaSave& sv, int ldy, hipStream_t s);
+// dy is overwritten (multiplied by act'(pre)*mask).
+int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, const float* x, int ldx, int M, const LaSave& sv,
+           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx = 0);
+
+// ---- observation decoder (state branch), aid/core/active_inference.py:237-242
+struct DecoderSave { LlaSave s0, s1, s2; float* h2; };
+size_t decoder_ws_bytes(const AidDecoderNet& d, int M);
+int decoder_fwd(const AidDecoderNet& d, int M, const float* z, int ldz, const float* const masks[3], float* out, int ldo, Workspace& ws,
+                hipStream_t s);
+
+// ---- reward predictor, aid/core/active_inference.py:164-171
+struct RewardSave { LlaSave s0; LaSave s1; float* out; };
+int reward_fwd(const AidRewardNet& r, int M, const float* z, int ldz, RewardSave& sv, Workspace& ws, hipStream_t s);
+// d_out: [M,2] gradient wrt the output (overwritten); dz accumulates? -> writes dz [M,L] (row stride lddz)
+int reward_bwd_data(const AidRewardNet& r, int M, const float* z, int ldz, const RewardSave& sv, float* d_out, float* dz, int lddz,
+                    Workspace& ws, hipStream_t s);
+
+// ---- dynamics, aid/models/dynamics_models.py:47-68 (+ the second residual of active_inference.py:461-462)
+struct DynSave { float* x; LlaSave s[3]; float* out; };   // x = [z | a]
+int dynamics_fwd(const AidDynamicsNet& d, int M, const float* z, int ldz, const float* a, int lda, float* next_mean, DynSave& sv,
+                 Workspace& ws, hipStream_t s);
+// d_next: gradient wrt next_mean = 2z + net([z|a]).  dz_out = 2 d_next + dx[:, :L] ; da_out = dx[:, L:]
+int dynamics_bwd(const AidDynamicsNet& d, const AidDynamicsNet* g, int M, const DynSave& sv, const float* d_next, float* dz_out,
+                 float* da_out, Workspace& ws, hipStream_t s);
+
+// ---- value network, aid/models/value_networks.py:47-60
+struct ValueSave { float *sin_e, *te_pre, *x; LlaSave s[3]; float* out; };   // x = [state | relu(te1(sinus(t)))]
+int value_fwd(const AidValueNet& v, int M, const float* state, int lds, const float* t, float* out, ValueSave& sv, Workspace& ws, hipStream_t s);
+// d_out [M] gradient wrt V.  dstate (optional) [M,L].  Parameter grads when g != null.
+int value_bwd(const AidValueNet& v, const AidValueNet* g, int M, const float* t, const ValueSave& sv, const float* d_out, float* dstate,
+              int ldds, Workspace& ws, hipStream_t s);
+
+// ---- policy, aid/models/policy_networks.py:95-146
+struct PolicySave { LlaSave e0; float* h; LlaSave tr[3]; float* h2; LaSave m0, s0; float *mean, *lstd, *action, *ent, *logp; };
+int policy_fwd(const AidPolicyNet& p, int M, const float* z, int ldz, const float* eps, PolicySave& sv, Workspace& ws, hipStream_t s);
+// d_action [M,A] (may be null = 0), ent_coef[M] = dLoss/d(entropy_sum) per row (may be null), accumulates param grads; dz optional
+int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
+               const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s);
+
+}  // namespace aid

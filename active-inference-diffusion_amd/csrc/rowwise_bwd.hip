@@ -1,0 +1,305 @@
+#include "rowwise_bwd.h"
+
+namespace aid {
+
+constexpr int RPB = 4;
+
+// ---------------------------------------------------------------------------------------------- colsum
+__global__ void colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int accumulate) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s = 0.f;
+    if (c < N) for (int r = w; r < M; r += 4) s += a[(size_t)r * lda + c];
+    red[w][lane] = s;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        out[c] = accumulate ? out[c] + v : v;
+    }
+}
+int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hipStream_t s) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, a, lda, out, M, N, accumulate);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- LN backward
+__global__ void ln_bwd_rows_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                   const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   int act, const float* __restrict__ mask, float* __restrict__ dx, int lddx,
+                                   float* __restrict__ dyeff, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    const float* xr = x + (size_t)row * ldx; const float* dyr = dy + (size_t)row * lddy;
+    float sg = 0.f, sgx = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * r;
+        float e = dyr[c];
+        if (mask) e *= mask[(size_t)row * D + c];
+        if (act != ACT_NONE) e *= act_grad(gamma ? xh * gamma[c] + beta[c] : xh, act);
+        const float g = gamma ? e * gamma[c] : e;
+        sg += g; sgx += g * xh;
+    }
+    sg = wave_sum(sg) / (float)D; sgx = wave_sum(sgx) / (float)D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (xr[c] - mean) * r;
+        float e = dyr[c];
+        if (mask) e *= mask[(size_t)row * D + c];
+        if (act != ACT_NONE) e *= act_grad(gamma ? xh * gamma[c] + beta[c] : xh, act);
+        if (dyeff) dyeff[(size_t)row * D + c] = e;
+        const float g = gamma ? e * gamma[c] : e;
+        if (dx) dx[(size_t)row * lddx + c] = r * (g - sg - xh * sgx);
+    }
+}
+int ln_bwd_rows(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
+                int act, const float* mask, float* dx, int lddx, float* dyeff, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3((M + RPB - 1) / RPB), dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, beta, act,
+                       mask, dx, lddx, dyeff, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void ln_param_grad_kernel(const float* __restrict__ dyeff, const float* __restrict__ x, int ldx,
+                                     const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                     int M, int D) {
+    __shared__ float rg[4][64], rb[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float sg = 0.f, sb = 0.f;
+    if (c < D) for (int r = w; r < M; r += 4) {
+        const float e = dyeff[(size_t)r * D + c];
+        sg += e * (x[(size_t)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
+        sb += e;
+    }
+    rg[w][lane] = sg; rb[w][lane] = sb;
+    __syncthreads();
+    if (w == 0 && c < D) {
+        dgamma[c] += rg[0][lane] + rg[1][lane] + rg[2][lane] + rg[3][lane];
+        dbeta[c] += rb[0][lane] + rb[1][lane] + rb[2][lane] + rb[3][lane];
+    }
+}
+int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dyeff, x, ldx, stats, dgamma, dbeta, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- adaLN dual backward
+__global__ void adaln_bwd_dual_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ stats,
+                                      const float* __restrict__ mod, int ldmod, const float* __restrict__ mu_nx,
+                                      const float* __restrict__ hd, const float* __restrict__ lam_nxd,
+                                      const float* __restrict__ mu_in, const float* __restrict__ lam_in,
+                                      float* __restrict__ mu_out, float* __restrict__ lam_out, float* __restrict__ dmod,
+                                      int lddmod, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    const size_t o = (size_t)row * D;
+    const float* hr = h + (size_t)row * ldh; const float* sc = mod + (size_t)row * ldmod;
+    const bool dual = lam_nxd != nullptr;
+    float s_hd = 0.f, s_xhd = 0.f, s_mg = 0.f, s_xmg = 0.f, s_la = 0.f, s_xla = 0.f, s_lahd = 0.f;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (hr[c] - mean) * r, one_s = 1.f + sc[c];
+        if (mu_nx) { const float mg = mu_nx[o + c] * one_s; s_mg += mg; s_xmg += mg * xh; }
+        if (dual) {
+            const float d = hd[o + c], la = lam_nxd[o + c] * one_s;
+            s_hd += d; s_xhd += xh * d; s_la += la; s_xla += xh * la; s_lahd += la * d;
+        }
+    }
+    const float invD = 1.f / (float)D;
+    s_mg = wave_sum(s_mg) * invD; s_xmg = wave_sum(s_xmg) * invD;
+    float p = 0.f, q = 0.f, A = 0.f;
+    if (dual) {
+        s_hd = wave_sum(s_hd) * invD; s_xhd = wave_sum(s_xhd) * invD; s_la = wave_sum(s_la) * invD;
+        s_xla = wave_sum(s_xla) * invD; s_lahd = wave_sum(s_lahd) * invD;
+        p = s_xhd; q = s_xla; A = s_lahd - s_la * s_hd;   // mean(lam_a * (hd - mean hd))
+    }
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (hr[c] - mean) * r, one_s = 1.f + sc[c];
+        float mu = mu_in ? mu_in[o + c] : 0.f;
+        float dscale = 0.f, dshift = 0.f;
+        if (mu_nx) {
+            const float m = mu_nx[o + c];
+            mu += r * (m * one_s - s_mg - xh * s_xmg);
+            dscale = m * xh; dshift = m;
+        }
+        if (dual) {
+            const float d = hd[o + c], ln = lam_nxd[o + c], la = ln * one_s;
+            const float hc = d - s_hd, lc = la - s_la;
+            const float a = r * (hc - xh * p);                     // T(h)[hd]
+            dscale += ln * a;
+            mu += -(r * r) * (xh * (A - 3.f * p * q) + q * hc + p * lc);
+            lam_out[o + c] = (lam_in ? lam_in[o + c] : 0.f) + r * (lc - xh * q);
+        }
+        mu_out[o + c] = mu;
+        if (dmod) { dmod[(size_t)row * lddmod + c] = dscale; dmod[(size_t)row * lddmod + D + c] = dshift; }
+    }
+}
+int adaln_bwd_dual(const float* h, int ldh, const float* stats, const float* mod, int ldmod, const float* mu_nx,
+                   const float* hd, const float* lam_nxd, const float* mu_in, const float* lam_in, float* mu_out,
+                   float* lam_out, float* dmod, int lddmod, int M, int D, hipStream_t s) {
+    hipLaunchKernelGGL(adaln_bwd_dual_kernel, dim3((M + RPB - 1) / RPB), dim3(256), 0, s, h, ldh, stats, mod, ldmod, mu_nx, hd,
+                       lam_nxd, mu_in, lam_in, mu_out, lam_out, dmod, lddmod, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void adaln_tangent_kernel(const float* __restrict__ h, int ldh, const float* __restrict__ stats,
+                                     const float* __restrict__ mod, int ldmod, const float* __restrict__ hd,
+                                     float* __restrict__ nxd, int M, int D) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    const size_t o = (size_t)row * D;
+    const float* hr = h + (size_t)row * ldh; const float* sc = mod + (size_t)row * ldmod;
+    float s_hd = 0.f, s_xhd = 0.f;
+    for (int c = lane; c < D; c += 64) { const float d = hd[o + c]; s_hd += d; s_xhd += (hr[c] - mean) * r * d; }
+    s_hd = wave_sum(s_hd) / (float)D; s_xhd = wave_sum(s_xhd) / (float)D;
+    for (int c = lane; c < D; c += 64) {
+        const float xh = (hr[c] - mean) * r;
+        nxd[o + c] = r * (hd[o + c] - s_hd - xh * s_xhd) * (1.f + sc[c]);
+    }
+}
+int adaln_tangent(const float* h, int ldh, const float* stats, const float* mod, int ldmod, const float* hd, float* nxd, int M,
+                  int D, hipStream_t s) {
+    hipLaunchKernelGGL(adaln_tangent_kernel, dim3((M + RPB - 1) / RPB), dim3(256), 0, s, h, ldh, stats, mod, ldmod, hd, nxd, M, D);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void act_bwd_dual_kernel(const float* __restrict__ pre, float* __restrict__ mu, float* __restrict__ lam,
+                                    const float* __restrict__ xd, int act, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const float x = pre[i], g1 = act_grad(x, act);
+        float m = mu[i] * g1;
+        if (lam) { const float l = lam[i]; m += l * xd[i] * act_grad2(x, act); lam[i] = l * g1; }
+        mu[i] = m;
+    }
+}
+int act_bwd_dual(const float* pre, float* mu, float* lam, const float* xd, int act, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(act_bwd_dual_kernel, dim3(blocks), dim3(256), 0, s, pre, mu, lam, xd, act, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- single-workgroup reductions
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x < 64) { t = (threadIdx.x < (blockDim.x >> 6)) ? sh[threadIdx.x] : 0.f; t = wave_sum(t); }
+    __syncthreads();
+    return t;  // valid in wave 0
+}
+
+__global__ void head_bwd_kernel(const float* __restrict__ raw, const float* __restrict__ d_score, const float* __restrict__ mult,
+                                const float* __restrict__ t, int mode, const float* __restrict__ rawd, float coef,
+                                float* __restrict__ mu_raw, float* __restrict__ lam_raw, float* __restrict__ dmult, int M, int L) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    const float mlt = mult[0];
+    for (int i = threadIdx.x; i < M * L; i += blockDim.x) {
+        const int row = i / L;
+        const float rv = raw[i];
+        const float inside = (rv >= -10.f && rv <= 10.f) ? 1.f : 0.f;
+        const bool cont = mode == 1 || (mode == 2 && t[row] <= 1.0f);
+        const float tw = cont ? sqrtf(1.0f / (1e-5f + t[row])) : 1.f;
+        if (rawd) {
+            lam_raw[i] = coef * inside * mlt * tw; mu_raw[i] = 0.f;
+            acc += coef * inside * tw * rawd[i];
+        } else {
+            const float ds = d_score ? d_score[i] : 1.f;
+            mu_raw[i] = ds * mlt * tw * inside;
+            acc += ds * fminf(fmaxf(rv, -10.f), 10.f) * tw;
+        }
+    }
+    const float tot = block_sum_1024(acc, sh);
+    if (dmult && threadIdx.x == 0) dmult[0] += tot;
+}
+int head_bwd(const float* raw, const float* d_score, const float* mult, const float* t, int mode, const float* rawd, float coef,
+             float* mu_raw, float* lam_raw, float* dmult, int M, int L, hipStream_t s) {
+    hipLaunchKernelGGL(head_bwd_kernel, dim3(1), dim3(1024), 0, s, raw, d_score, mult, t, mode, rawd, coef, mu_raw, lam_raw, dmult, M, L);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void sinusoid_bwd_kernel(const float* __restrict__ dsin, const float* __restrict__ t, const float* __restrict__ fs,
+                                    float tmul, int mode, float* __restrict__ dfs, int M, int dim) {
+    __shared__ float sh[16];
+    const int half = dim / 2;
+    const float negc = -(float)(9.210340371976184 / (double)(half - 1));
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < M * half; i += blockDim.x) {
+        const int row = i / half, k = i % half;
+        float tv = t[row];
+        const bool cont = mode == 1 || (mode == 2 && tv <= 1.0f);
+        if (cont) tv *= tmul;
+        const float base = tv * expf((float)k * negc);   // d(arg)/d(fs)
+        const float a = base * fs[0];
+        acc += (dsin[(size_t)row * dim + k] * cosf(a) - dsin[(size_t)row * dim + half + k] * sinf(a)) * base;
+    }
+    const float tot = block_sum_1024(acc, sh);
+    if (threadIdx.x == 0) dfs[0] += tot;
+}
+int sinusoid_bwd(const float* dsin, const float* t, const float* fs, float tmul, int mode, float* dfs, int M, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(sinusoid_bwd_kernel, dim3(1), dim3(1024), 0, s, dsin, t, fs, tmul, mode, dfs, M, dim);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void dot_accum_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float scale, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += a[i] * (b ? b[i] : 1.f);
+    const float tot = block_sum_1024(acc, sh);
+    if (threadIdx.x == 0) out[0] += scale * tot;
+}
+int dot_accum(const float* a, const float* b, size_t n, float scale, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(dot_accum_kernel, dim3(1), dim3(1024), 0, s, a, b, n, scale, out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void scale_by_ptr_kernel(const float* __restrict__ a, const float* __restrict__ sc, float* __restrict__ o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float k = sc[0];
+    for (; i < n; i += stride) o[i] = k * a[i];
+}
+int scale_by_ptr(const float* a, const float* scalar, float* out, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(scale_by_ptr_kernel, dim3(blocks), dim3(256), 0, s, a, scalar, out, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+__global__ void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) a[i] += b[i];
+}
+int add_inplace(float* a, const float* b, size_t n, hipStream_t s) {
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(blocks), dim3(256), 0, s, a, b, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+__global__ void gp_weights_kernel(const float* __restrict__ g, float* __restrict__ w, float* __restrict__ pen, int B, int L) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float n2 = 0.f;
+        for (int l = 0; l < L; ++l) { const float v = g[(size_t)b * L + l]; n2 += v * v; }
+        const float nrm = sqrtf(n2);
+        acc += (nrm - 1.f) * (nrm - 1.f);
+        const float k = nrm > 0.f ? (2.0f / (float)B) * (nrm - 1.f) / nrm : 0.f;
+        for (int l = 0; l < L; ++l) w[(size_t)b * L + l] = k * g[(size_t)b * L + l];
+    }
+    const float tot = block_sum_1024(acc, sh);
+    if (threadIdx.x == 0) pen[0] = tot / (float)B;
+}
+int gp_weights(const float* g, float* w, float* pen, int B, int L, hipStream_t s) {
+    hipLaunchKernelGGL(gp_weights_kernel, dim3(1), dim3(1024), 0, s, g, w, pen, B, L);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+}  // namespace aid

@@ -112,6 +112,86 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int n_steps, const float* co
                      uint64_t seed, uint64_t offset, float* z_out, float* traj, void* ws, size_t ws_bytes,
                      void* stream);
 
+
+/* ---- small networks (A4/A9/A10): parameter tables named after the reference modules -----------
+ * aid/models/policy_networks.py:42-71, value_networks.py:24-45, dynamics_models.py:28-45,
+ * aid/core/active_inference.py:111-131 (decoder), :164-171 (reward predictor), :886-919 (MINE). */
+typedef struct AidLinear { float *w, *b; int32_t in, out; } AidLinear;  /* torch Linear: w [out,in], b [out] (may be NULL) */
+typedef struct AidLN { float *g, *b; } AidLN;                           /* LayerNorm weight / bias */
+
+typedef struct AidPolicyNet {
+    int32_t L, A, D, _pad;
+    AidLinear enc0; AidLN enc_ln; AidLinear enc3;        /* latent_encoder.{0,1,3} */
+    AidLinear trunk[3]; AidLN trunk_ln[3];               /* trunk.{0,3,6} / {1,4,7} */
+    AidLinear mean0, mean2, lstd0, lstd2;                /* mean_head.{0,2}, log_std_head.{0,2} */
+} AidPolicyNet;
+typedef struct AidValueNet {
+    int32_t L, D, TE, _pad;
+    float* freq_scale;                                   /* time_embed.0.freq_scale */
+    AidLinear te1;                                       /* time_embed.1 */
+    AidLinear net[3]; AidLN ln[3]; AidLinear out;        /* network.{0,3,6}/{1,4,7}/9 */
+} AidValueNet;
+typedef struct AidDynamicsNet {
+    int32_t L, A, D, _pad;
+    AidLinear net[3]; AidLN ln[3]; AidLinear out;
+} AidDynamicsNet;
+typedef struct AidRewardNet { int32_t L, D; AidLinear l0; AidLN ln; AidLinear l3, l5; } AidRewardNet;
+typedef struct AidDecoderNet { int32_t L, O, D, _pad; AidLinear s[3]; AidLN ln[3]; AidLinear out; } AidDecoderNet;
+typedef struct AidEpistemicNet {
+    int32_t L, O;
+    float* perturbation_scale;
+    AidLinear fe0, fe2, fe4;                             /* feature_extractor.{0,2,4} */
+    AidLinear jp0; AidLN jp_ln; AidLinear jp4;           /* jacobian_projector.{0,1,4} */
+    AidLinear lp0, lp2;                                  /* latent_processor.{0,2} */
+    AidLinear mn0, mn3, mn6;                             /* mine_network.{0,3,6} */
+} AidEpistemicNet;
+typedef struct AidDiffusionParams { float *prior_mean, *prior_log_std, *log_snr_min, *log_snr_max; } AidDiffusionParams;
+
+/* decode_observation, state branch (active_inference.py:237-242).  masks: 3 scaled keep masks
+ * [B,2D],[B,2D],[B,D] (Dropout 0.2) or NULL pointers for eval mode. */
+size_t aid_decode_workspace(const AidDecoderNet* dec, int B);
+int aid_decode_observation(const AidDecoderNet* dec, int B, const float* z, const float* mask0, const float* mask1,
+                           const float* mask2, float* out, void* ws, size_t ws_bytes, void* stream);
+
+/* A4 update_belief_via_diffusion (active_inference.py:256-312): reverse loop + batch stats + decode + MSE.
+ * stats_out: [2L+1] = latent mean[L], unbiased std[L], reconstruction error.  dec_masks: 3 pointers or NULL. */
+size_t aid_belief_update_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B, int n_steps);
+int aid_belief_update(const AidScoreNet* net, const AidDecoderNet* dec, int B, int n_steps, const float* coefs,
+                      const float* obs, const float* z_init, const float* step_noise, const float* drop_masks,
+                      const float* const* dec_masks, int train, uint64_t seed, uint64_t offset, float* z_out,
+                      float* stats_out, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- A5/A7: compute_diffusion_elbo forward + backward (active_inference.py:533-636, 709-771) ---
+ * Gradients of loss = -elbo are ACCUMULATED into `grads` / `dgrads` (caller zeroes them): score net incl. the
+ * gradient-penalty double backward, log_snr_min/max, latent prior.  Decoder / reward-predictor gradients are
+ * not produced (the reference zeroes them before any optimiser step: state_agent.py:225).
+ * noise: any NULL member is drawn on device (Philox, seed/offset).  t NULL => uniform (first call) or importance
+ * sampled from time_importance[100] (later calls).  time_importance is updated in place (sequential EMA, K10).
+ * metrics (device, 16 floats): 0 recon, 1 kl, 2 score_matching, 3 elbo, 4 reward_nll, 5 grad_penalty,
+ * 6 mean_time, 7 loss_weight_mean, 8 loss(=-elbo). */
+typedef struct AidElboNoise {
+    const float *t, *eps, *prior_eps, *score_mask, *gp_mask, *dec_mask0, *dec_mask1, *dec_mask2;
+} AidElboNoise;
+typedef struct AidElboCfg {
+    float kl_weight, diffusion_weight, reward_weight, gp_weight;
+    int32_t train, first_call;
+    uint64_t seed, offset;
+} AidElboCfg;
+size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B);
+int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDiffusionParams* dp,
+                  const AidDiffusionParams* dgrads, const AidDecoderNet* dec, const AidRewardNet* rew, int B,
+                  const float* obs, const float* rewards, const float* latents, const AidElboNoise* noise,
+                  const AidElboCfg* cfg, float* time_importance, float* t_out, float* per_sample_out,
+                  float* metrics, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K15: clip_grad_norm_ -> AdamW -> EMA over one flat parameter arena (state_agent.py:152-158) ---
+ * p,g,m,v,(ema) are [n] float32 arenas.  All on device: the global L2 norm (deterministic two-stage
+ * reduction) lands in scratch[0], the clip coefficient min(1, clip/(norm+1e-6)) in scratch[1].
+ * step is 1-based.  ema may be NULL.  scratch: >= 4096 floats. */
+int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay,
+                   float beta1, float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

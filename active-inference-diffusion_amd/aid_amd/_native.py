@@ -110,6 +110,16 @@ class AidElboNoise(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2")]
 
 
+class AidEfeNoise(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("policy_eps", "reparam_eps", "mine_z_eps", "mine_delta", "proj_mask", "mine_mask", "perms")]
+
+
+class AidEfeCfg(C.Structure):
+    _fields_ = [("H", C.c_int32), ("K", C.c_int32), ("S", C.c_int32), ("train", C.c_int32), ("skip_epistemic", C.c_int32), ("_pad", C.c_int32),
+                ("epistemic_weight", C.c_float), ("pragmatic_weight", C.c_float), ("consistency_weight", C.c_float), ("discount", C.c_float),
+                ("temperature", C.c_float), ("mine_alpha", C.c_float), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
 class AidElboCfg(C.Structure):
     _fields_ = [("kl_weight", C.c_float), ("diffusion_weight", C.c_float), ("reward_weight", C.c_float), ("gp_weight", C.c_float),
                 ("train", C.c_int32), ("first_call", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
@@ -209,7 +219,8 @@ def lib() -> C.CDLL:
     L.aid_last_error.restype = C.c_char_p
     L.aid_version.restype = C.c_int
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
-                 "aid_elbo_step_workspace"):
+                 "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
+                 "aid_small_net_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -376,3 +387,127 @@ def adamw_step(p, g, m, v, ema, lr, weight_decay, step, clip_norm, scratch, beta
     check(lib().aid_adamw_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay),
                                C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), C.c_float(ema_decay),
                                _ptr(scratch), _stream()), "aid_adamw_step")
+
+
+EFE_INFO = ("policy_loss", "epistemic_mean", "pragmatic_mean", "consistency_mean", "epistemic/mi_estimate", "epistemic/joint_term",
+            "epistemic/marginal_term")
+
+
+def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizon=5, num_trajectories=10, num_samples=10, noise=None,
+             train=True, skip_epistemic=False, epistemic_weight=0.1, pragmatic_weight=1.0, consistency_weight=0.1, discount=0.99,
+             temperature=1.0, mine_alpha=0.01, seed=0, offset=0, ws: Workspace = None):
+    """compute_expected_free_energy_diffusion (+ policy backward when pgrads is given).
+    -> (efe [B], info [16] device tensor); running_mean (device scalar tensor) is updated in place."""
+    B = latents.shape[0]
+    nz = AidEfeNoise(); noise = noise or {}
+    for k, _ in AidEfeNoise._fields_:
+        v = noise.get(k)
+        if k == "perms" and v is not None:
+            assert v.dtype == torch.int32 and v.is_cuda and v.is_contiguous()
+            setattr(nz, k, v.data_ptr())
+        else:
+            setattr(nz, k, _ptr(v).value)
+    cfg = AidEfeCfg(horizon, num_trajectories, num_samples, int(bool(train)), int(bool(skip_epistemic)), 0, epistemic_weight, pragmatic_weight,
+                    consistency_weight, discount, temperature, mine_alpha, seed, offset)
+    efe = torch.empty(B, device=latents.device, dtype=torch.float32)
+    info = torch.zeros(16, device=latents.device, dtype=torch.float32)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_efe_step_workspace(C.byref(pol), C.byref(dec), B, C.byref(cfg)))
+    check(lib().aid_efe_step(C.byref(pol), C.byref(pgrads) if pgrads is not None else None, C.byref(dyn), C.byref(rew), C.byref(val),
+                             C.byref(dec), C.byref(epi), B, _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(running_mean), _ptr(efe), _ptr(info),
+                             C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_efe_step")
+    return efe, info
+
+
+def lambda_returns(rewards, next_values, dones, gamma=0.99, lam=0.95, n_steps=5):
+    out = torch.empty_like(rewards)
+    check(lib().aid_lambda_returns(_ptr(rewards), _ptr(next_values), _ptr(dones), rewards.shape[0], C.c_float(gamma), C.c_float(lam), n_steps,
+                                   _ptr(out), _stream()), "aid_lambda_returns")
+    return out
+
+
+def value_step(val, vgrads, latents, next_latents, rewards, dones, gamma=0.99, lam=0.95, n_steps=5, ws: Workspace = None):
+    """-> (loss device scalar, targets [B]); gradients accumulate into vgrads."""
+    B = latents.shape[0]
+    loss = torch.zeros(1, device=latents.device); targets = torch.empty(B, device=latents.device)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_value_step_workspace(C.byref(val), B))
+    check(lib().aid_value_step(C.byref(val), C.byref(vgrads), B, _ptr(latents), _ptr(next_latents), _ptr(rewards), _ptr(dones), C.c_float(gamma),
+                               C.c_float(lam), n_steps, _ptr(targets), _ptr(loss), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_value_step")
+    return loss, targets
+
+
+def dynamics_step(dyn, dgrads, latents, actions, next_latents, ws: Workspace = None):
+    B = latents.shape[0]
+    loss = torch.zeros(1, device=latents.device)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_dynamics_step_workspace(C.byref(dyn), B))
+    check(lib().aid_dynamics_step(C.byref(dyn), C.byref(dgrads), B, _ptr(latents), _ptr(actions), _ptr(next_latents), _ptr(loss),
+                                  C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_dynamics_step")
+    return loss
+
+
+def _small_ws(ws, device, B, D):
+    ws = ws or Workspace(device)
+    return ws.get(lib().aid_small_net_workspace(B, D))
+
+
+def policy_forward(pol, z, eps=None, ws: Workspace = None):
+    B = z.shape[0]
+    action = torch.empty(B, pol.A, device=z.device); logp = torch.empty(B, device=z.device); ent = torch.empty(B, device=z.device)
+    buf = _small_ws(ws, z.device, B, pol.D)
+    check(lib().aid_policy_forward(C.byref(pol), B, _ptr(z), _ptr(eps), _ptr(action), _ptr(logp), _ptr(ent), C.c_void_p(buf.data_ptr()),
+                                   C.c_size_t(buf.numel()), _stream()), "aid_policy_forward")
+    return action, logp, ent
+
+
+def value_forward(val, state, t, ws: Workspace = None):
+    B = state.shape[0]
+    out = torch.empty(B, 1, device=state.device)
+    buf = _small_ws(ws, state.device, B, val.D)
+    check(lib().aid_value_forward(C.byref(val), B, _ptr(state), _ptr(t), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_value_forward")
+    return out
+
+
+def predict_next_latent(dyn, z, a, ws: Workspace = None):
+    B = z.shape[0]
+    out = torch.empty(B, dyn.L, device=z.device)
+    buf = _small_ws(ws, z.device, B, dyn.D)
+    check(lib().aid_predict_next_latent(C.byref(dyn), B, _ptr(z), _ptr(a), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_predict_next_latent")
+    return out
+
+
+def reward_forward(rew, z, ws: Workspace = None):
+    B = z.shape[0]
+    out = torch.empty(B, 2, device=z.device)
+    buf = _small_ws(ws, z.device, B, rew.D)
+    check(lib().aid_reward_forward(C.byref(rew), B, _ptr(z), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_reward_forward")
+    return out
+
+
+def replay_gather(obs, next_obs, actions, rewards, dones, idx):
+    B, O, A = idx.shape[0], obs.shape[1], actions.shape[1]
+    assert idx.dtype == torch.int64 and idx.is_cuda
+    dev = obs.device
+    o, n, a = torch.empty(B, O, device=dev), torch.empty(B, O, device=dev), torch.empty(B, A, device=dev)
+    r, d = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    check(lib().aid_replay_gather(_ptr(obs), _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), C.c_void_p(idx.data_ptr()), B, O, A,
+                                  _ptr(o), _ptr(n), _ptr(a), _ptr(r), _ptr(d), _stream()), "aid_replay_gather")
+    return o, n, a, r, d
+
+
+def fokker_planck_step(mean, var, obs, score, xi, dt=0.01, D=0.1, lr=0.1, noise_scale=0.01, min_var=1e-6, max_var=10.0, want_entropy=True):
+    """In-place fp64 diagonal belief step over [n, L] tensors; returns entropy [n] (or None)."""
+    for t in (mean, var, obs, score, xi):
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    n, L = mean.shape
+    ent = torch.empty(n, device=mean.device, dtype=torch.float64) if want_entropy else None
+    check(lib().aid_fokker_planck_step(C.c_void_p(mean.data_ptr()), C.c_void_p(var.data_ptr()), C.c_void_p(obs.data_ptr()),
+                                       C.c_void_p(score.data_ptr()), C.c_void_p(xi.data_ptr()), n, L, C.c_double(dt), C.c_double(D), C.c_double(lr),
+                                       C.c_double(noise_scale), C.c_double(min_var), C.c_double(max_var),
+                                       C.c_void_p(ent.data_ptr()) if ent is not None else None, _stream()), "aid_fokker_planck_step")
+    return ent

@@ -1,0 +1,345 @@
+// Expected-Free-Energy horizon rollout + MINE epistemic estimator, forward and policy backward.
+// Reference: aid/core/active_inference.py:314-396 (rollout), :398-418 + :940-1063 (estimator), :815-836 (EMA loss).
+//
+// MI355X-first restructuring (results unchanged): the K=10 trajectories start from the same latent and are
+// independent, so they are batched into M = K*B rows per horizon step (2 560-row GEMMs instead of 256-row
+// ones); the estimator's K*S*B = 25 600 sample rows per step run as large MFMA GEMMs; per-(k,t) MINE
+// statistics become segmented reductions, and the running-mean EMA - the only order-dependent piece - is
+// replayed afterwards in the reference's (k outer, t inner) order.  The epistemic value carries no gradient
+// (computed under no_grad in the reference), so the backward is BPTT over H steps through
+// policy -> dynamics -> {reward, value} with parameter gradients for the policy only.
+#include "mlp.h"
+#include "score_net.h"   // philox_fill
+
+namespace aid {
+
+__device__ __forceinline__ float wg_sum(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x < 64) { t = (threadIdx.x < (blockDim.x >> 6)) ? sh[threadIdx.x] : 0.f; t = wave_sum(t); }
+    return t;
+}
+
+__global__ void reparam_kernel(const float* __restrict__ mean, const float* __restrict__ eps, float sd, float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = mean[i] + eps[i] * sd;
+}
+// z_all[(k*S+s)*B + b] = next_mean[k*B + b] + eps * std          (active_inference.py:1009-1014)
+__global__ void mine_sample_kernel(const float* __restrict__ nm, const float* __restrict__ eps, float sd, float* __restrict__ z,
+                                   int K, int S, int B, int L) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)K * S * B * L;
+    if (i >= n) return;
+    const int l = i % L; const size_t r = i / L;
+    const int b = r % B; const int k = (r / B) / S;
+    z[i] = nm[((size_t)k * B + b) * L + l] + eps[i] * sd;
+}
+// zp = z + normalize(delta) * eps_scale (F.normalize: / max(||d||, 1e-12))   (:962)
+__global__ void perturb_kernel(const float* __restrict__ z, const float* __restrict__ d, const float* __restrict__ scale,
+                               float* __restrict__ zp, size_t R, int L) {
+    const size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float n2 = 0.f;
+    for (int l = 0; l < L; ++l) { const float v = d[r * L + l]; n2 += v * v; }
+    const float inv = scale[0] / fmaxf(sqrtf(n2), 1e-12f);
+    for (int l = 0; l < L; ++l) zp[r * L + l] = z[r * L + l] + d[r * L + l] * inv;
+}
+__global__ void fd_kernel(const float* __restrict__ fp, const float* __restrict__ fz, const float* __restrict__ scale,
+                          float* __restrict__ out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (fp[i] - fz[i]) / scale[0];
+}
+// marginal features: rows of each (k,s) block permuted (:1029-1039); copies `nc` columns
+__global__ void perm_rows_kernel(const float* __restrict__ src, int lds, const int32_t* __restrict__ perms, float* __restrict__ dst,
+                                 int ldd, size_t R, int B, int nc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * nc) return;
+    const size_t r = i / nc; const int c = i % nc;
+    const size_t blk = r / B;
+    const size_t sr = blk * B + (size_t)perms[r];
+    dst[r * ldd + c] = src[sr * lds + c];
+}
+// one workgroup per trajectory k: joint mean, log-mean-exp of the marginal statistics, t_exp, MI  (:1046-1053,828-836)
+__global__ void mine_reduce_kernel(const float* __restrict__ tj, const float* __restrict__ tm, int n, float* __restrict__ out /*[K][4]*/) {
+    __shared__ float sh[16];
+    __shared__ float s_mx;
+    const float* a = tj + (size_t)blockIdx.x * n; const float* m = tm + (size_t)blockIdx.x * n;
+    float acc = 0.f, mx = -3.4e38f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { acc += a[i]; mx = fmaxf(mx, m[i]); }
+    const float js = wg_sum(acc, sh);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) { float v = sh[0]; for (int w = 1; w < (int)(blockDim.x >> 6); ++w) v = fmaxf(v, sh[w]); s_mx = v; }
+    __syncthreads();
+    const float gmx = s_mx;
+    float e0 = 0.f, e1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { e0 += expf(m[i]); e1 += expf(m[i] - gmx); }
+    const float es = wg_sum(e0, sh); const float es1 = wg_sum(e1, sh);
+    if (threadIdx.x == 0) {
+        const float joint = js / (float)n;
+        const float tlog = logf(es / (float)n);                               // EMALoss.forward: x.exp().mean().log()
+        const float texp = expf((gmx + logf(es1)) - logf((float)n));          // exp(logsumexp(x) - log n)
+        out[4 * blockIdx.x + 0] = joint; out[4 * blockIdx.x + 1] = tlog; out[4 * blockIdx.x + 2] = texp;
+        out[4 * blockIdx.x + 3] = joint - tlog;
+    }
+}
+// traj_efe += gamma^t (ew*epi + pw*prag + cw*cons), prag = pw*r/tau + V, cons = -entropy, epi = clamp(mi_k, 0)
+__global__ void efe_accum_kernel(const float* __restrict__ rout, const float* __restrict__ V, const float* __restrict__ ent,
+                                 const float* __restrict__ mine /*[K][4] or null*/, float gt, float ew, float pw, float cw, float tau,
+                                 float* __restrict__ acc, float* __restrict__ prag_out, float* __restrict__ cons_out, int M, int B, int first) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= M) return;
+    const float prag = pw * (rout[2 * r] / tau) + V[r];
+    const float cons = -ent[r];
+    const float epi = mine ? fmaxf(mine[4 * (r / B) + 3], 0.f) : 0.f;
+    const float step = ew * epi + pw * prag + cw * cons;
+    acc[r] = (first ? 0.f : acc[r]) + gt * step;
+    prag_out[r] = prag; cons_out[r] = cons;
+}
+__global__ void efe_final_kernel(const float* __restrict__ acc, const float* __restrict__ prag, const float* __restrict__ cons,
+                                 const float* __restrict__ mine, int K, int B, float* __restrict__ efe, float* __restrict__ info) {
+    __shared__ float sh[16];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        float t = 0.f;
+        for (int k = 0; k < K; ++k) t += acc[(size_t)k * B + b] / (float)K;
+        efe[b] = t; a0 += t;
+    }
+    for (int r = threadIdx.x; r < K * B; r += blockDim.x) { a1 += prag[r]; a2 += cons[r]; }
+    const float s0 = wg_sum(a0, sh); const float s1 = wg_sum(a1, sh); const float s2 = wg_sum(a2, sh);
+    if (threadIdx.x == 0) {
+        info[0] = s0 / (float)B; info[2] = s1 / (float)(K * B); info[3] = s2 / (float)(K * B);
+        float e = 0.f;
+        if (mine) { for (int k = 0; k < K; ++k) e += fmaxf(mine[4 * k + 3], 0.f); e /= (float)K;
+                    info[4] = mine[4 * (K - 1) + 3]; info[5] = mine[4 * (K - 1) + 0]; info[6] = mine[4 * (K - 1) + 1]; }
+        info[1] = e;
+    }
+}
+// EMA of ema_loss (:828-836) replayed in the reference order: k outer, t inner.  texp: [H][K][4] (slot 2)
+__global__ void running_mean_kernel(const float* __restrict__ mine_all, int H, int K, float alpha, float* __restrict__ rm) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float r = rm[0];
+    for (int k = 0; k < K; ++k)
+        for (int t = 0; t < H; ++t) {
+            const float te = mine_all[((size_t)t * K + k) * 4 + 2];
+            if (r == 0.f) r = te;
+            else r = (alpha * te) + (float)((1.0 - (double)alpha) * (double)r);
+        }
+    rm[0] = r;
+}
+__global__ void fill_pair_kernel(float* __restrict__ p, float v0, float v1, int M) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < M) { p[2 * r] = v0; p[2 * r + 1] = v1; }
+}
+__global__ void add3_kernel(const float* __restrict__ a, const float* __restrict__ b, const float* __restrict__ c, float* __restrict__ o, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) o[i] = (a ? a[i] : 0.f) + b[i] + c[i];
+}
+__global__ void tile_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int K, size_t n) {   // dst[k] = src for k<K
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n * K) dst[i] = src[i % n];
+}
+// random permutation of 0..B-1 per block: bitonic sort of (random key, index) in LDS.  B <= 2048.
+__global__ void randperm_blocks_kernel(const float* __restrict__ keys, int32_t* __restrict__ perms, int B, int P2) {
+    extern __shared__ float sm[];
+    float* kk = sm; int32_t* ix = (int32_t*)(sm + P2);
+    const size_t base = (size_t)blockIdx.x * B;
+    for (int i = threadIdx.x; i < P2; i += blockDim.x) { kk[i] = i < B ? keys[base + i] : 3.0f; ix[i] = i; }
+    __syncthreads();
+    for (int k = 2; k <= P2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < P2; i += blockDim.x) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const bool up = (i & k) == 0;
+                    const bool sw = up ? (kk[i] > kk[l] || (kk[i] == kk[l] && ix[i] > ix[l])) : (kk[i] < kk[l] || (kk[i] == kk[l] && ix[i] < ix[l]));
+                    if (sw) { const float tk = kk[i]; kk[i] = kk[l]; kk[l] = tk; const int32_t ti = ix[i]; ix[i] = ix[l]; ix[l] = ti; }
+                }
+            }
+            __syncthreads();
+        }
+    for (int i = threadIdx.x; i < B; i += blockDim.x) perms[base + i] = ix[i];
+}
+
+#define LAUNCH1D(kern, n, s, ...)                                                                         \
+    do {                                                                                                  \
+        if ((n) > 0) { hipLaunchKernelGGL(kern, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s, __VA_ARGS__); AID_LAUNCH_CHECK(); } \
+    } while (0)
+
+// ---- MINE forward for one horizon step, all K trajectories: fills mine_out [K][4]
+static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int K, int S, int B, const float* next_mean,
+                        const float* z_eps, const float* delta, const float* proj_mask, const float* mine_mask, const int32_t* perms,
+                        bool train, float* mine_out, Workspace& ws, hipStream_t s) {
+    const int L = e.L, O = e.O;
+    const size_t R = (size_t)K * S * B;
+    const int Rm = (int)R;
+    const size_t mark = ws.mark();
+    float* z_all = ws.f32(R * L); float* zp = ws.f32(R * L); float* fz = ws.f32(R * O); float* fp = ws.f32(R * O);
+    float* f0 = ws.f32(R * e.fe0.out); float* f1 = ws.f32(R * e.fe2.out);
+    float* jin = ws.f32(R * 4 * e.fe4.out);
+    float* comb = ws.f32(R * (e.jp4.out + e.lp2.out)); float* comb_m = ws.f32(R * (e.jp4.out + e.lp2.out));
+    float* l0 = ws.f32(R * e.lp0.out);
+    float* m0 = ws.f32(R * e.mn0.out); float* m1 = ws.f32(R * e.mn3.out); float* tj = ws.f32(R); float* tm = ws.f32(R);
+    LlaSave pj; lla_alloc(Rm, e.jp0.out, ws, pj);
+    AID_WS_OK(ws);
+    const float sd = sqrtf(0.1f);   // exp(0.5 * ln 0.1)  (predict_next_latent :463)
+    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), z_all, K, S, B, L);
+    (void)sd;
+    AID_TRY(decoder_fwd(dec, Rm, z_all, L, nullptr, fz, O, ws, s));           // decoder in eval mode (:949)
+    const int FE = e.fe4.out, CW = e.jp4.out + e.lp2.out;
+    for (int j = 0; j < 4; ++j) {
+        LAUNCH1D(perturb_kernel, R, s, z_all, delta + (size_t)j * R * L, e.perturbation_scale, zp, R, L);
+        AID_TRY(decoder_fwd(dec, Rm, zp, L, nullptr, fp, O, ws, s));
+        LAUNCH1D(fd_kernel, R * O, s, fp, fz, e.perturbation_scale, fp, R * O);
+        AID_TRY(linear_fwd(fp, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, Rm, e.fe0.out, O, ACT_RELU, s));
+        AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, Rm, e.fe2.out, e.fe0.out, ACT_RELU, s));
+        AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin + (size_t)j * FE, 4 * FE, Rm, FE, e.fe2.out, ACT_NONE, s));
+    }
+    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s));
+    AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, comb, CW, Rm, e.jp4.out, e.jp0.out, ACT_NONE, s));
+    AID_TRY(linear_fwd(z_all, L, e.lp0.w, e.lp0.b, l0, e.lp0.out, Rm, e.lp0.out, L, ACT_RELU, s));
+    AID_TRY(linear_fwd(l0, e.lp0.out, e.lp2.w, e.lp2.b, comb + e.jp4.out, CW, Rm, e.lp2.out, e.lp0.out, ACT_NONE, s));
+    const size_t MSZ = R * e.mn0.out;
+    auto mine_net = [&](const float* x, const float* k0, const float* k1, float* out) -> int {
+        AID_TRY(linear_fwd(x, CW, e.mn0.w, e.mn0.b, m0, e.mn0.out, Rm, e.mn0.out, CW, ACT_RELU, s, nullptr, nullptr, 0, train ? k0 : nullptr));
+        AID_TRY(linear_fwd(m0, e.mn0.out, e.mn3.w, e.mn3.b, m1, e.mn3.out, Rm, e.mn3.out, e.mn0.out, ACT_RELU, s, nullptr, nullptr, 0, train ? k1 : nullptr));
+        AID_TRY(linear_fwd(m1, e.mn3.out, e.mn6.w, e.mn6.b, out, 1, Rm, 1, e.mn3.out, ACT_NONE, s));
+        return AID_OK;
+    };
+    AID_TRY(mine_net(comb, mine_mask, mine_mask + MSZ, tj));
+    LAUNCH1D(perm_rows_kernel, R * e.jp4.out, s, comb, CW, perms, comb_m, CW, R, B, e.jp4.out);
+    AID_TRY(copy_cols(comb + e.jp4.out, CW, comb_m + e.jp4.out, CW, Rm, e.lp2.out, s));
+    AID_TRY(mine_net(comb_m, mine_mask + 2 * MSZ, mine_mask + 3 * MSZ, tm));
+    hipLaunchKernelGGL(mine_reduce_kernel, dim3(K), dim3(1024), 0, s, tj, tm, S * B, mine_out);
+    AID_LAUNCH_CHECK();
+    ws.release(mark);
+    return AID_OK;
+}
+
+static size_t mine_ws_bytes(const AidDecoderNet& dec, int K, int S, int B) {
+    const size_t R = (size_t)K * S * B;
+    return decoder_ws_bytes(dec, (int)R) + sizeof(float) * R * (2 * 128 + 2 * dec.O + 128 + 256 + 512 + 2 * 384 + 128 + 1024 + 2 + 1024 + 16) + (1 << 16);
+}
+
+}  // namespace aid
+
+using namespace aid;
+
+extern "C" {
+
+size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg) {
+    if (!pol || !dec || !cfg || B <= 0) return 0;
+    const size_t M = (size_t)cfg->K * B, R = M * cfg->S, D = pol->D, H = cfg->H;
+    size_t n = mine_ws_bytes(*dec, cfg->K, cfg->S, B);
+    n += sizeof(float) * H * M * (40 * D + 64);                       // per-step saved activations (policy, dynamics, reward, value)
+    n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
+    n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
+    n += sizeof(int32_t) * H * R + (1 << 20);
+    return n;
+}
+
+int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
+                 const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
+                 const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, void* wsp,
+                 size_t ws_bytes, void* stream) {
+    AID_REQUIRE(pol && dyn && rew && val && dec && epi && latents && noise && cfg && running_mean && efe_out && info, AID_E_NULL,
+                "aid_efe_step: null argument");
+    const int H = cfg->H, K = cfg->K, S = cfg->S, L = pol->L, A = pol->A;
+    AID_REQUIRE(B > 0 && H > 0 && K > 0 && S > 0 && B <= 2048, AID_E_SHAPE, "aid_efe_step: B=%d H=%d K=%d S=%d", B, H, K, S);
+    hipStream_t s = (hipStream_t)stream;
+    const int M = K * B; const size_t R = (size_t)M * S;
+    const bool train = cfg->train != 0, do_epi = !cfg->skip_epistemic;
+    Workspace ws(wsp, ws_bytes);
+    uint64_t ctr = cfg->offset;
+    auto draw = [&](const float* given, size_t cnt, int kind, float p, const float** out) -> int {
+        if (given) { *out = given; return AID_OK; }
+        float* buf = ws.f32(cnt); AID_WS_OK(ws);
+        AID_TRY(philox_fill(buf, cnt, kind, p, cfg->seed, ctr, s)); ctr += (cnt + 3) / 4; *out = buf; return AID_OK;
+    };
+    const float *pol_eps, *rep_eps, *z_eps = nullptr, *delta = nullptr, *pmask = nullptr, *mmask = nullptr;
+    const int32_t* perms = noise->perms;
+    AID_TRY(draw(noise->policy_eps, (size_t)H * M * A, 0, 0.f, &pol_eps));
+    AID_TRY(draw(noise->reparam_eps, (size_t)H * M * L, 0, 0.f, &rep_eps));
+    if (do_epi) {
+        AID_TRY(draw(noise->mine_z_eps, (size_t)H * R * L, 0, 0.f, &z_eps));
+        AID_TRY(draw(noise->mine_delta, (size_t)H * 4 * R * L, 0, 0.f, &delta));
+        if (train) {
+            AID_TRY(draw(noise->proj_mask, (size_t)H * R * epi->jp0.out, 2, 0.1f, &pmask));
+            AID_TRY(draw(noise->mine_mask, (size_t)H * 4 * R * epi->mn0.out, 2, 0.1f, &mmask));
+        }
+        if (!perms) {
+            const float* keys; AID_TRY(draw(nullptr, (size_t)H * R, 1, 0.f, &keys));
+            int32_t* pb = (int32_t*)ws.raw(sizeof(int32_t) * (size_t)H * R); AID_WS_OK(ws);
+            int P2 = 1; while (P2 < B) P2 <<= 1;
+            hipLaunchKernelGGL(randperm_blocks_kernel, dim3((unsigned)(H * K * S)), dim3(256), (size_t)P2 * 8, s, keys, pb, B, P2);
+            AID_LAUNCH_CHECK(); perms = pb;
+        }
+    }
+    // ---- per-step saved state
+    struct Step { float* cur; float* next_mean; float* nxt; PolicySave ps; DynSave ds; RewardSave rs; ValueSave vs; float* V; float* tvec; };
+    Step st[16];
+    AID_REQUIRE(H <= 16, AID_E_SHAPE, "aid_efe_step: horizon %d > 16", H);
+    float* acc = ws.f32(M); float* prag = ws.f32(M); float* cons = ws.f32(M);
+    float* mine_all = ws.f32((size_t)H * K * 4);
+    float* lat_rep = ws.f32((size_t)M * L);
+    AID_WS_OK(ws);
+    LAUNCH1D(tile_rows_kernel, (size_t)M * L, s, latents, lat_rep, K, (size_t)B * L);   // latent.clone() per trajectory
+    const float sd = expf(0.5f * logf(0.1f));
+    const float* cur = lat_rep;
+    for (int t = 0; t < H; ++t) {
+        Step& q = st[t];
+        q.cur = (float*)cur; q.next_mean = ws.f32((size_t)M * L); q.nxt = ws.f32((size_t)M * L); q.V = ws.f32(M); q.tvec = ws.f32(M);
+        AID_WS_OK(ws);
+        AID_TRY(policy_fwd(*pol, M, cur, L, pol_eps + (size_t)t * M * A, q.ps, ws, s));
+        AID_TRY(dynamics_fwd(*dyn, M, cur, L, q.ps.action, A, q.next_mean, q.ds, ws, s));
+        LAUNCH1D(reparam_kernel, (size_t)M * L, s, q.next_mean, rep_eps + (size_t)t * M * L, sd, q.nxt, (size_t)M * L);
+        AID_TRY(reward_fwd(*rew, M, q.nxt, L, q.rs, ws, s));
+        AID_TRY(fill_const(q.tvec, (float)t, M, s));
+        AID_TRY(value_fwd(*val, M, q.nxt, L, q.tvec, q.V, q.vs, ws, s));
+        float* mine_t = nullptr;
+        if (do_epi) {
+            mine_t = mine_all + (size_t)t * K * 4;
+            AID_TRY(mine_forward(*dec, *epi, K, S, B, q.next_mean, z_eps + (size_t)t * R * L, delta + (size_t)t * 4 * R * L,
+                                 train ? pmask + (size_t)t * R * epi->jp0.out : nullptr, train ? mmask + (size_t)t * 4 * R * epi->mn0.out : nullptr,
+                                 perms + (size_t)t * R, train, mine_t, ws, s));
+        }
+        LAUNCH1D(efe_accum_kernel, M, s, q.rs.out, q.V, q.ps.ent, mine_t, powf(cfg->discount, (float)t), cfg->epistemic_weight,
+                 cfg->pragmatic_weight, cfg->consistency_weight, cfg->temperature, acc, prag, cons, M, B, t == 0);
+        cur = q.nxt;
+    }
+    hipLaunchKernelGGL(efe_final_kernel, dim3(1), dim3(1024), 0, s, acc, prag, cons, do_epi ? mine_all + (size_t)(H - 1) * K * 4 : nullptr, K, B, efe_out, info);
+    AID_LAUNCH_CHECK();
+    if (do_epi) { hipLaunchKernelGGL(running_mean_kernel, dim3(1), dim3(64), 0, s, mine_all, H, K, cfg->mine_alpha, running_mean); AID_LAUNCH_CHECK(); }
+    if (!pgrads) return AID_OK;
+
+    // ---- backward (BPTT): policy_loss = mean_b efe_b
+    float* d_r = ws.f32((size_t)M * 2); float* d_v = ws.f32(M); float* entc = ws.f32(M);
+    float* dz_r = ws.f32((size_t)M * L); float* dz_v = ws.f32((size_t)M * L); float* dnxt = ws.f32((size_t)M * L);
+    float* dz_dyn = ws.f32((size_t)M * L); float* dz_pol = ws.f32((size_t)M * L); float* da = ws.f32((size_t)M * A);
+    float* carry = ws.f32((size_t)M * L);
+    AID_WS_OK(ws);
+    bool have_carry = false;
+    for (int t = H - 1; t >= 0; --t) {
+        Step& q = st[t];
+        const float c = powf(cfg->discount, (float)t) * cfg->pragmatic_weight / ((float)K * (float)B);   // dLoss/dprag
+        LAUNCH1D(fill_pair_kernel, M, s, d_r, c * cfg->pragmatic_weight / cfg->temperature, 0.f, M);
+        AID_TRY(fill_const(d_v, c, M, s));
+        AID_TRY(fill_const(entc, -powf(cfg->discount, (float)t) * cfg->consistency_weight / ((float)K * (float)B), M, s));
+        AID_TRY(reward_bwd_data(*rew, M, q.nxt, L, q.rs, d_r, dz_r, L, ws, s));
+        AID_TRY(value_bwd(*val, nullptr, M, q.tvec, q.vs, d_v, dz_v, L, ws, s));
+        LAUNCH1D(add3_kernel, (size_t)M * L, s, have_carry ? carry : nullptr, dz_r, dz_v, dnxt, (size_t)M * L);
+        AID_TRY(dynamics_bwd(*dyn, nullptr, M, q.ds, dnxt, dz_dyn, da, ws, s));
+        AID_TRY(policy_bwd(*pol, pgrads, M, q.cur, L, pol_eps + (size_t)t * M * A, q.ps, da, entc, t > 0 ? dz_pol : nullptr, L, ws, s));
+        if (t > 0) { LAUNCH1D(add3_kernel, (size_t)M * L, s, (const float*)nullptr, dz_dyn, dz_pol, carry, (size_t)M * L); have_carry = true; }
+    }
+    return AID_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,219 @@
+// lambda-returns, value / dynamics optimiser phases, forward-only helpers (act()), replay gather, Fokker-Planck.
+// Reference: aid/core/active_inference.py:638-707; aid/agents/state_agent.py:183-241; aid/utils/buffers.py:83-111;
+// aid/core/belief_dynamics.py:97-172,368-389.
+#include "mlp.h"
+
+namespace aid {
+
+// One thread per minibatch position; float32 accumulation order mirrors the reference's tensor arithmetic
+// (python-float scalars are rounded to float32 when they meet a tensor).  O(B * n^2), n <= 5.
+__global__ void lambda_returns_kernel(const float* __restrict__ r, const float* __restrict__ nv, const float* __restrict__ done,
+                                      int B, float gamma, double lam, int n_steps, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B) return;
+    float rets[16];
+    int cnt = 0;
+    const int nmax = min(n_steps + 1, B - idx);
+    for (int n = 1; n < nmax && cnt < 16; ++n) {
+        float ret = 0.f, disc = 1.0f;
+        for (int k = 0; k < n; ++k) {
+            ret = ret + disc * r[idx + k];
+            const float nd = done[idx + k] != 0.f ? 0.f : gamma;
+            disc = disc * nd;
+        }
+        if (idx + n < B && done[idx + n - 1] == 0.f) ret = ret + disc * nv[idx + n];
+        rets[cnt++] = ret;
+    }
+    if (cnt > 0) {
+        float wr = 0.f; double ls = 0.0, li = 1.0;
+        for (int i = 0; i < cnt - 1; ++i) { const double w = (1.0 - lam) * li; wr = wr + (float)w * rets[i]; ls += w; li *= lam; }
+        double lw = 1.0; for (int i = 0; i < cnt - 1; ++i) lw *= lam;
+        wr = wr + (float)lw * rets[cnt - 1]; ls += lw;
+        out[idx] = wr / (float)(ls + 1e-8);
+    } else {
+        out[idx] = r[idx] + (done[idx] != 0.f ? 0.f : gamma) * nv[idx];
+    }
+}
+
+__device__ __forceinline__ float wgs(float v, float* sh) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    if (threadIdx.x < 64) { t = (threadIdx.x < (blockDim.x >> 6)) ? sh[threadIdx.x] : 0.f; t = wave_sum(t); }
+    return t;
+}
+// F.huber_loss(values, targets) (delta=1, mean) and its gradient wrt values
+__global__ void huber_kernel(const float* __restrict__ v, const float* __restrict__ tg, int B, float* __restrict__ dv, float* __restrict__ loss) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) {
+        const float d = v[i] - tg[i], a = fabsf(d);
+        acc += a < 1.f ? 0.5f * d * d : a - 0.5f;
+        dv[i] = fminf(fmaxf(d, -1.f), 1.f) / (float)B;
+    }
+    const float s = wgs(acc, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
+}
+__global__ void mse_grad_kernel(const float* __restrict__ p, const float* __restrict__ tg, size_t n, float* __restrict__ dp, float* __restrict__ loss) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += blockDim.x) { const float d = p[i] - tg[i]; acc += d * d; dp[i] = 2.f * d / (float)n; }
+    const float s = wgs(acc, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+
+__global__ void replay_gather_kernel(const float* __restrict__ obs, const float* __restrict__ nobs, const float* __restrict__ act,
+                                     const float* __restrict__ rew, const float* __restrict__ done, const int64_t* __restrict__ idx,
+                                     int B, int O, int A, float* __restrict__ o_out, float* __restrict__ n_out, float* __restrict__ a_out,
+                                     float* __restrict__ r_out, float* __restrict__ d_out) {
+    const int W = 2 * O + A + 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * W) return;
+    const int b = i / W, c = i % W;
+    const int64_t row = idx[b];
+    if (c < O) o_out[(size_t)b * O + c] = obs[row * O + c];
+    else if (c < 2 * O) n_out[(size_t)b * O + (c - O)] = nobs[row * O + (c - O)];
+    else if (c < 2 * O + A) a_out[(size_t)b * A + (c - 2 * O)] = act[row * A + (c - 2 * O)];
+    else if (c == 2 * O + A) r_out[b] = rew[row];
+    else d_out[b] = done[row];
+}
+
+// fp64 diagonal Fokker-Planck belief step (closed form; see oracle.aid_oracle.fokker_planck_step)
+__global__ void fokker_planck_kernel(double* __restrict__ mean, double* __restrict__ var, const double* __restrict__ obs,
+                                     const double* __restrict__ score, const double* __restrict__ xi, int n, int L, double dt, double D,
+                                     double lr, double ns, double min_var, double max_var, double* __restrict__ ent) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n) return;
+    const double ns2 = ns * ns;
+    double g2 = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const double m = mean[(size_t)b * L + l];
+        const double g = -(m - obs[(size_t)b * L + l]) / ns2 - m + score[(size_t)b * L + l];
+        g2 += g * g;
+    }
+    const double adt = dt / (1.0 + 0.1 * sqrt(g2));
+    const double nz = sqrt(2.0 * D * dt) * ns;
+    const double h = -(1.0 / ns2 + 1.0);
+    const double fac = exp((-2.0 * h + 2.0 * D) * dt);
+    const double lo = fmax(min_var, 1e-8);
+    double e = 0.0;
+    for (int l = 0; l < L; ++l) {
+        const size_t i = (size_t)b * L + l;
+        const double m = mean[i];
+        const double g = -(m - obs[i]) / ns2 - m + score[i];
+        mean[i] = m + (-lr * g) * adt + nz * xi[i];
+        const double v = fmin(fmax(var[i] * fac, lo), max_var);
+        var[i] = v;
+        e += 0.5 * (log(2.0 * 3.14159265358979323846 * 2.718281828459045) + log(v));
+    }
+    if (ent) ent[b] = e;
+}
+
+}  // namespace aid
+
+using namespace aid;
+
+extern "C" {
+
+int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam, int n_steps,
+                       float* out, void* stream) {
+    AID_REQUIRE(rewards && next_values && dones && out, AID_E_NULL, "aid_lambda_returns: null tensor");
+    AID_REQUIRE(B > 0 && n_steps >= 1 && n_steps <= 16, AID_E_SHAPE, "aid_lambda_returns: B=%d n_steps=%d", B, n_steps);
+    hipLaunchKernelGGL(lambda_returns_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards, next_values, dones, B, gamma,
+                       (double)lam, n_steps, out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+size_t aid_small_net_workspace(int B, int D) { return sizeof(float) * (size_t)B * (64 * (size_t)D + 1024) + (1 << 16); }
+size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 * aid_small_net_workspace(B, val->D) : 0; }
+size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B) { return dyn ? aid_small_net_workspace(B, dyn->D) : 0; }
+
+int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
+                   const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out, float* loss_out,
+                   void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(val && vgrads && latents && next_latents && rewards && dones && loss_out, AID_E_NULL, "aid_value_step: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    float* t0 = ws.f32(B); float* t1 = ws.f32(B); float* v = ws.f32(B); float* nv = ws.f32(B); float* tg = ws.f32(B); float* dv = ws.f32(B);
+    AID_WS_OK(ws);
+    AID_TRY(fill_const(t0, 0.f, B, s)); AID_TRY(fill_const(t1, 1.f, B, s));
+    ValueSave sv, sv2;
+    AID_TRY(value_fwd(*val, B, latents, val->L, t0, v, sv, ws, s));
+    { const size_t mk = ws.mark(); AID_TRY(value_fwd(*val, B, next_latents, val->L, t1, nv, sv2, ws, s)); ws.release(mk); }
+    AID_TRY(aid_lambda_returns(rewards, nv, dones, B, gamma, lam, n_steps, tg, stream));
+    hipLaunchKernelGGL(huber_kernel, dim3(1), dim3(1024), 0, s, v, tg, B, dv, loss_out);
+    AID_LAUNCH_CHECK();
+    AID_TRY(value_bwd(*val, vgrads, B, t0, sv, dv, nullptr, 0, ws, s));
+    if (targets_out) AID_TRY(copy_f32(tg, targets_out, B, s));
+    return AID_OK;
+}
+
+int aid_dynamics_step(const AidDynamicsNet* dyn, const AidDynamicsNet* dgrads, int B, const float* latents, const float* actions,
+                      const float* next_latents, float* loss_out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dyn && dgrads && latents && actions && next_latents && loss_out, AID_E_NULL, "aid_dynamics_step: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const int L = dyn->L;
+    float* pred = ws.f32((size_t)B * L); float* dp = ws.f32((size_t)B * L);
+    DynSave sv;
+    AID_TRY(dynamics_fwd(*dyn, B, latents, L, actions, dyn->A, pred, sv, ws, s));
+    hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, s, pred, next_latents, (size_t)B * L, dp, loss_out);
+    AID_LAUNCH_CHECK();
+    AID_TRY(dynamics_bwd(*dyn, dgrads, B, sv, dp, nullptr, nullptr, ws, s));
+    return AID_OK;
+}
+
+int aid_policy_forward(const AidPolicyNet* pol, int B, const float* z, const float* eps, float* action, float* log_prob, float* entropy,
+                       void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(pol && z && action, AID_E_NULL, "aid_policy_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes); PolicySave sv;
+    AID_TRY(policy_fwd(*pol, B, z, pol->L, eps, sv, ws, s));
+    AID_TRY(copy_f32(sv.action, action, (size_t)B * pol->A, s));
+    if (log_prob) AID_TRY(copy_f32(sv.logp, log_prob, B, s));
+    if (entropy) AID_TRY(copy_f32(sv.ent, entropy, B, s));
+    return AID_OK;
+}
+int aid_value_forward(const AidValueNet* val, int B, const float* state, const float* t, float* out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(val && state && t && out, AID_E_NULL, "aid_value_forward: null argument");
+    Workspace ws(wsp, ws_bytes); ValueSave sv;
+    return value_fwd(*val, B, state, val->L, t, out, sv, ws, (hipStream_t)stream);
+}
+int aid_predict_next_latent(const AidDynamicsNet* dyn, int B, const float* z, const float* a, float* next_mean, void* wsp, size_t ws_bytes,
+                            void* stream) {
+    AID_REQUIRE(dyn && z && a && next_mean, AID_E_NULL, "aid_predict_next_latent: null argument");
+    Workspace ws(wsp, ws_bytes); DynSave sv;
+    return dynamics_fwd(*dyn, B, z, dyn->L, a, dyn->A, next_mean, sv, ws, (hipStream_t)stream);
+}
+int aid_reward_forward(const AidRewardNet* rew, int B, const float* z, float* out2, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(rew && z && out2, AID_E_NULL, "aid_reward_forward: null argument");
+    Workspace ws(wsp, ws_bytes); RewardSave sv;
+    AID_TRY(reward_fwd(*rew, B, z, rew->L, sv, ws, (hipStream_t)stream));
+    return copy_f32(sv.out, out2, (size_t)B * 2, (hipStream_t)stream);
+}
+
+int aid_replay_gather(const float* obs, const float* next_obs, const float* actions, const float* rewards, const float* dones,
+                      const int64_t* idx, int B, int O, int A, float* obs_out, float* next_obs_out, float* act_out, float* rew_out,
+                      float* done_out, void* stream) {
+    AID_REQUIRE(obs && next_obs && actions && rewards && dones && idx && obs_out && next_obs_out && act_out && rew_out && done_out, AID_E_NULL,
+                "aid_replay_gather: null tensor");
+    const int n = B * (2 * O + A + 2);
+    if (n == 0) return AID_OK;
+    hipLaunchKernelGGL(replay_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, next_obs, actions, rewards, dones,
+                       idx, B, O, A, obs_out, next_obs_out, act_out, rew_out, done_out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_fokker_planck_step(double* mean, double* var, const double* obs, const double* score, const double* xi, int n, int L, double dt,
+                           double D, double lr, double noise_scale, double min_var, double max_var, double* entropy_out, void* stream) {
+    AID_REQUIRE(mean && var && obs && score && xi, AID_E_NULL, "aid_fokker_planck_step: null tensor");
+    AID_REQUIRE(n > 0 && L > 0, AID_E_SHAPE, "aid_fokker_planck_step: n=%d L=%d", n, L);
+    hipLaunchKernelGGL(fokker_planck_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean, var, obs, score, xi, n, L, dt, D, lr,
+                       noise_scale, min_var, max_var, entropy_out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+}  // extern "C"

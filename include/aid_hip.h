@@ -192,6 +192,70 @@ int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, siz
                    float beta1, float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch,
                    void* stream);
 
+
+/* ---- A8/A10: compute_expected_free_energy_diffusion + MINE epistemic estimator, forward + policy backward
+ * (active_inference.py:314-418, 940-1063).  The K trajectories are batched: row r = k*B + b.
+ * Noise tensors (NULL member => Philox draw), H = horizon, M = K*B, R = K*S*B:
+ *   policy_eps [H,M,A]  rsample draws;  reparam_eps [H,M,L]  reparameterize draws;
+ *   mine_z_eps [H,R,L] (row (k*S+s)*B+b);  mine_delta [H,4,R,L] raw N(0,1) perturbation directions;
+ *   proj_mask [H,R,512] jacobian_projector dropout;  mine_mask [H,4,R,512] = joint(0,1), marginal(2,3) masks;
+ *   perms [H,K,S,B] int32 permutations (randperm per sample block).
+ * Outputs: efe[B]; info (device, 16 floats): 0 policy_loss(=mean efe) 1 epistemic_mean 2 pragmatic_mean
+ * 3 consistency_mean 4 mi_estimate 5 joint_term 6 marginal_term (last (k,t) call) ;
+ * running_mean: device scalar, EMA updated in the reference's (k outer, t inner) order.
+ * pgrads == NULL => forward only (act()).  Only POLICY gradients are produced: the EFE is minimised by the
+ * policy optimiser alone (state_agent.py:162-177); data gradients flow through dynamics/reward/value. */
+typedef struct AidEfeNoise {
+    const float *policy_eps, *reparam_eps, *mine_z_eps, *mine_delta, *proj_mask, *mine_mask;
+    const int32_t* perms;
+} AidEfeNoise;
+typedef struct AidEfeCfg {
+    int32_t H, K, S, train, skip_epistemic, _pad;
+    float epistemic_weight, pragmatic_weight, consistency_weight, discount, temperature, mine_alpha;
+    uint64_t seed, offset;
+} AidEfeCfg;
+size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg);
+int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
+                 const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
+                 const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info,
+                 void* ws, size_t ws_bytes, void* stream);
+
+/* ---- A11 + value/dynamics optimiser phases (state_agent.py:183-241) -----------------------------
+ * lambda-returns (active_inference.py:638-707; minibatch order treated as time), Huber value loss with
+ * gradients, MSE dynamics loss with gradients.  dones: [B] floats (0/1).  loss_out: device scalar. */
+int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+                       int n_steps, float* out, void* stream);
+size_t aid_value_step_workspace(const AidValueNet* val, int B);
+int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
+                   const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,
+                   float* loss_out, void* ws, size_t ws_bytes, void* stream);
+size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B);
+int aid_dynamics_step(const AidDynamicsNet* dyn, const AidDynamicsNet* dgrads, int B, const float* latents, const float* actions,
+                      const float* next_latents, float* loss_out, void* ws, size_t ws_bytes, void* stream);
+
+/* forward-only helpers used by act() and tests */
+size_t aid_small_net_workspace(int B, int D);
+int aid_policy_forward(const AidPolicyNet* pol, int B, const float* z, const float* eps /*NULL = deterministic*/, float* action,
+                       float* log_prob, float* entropy, void* ws, size_t ws_bytes, void* stream);
+int aid_value_forward(const AidValueNet* val, int B, const float* state, const float* t, float* out, void* ws, size_t ws_bytes,
+                      void* stream);
+int aid_predict_next_latent(const AidDynamicsNet* dyn, int B, const float* z, const float* a, float* next_mean, void* ws,
+                            size_t ws_bytes, void* stream);
+int aid_reward_forward(const AidRewardNet* rew, int B, const float* z, float* out2, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- A0: ReplayBuffer.sample gather (aid/utils/buffers.py:83-111), device-resident ring arrays.
+ * idx: [B] int64 row indices.  One coalesced pass over the 2*O + A + 2 floats of each transition. */
+int aid_replay_gather(const float* obs, const float* next_obs, const float* actions, const float* rewards, const float* dones,
+                      const int64_t* idx, int B, int O, int A, float* obs_out, float* next_obs_out, float* act_out,
+                      float* rew_out, float* done_out, void* stream);
+
+/* ---- A14: Fokker-Planck belief step, diagonal covariance, fp64 (aid/core/belief_dynamics.py:97-172) ---
+ * Batched over n beliefs of dimension L (double pointers): mean/var updated in place; entropy_out [n] optional.
+ * xi: [n,L] N(0,1) draws (double).  Closed form documented in oracle.aid_oracle.fokker_planck_step. */
+int aid_fokker_planck_step(double* mean, double* var, const double* obs, const double* score, const double* xi, int n, int L,
+                           double dt, double D, double lr, double noise_scale, double min_var, double max_var,
+                           double* entropy_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -138,3 +138,201 @@ def test_adamw_clip_ema(nat):
         np.testing.assert_allclose(p.cpu().numpy(), pr.numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(ema.cpu().numpy(), er.numpy(), rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(v.cpu().numpy(), vr.numpy(), rtol=1e-5, atol=1e-12)
+
+
+# ------------------------------------------------------------------------------------------------- EFE / MINE
+def _efe_noise(key, B, L, A, H, K, S):
+    """Reference draw order (k outer, t inner) -> the batched [t][k] layouts of AidEfeNoise."""
+    ns = NoiseStream(key)
+    M, R = K * B, K * S * B
+    n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),
+         "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((H, 4, R, L), np.float32),
+         "proj_mask": np.zeros((H, R, 512), np.float32), "mine_mask": np.zeros((H, 4, R, 512), np.float32),
+         "perms": np.zeros((H, K, S, B), np.int32)}
+    for k in range(K):
+        rs = slice(k * S * B, (k + 1) * S * B)
+        for t in range(H):
+            n["policy_eps"][t, k * B:(k + 1) * B] = ns.randn(B, A)
+            n["reparam_eps"][t, k * B:(k + 1) * B] = ns.randn(B, L)
+            for s_ in range(S):
+                n["mine_z_eps"][t, k * S * B + s_ * B:k * S * B + (s_ + 1) * B] = ns.randn(B, L)
+            for j in range(4):
+                n["mine_delta"][t, j, rs] = ns.randn(S * B, L)
+            n["proj_mask"][t, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][t, 0, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][t, 1, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            for s_ in range(S):
+                n["perms"][t, k, s_] = ns.randperm(B)
+            n["mine_mask"][t, 2, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][t, 3, rs] = ns.dropout_mask((S * B, 512), 0.1)
+    return n
+
+
+def _efe_case(nat, O, A, D, B, H, K, S, wkey, key, check_grads=True):
+    L, N = O, 4
+    p = draw_params(param_specs(O, A, L, D, N), wkey, orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    gd = {k: torch.zeros_like(v) for k, v in pd.items()}
+    z = NoiseStream(key + 7).randn(B, L)
+    nz = _efe_noise(key, B, L, A, H, K, S)
+    nzd = {k: (torch.from_numpy(v).cuda().contiguous() if k == "perms" else dev(v)) for k, v in nz.items()}
+    rm = torch.zeros(1, device="cuda")
+    efe, info = nat.efe_step(nat.policy_table(pd), nat.policy_table(gd), nat.dynamics_table(pd, A), nat.reward_table(pd), nat.value_table(pd),
+                             nat.decoder_table(pd), nat.epistemic_table(pd), dev(z), rm, H, K, S, noise=nzd, train=True)
+    for n_ in p:
+        p[n_].requires_grad_(orc.is_param(n_))
+    efe_ref, info_ref, rm_ref = orc.expected_free_energy(p, T(z), NoiseStream(key), 0.0, H, K, S, True)
+    np.testing.assert_allclose(efe.cpu().numpy(), efe_ref.detach().numpy(), rtol=2e-4, atol=2e-5)
+    got = dict(zip(nat.EFE_INFO, info.cpu().numpy()))
+    np.testing.assert_allclose(got["policy_loss"], float(efe_ref.mean().detach()), rtol=2e-4, atol=1e-5)
+    for kk in ("epistemic_mean", "pragmatic_mean", "consistency_mean", "epistemic/mi_estimate", "epistemic/joint_term", "epistemic/marginal_term"):
+        np.testing.assert_allclose(got[kk], float(torch.as_tensor(info_ref[kk]).detach()), rtol=5e-4, atol=2e-5, err_msg=kk)
+    np.testing.assert_allclose(float(rm), rm_ref, rtol=1e-4)
+    if check_grads:
+        names = orc.group_names(p, "policy")
+        gref = torch.autograd.grad(efe_ref.mean(), [p[n_] for n_ in names])
+        for n_, gr in zip(names, gref):
+            scale = float(gr.abs().max()) + 1e-12
+            err = float((gd[n_].cpu() - gr).abs().max()) / scale
+            assert err < 2e-3, (n_, err, scale)
+        for n_ in p:   # nothing but the policy receives gradients
+            if not n_.startswith("policy_network."):
+                assert float(gd[n_].abs().max()) == 0.0, n_
+
+
+@pytest.mark.parametrize("O,A", [(17, 6), (11, 3)])
+def test_efe_step_small(nat, O, A):
+    _efe_case(nat, O, A, 64, 8, 2, 2, 2, 1234 + O, 30)
+
+
+def test_efe_step_reference_kh(nat):
+    """K=10, S=10, H=5 as hard-coded in train_step, small width."""
+    _efe_case(nat, 17, 6, 64, 8, 5, 10, 10, 91, 300)
+
+
+def test_efe_step_full_size(nat):
+    """D=512, B=256, K=2, S=2, H=2: full-width kernels against the oracle."""
+    _efe_case(nat, 17, 6, 512, 256, 2, 2, 2, 17, 700)
+
+
+def test_efe_golden(nat, golden_dir):
+    g = np.load(os.path.join(golden_dir, "state_hc.npz"))
+    O, A, L, D, N, B, H = (int(g[k]) for k in ("O", "A", "L", "D", "N", "B", "H"))
+    p = draw_params(param_specs(O, A, L, D, N), int(g["weights_key"]), orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    gd = {k: torch.zeros_like(v) for k, v in pd.items()}
+    nz = _efe_noise(int(g["efe_key"]), B, L, A, H, 2, 2)
+    nzd = {k: (torch.from_numpy(v).cuda().contiguous() if k == "perms" else dev(v)) for k, v in nz.items()}
+    rm = torch.zeros(1, device="cuda")
+    efe, info = nat.efe_step(nat.policy_table(pd), nat.policy_table(gd), nat.dynamics_table(pd, A), nat.reward_table(pd), nat.value_table(pd),
+                             nat.decoder_table(pd), nat.epistemic_table(pd), dev(g["z"]), rm, H, 2, 2, noise=nzd, train=True)
+    np.testing.assert_allclose(efe.cpu().numpy(), g["efe"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(float(rm), g["efe_running_mean"], rtol=1e-4)
+    got = dict(zip(nat.EFE_INFO, info.cpu().numpy()))
+    np.testing.assert_allclose(got["epistemic/mi_estimate"], g["efe_mi"], rtol=5e-4, atol=2e-5)
+    np.testing.assert_allclose(got["pragmatic_mean"], g["efe_pragmatic_mean"], rtol=5e-4, atol=2e-5)
+    for k in g.files:
+        if k.startswith("efe_grad/"):
+            ref = g[k]
+            np.testing.assert_allclose(gd[k.split("/", 1)[1]].cpu().numpy(), ref, rtol=2e-3, atol=2e-6 * max(1.0, np.abs(ref).max()), err_msg=k)
+
+
+# ------------------------------------------------------------------------------------------------- value / dynamics / lambda
+def test_lambda_returns_golden(nat, golden_dir):
+    for tag in ("hc", "hop"):
+        g = np.load(os.path.join(golden_dir, f"state_{tag}.npz"))
+        out = nat.lambda_returns(dev(g["rew"]), dev(g["lam_next_values"]), dev(g["lam_dones"].astype(np.float32)))
+        np.testing.assert_allclose(out.cpu().numpy(), g["lam_returns"], rtol=1e-6, atol=1e-7)
+        out = nat.lambda_returns(dev(g["lam64_r"]), dev(g["lam64_v"]), dev(g["lam64_d"].astype(np.float32)))
+        np.testing.assert_allclose(out.cpu().numpy(), g["lam64_returns"], rtol=1e-6, atol=1e-7)
+    # edge cases: B=1, B=2, all done, 1024 rows vs the oracle
+    for B, pd_ in ((1, 0.0), (2, 0.5), (7, 1.0), (1024, 0.01)):
+        ns = NoiseStream(B)
+        r, v, d = ns.randn(B), ns.randn(B), (ns.rand(B) < pd_)
+        out = nat.lambda_returns(dev(r), dev(v), dev(d.astype(np.float32)))
+        np.testing.assert_allclose(out.cpu().numpy(), orc.lambda_returns(r, v, d), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("D,B", [(64, 8), (512, 256)])
+def test_value_and_dynamics_steps(nat, D, B):
+    O, A, L, N = 17, 6, 17, 4
+    p = draw_params(param_specs(O, A, L, D, N), 5 + D, orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    gd = {k: torch.zeros_like(v) for k, v in pd.items()}
+    ns = NoiseStream(D)
+    z, nzl, act, r = ns.randn(B, L), ns.randn(B, L), np.tanh(ns.randn(B, A)).astype(np.float32), ns.randn(B)
+    d = (ns.rand(B) < 0.1)
+    loss, targets = nat.value_step(nat.value_table(pd), nat.value_table(gd), dev(z), dev(nzl), dev(r), dev(d.astype(np.float32)))
+    for n_ in p:
+        p[n_].requires_grad_(orc.is_param(n_))
+    values = orc.value_forward(p, T(z), torch.zeros(B)).squeeze(-1)
+    with torch.no_grad():
+        nv = orc.value_forward(p, T(nzl), torch.ones(B)).squeeze(-1)
+        tg = T(orc.lambda_returns(r, nv.numpy(), d))
+    vloss = torch.nn.functional.huber_loss(values, tg)
+    np.testing.assert_allclose(targets.cpu().numpy(), tg.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(loss), float(vloss), rtol=1e-4)
+    names = orc.group_names(p, "value")
+    for n_, gr in zip(names, torch.autograd.grad(vloss, [p[n_] for n_ in names])):
+        scale = float(gr.abs().max()) + 1e-12
+        assert float((gd[n_].cpu() - gr).abs().max()) / scale < 2e-3, n_
+    dloss = nat.dynamics_step(nat.dynamics_table(pd, A), nat.dynamics_table(gd, A), dev(z), dev(act), dev(nzl))
+    pred, _ = orc.predict_next_latent(p, T(z), T(act))
+    ref = torch.nn.functional.mse_loss(pred, T(nzl))
+    np.testing.assert_allclose(float(dloss), float(ref), rtol=1e-4)
+    names = orc.group_names(p, "dynamics")
+    for n_, gr in zip(names, torch.autograd.grad(ref, [p[n_] for n_ in names])):
+        scale = float(gr.abs().max()) + 1e-12
+        assert float((gd[n_].cpu() - gr).abs().max()) / scale < 2e-3, n_
+
+
+def test_small_net_forwards_golden(nat, golden_dir):
+    g = np.load(os.path.join(golden_dir, "state_hc.npz"))
+    O, A, L, D, N, B = (int(g[k]) for k in ("O", "A", "L", "D", "N", "B"))
+    p = draw_params(param_specs(O, A, L, D, N), int(g["weights_key"]), orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    z = dev(g["z"])
+    a, lp, ent = nat.policy_forward(nat.policy_table(pd), z, dev(NoiseStream(int(g["policy_key"])).randn(B, A)))
+    np.testing.assert_allclose(a.cpu().numpy(), g["policy_action"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(lp.cpu().numpy(), g["policy_logp"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(ent.cpu().numpy(), g["policy_entropy"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nat.value_forward(nat.value_table(pd), z, dev(np.full(B, 2.0))).cpu().numpy(), g["value_t2"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nat.predict_next_latent(nat.dynamics_table(pd, A), z, dev(g["act"])).cpu().numpy(), g["dyn_next_mean"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nat.reward_forward(nat.reward_table(pd), z).cpu().numpy(), g["reward_out"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(nat.decode_observation(nat.decoder_table(pd), z).cpu().numpy(), g["decoder_eval"], rtol=1e-4, atol=1e-5)
+
+
+def test_replay_gather_bit_exact(nat):
+    cap, O, A, B = 4096, 17, 6, 256
+    ns = NoiseStream(4)
+    store = {"observations": ns.randn(cap, O), "actions": ns.randn(cap, A), "rewards": ns.randn(cap), "next_observations": ns.randn(cap, O),
+             "dones": (ns.rand(cap) < 0.1)}
+    b = orc.replay_sample(store, cap, B, NoiseStream(9))
+    idx = torch.from_numpy(b["indices"]).cuda()
+    o, n, a, r, d = nat.replay_gather(dev(store["observations"]), dev(store["next_observations"]), dev(store["actions"]), dev(store["rewards"]),
+                                      dev(store["dones"].astype(np.float32)), idx)
+    assert np.array_equal(o.cpu().numpy(), b["observations"]) and np.array_equal(n.cpu().numpy(), b["next_observations"])
+    assert np.array_equal(a.cpu().numpy(), b["actions"]) and np.array_equal(r.cpu().numpy(), b["rewards"])
+    assert np.array_equal(d.cpu().numpy() != 0, b["dones"])
+
+
+def test_fokker_planck_fp64(nat, golden_dir):
+    n, L = 33, 17
+    rng = np.random.default_rng(3)
+    mean, var = rng.standard_normal((n, L)), np.abs(rng.standard_normal((n, L))) + 0.1
+    obs, sc, xi = rng.standard_normal((n, L)), rng.standard_normal((n, L)), rng.standard_normal((n, L))
+    for kw in ({}, {"dt": 1e-6, "noise_scale": 0.5, "max_var": 100.0}):
+        m_ref, v_ref = orc.fokker_planck_step(mean, var, obs, sc, xi, **kw)
+        md, vd = torch.from_numpy(mean.copy()).cuda(), torch.from_numpy(var.copy()).cuda()
+        ent = nat.fokker_planck_step(md, vd, torch.from_numpy(obs).cuda(), torch.from_numpy(sc).cuda(), torch.from_numpy(xi).cuda(), **kw)
+        np.testing.assert_allclose(md.cpu().numpy(), m_ref, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(vd.cpu().numpy(), v_ref, rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(ent.cpu().numpy(), orc.gaussian_entropy_diag(v_ref), rtol=1e-12)
+    # pinned sub-function: the gradient the reference's autodiff returns (tests/golden/misc.npz)
+    m = np.load(os.path.join(golden_dir, "misc.npz"))
+    mu, ob, s_ = m["fp_mu"][None], m["fp_obs"][None], m["fp_score"][None]
+    md, vd = torch.from_numpy(mu.copy()).cuda(), torch.ones(1, 6, dtype=torch.float64, device="cuda")
+    nat.fokker_planck_step(md, vd, torch.from_numpy(ob).cuda(), torch.from_numpy(s_).cuda(), torch.zeros(1, 6, dtype=torch.float64, device="cuda"))
+    g = m["fp_grad"]
+    expect = mu[0] + (-0.1 * g) * (0.01 / (1 + 0.1 * np.linalg.norm(g)))
+    np.testing.assert_allclose(md.cpu().numpy()[0], expect, rtol=1e-12)

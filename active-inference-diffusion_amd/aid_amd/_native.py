@@ -511,3 +511,26 @@ def fokker_planck_step(mean, var, obs, score, xi, dt=0.01, D=0.1, lr=0.1, noise_
                                        C.c_double(noise_scale), C.c_double(min_var), C.c_double(max_var),
                                        C.c_void_p(ent.data_ptr()) if ent is not None else None, _stream()), "aid_fokker_planck_step")
     return ent
+
+
+def p_sample(z, score, coefs, step: int, eps=None):
+    out = torch.empty_like(z)
+    check(lib().aid_p_sample(_ptr(z), _ptr(score), _ptr(eps), _ptr(coefs), int(step), z.shape[0], z.shape[1], _ptr(out), _stream()), "aid_p_sample")
+    return out
+
+
+def reward_normalize(rewards, state):
+    """state: CUDA float64 [3] = (mean, var, count), updated in place; returns normalised rewards."""
+    assert state.is_cuda and state.dtype == torch.float64 and state.numel() == 3
+    out = torch.empty_like(rewards)
+    check(lib().aid_reward_normalize(_ptr(rewards), rewards.shape[0], C.c_void_p(state.data_ptr()), _ptr(out), _stream()), "aid_reward_normalize")
+    return out
+
+
+def rowwise_sqdist_means(states, prior_mean, obs, score):
+    """-> [3] device tensor: mean_b sum_l (z-mu_p)^2, (o-z)^2, score^2 (FreeEnergyComputation terms)."""
+    assert states.shape == obs.shape == score.shape == prior_mean.shape, "free energy needs obs, states, score of one shape (as the reference)"
+    out = torch.empty(3, device=states.device, dtype=torch.float32)
+    check(lib().aid_free_energy_terms(_ptr(states), _ptr(prior_mean), _ptr(obs), _ptr(score), states.shape[0], states.shape[1], _ptr(out), _stream()),
+          "aid_free_energy_terms")
+    return out

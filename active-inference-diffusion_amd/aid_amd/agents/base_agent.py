@@ -1,0 +1,96 @@
+"""BaseActiveInferenceAgent and the reward normaliser
+(active_inference_diffusion/agents/base_agent.py:24-185)."""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..arena import ArenaOptimizer
+from ..configs.config import ActiveInferenceConfig, TrainingConfig
+from ..core.active_inference import EMAModel
+
+
+class RunningMeanStd:
+    """Welford-merge running statistics (base_agent.py:24-52) kept in fp64 ON THE DEVICE: update + normalise is one
+    small kernel, removing the two device<->host round trips of the reference's train_step (state_agent.py:126-133)."""
+
+    def __init__(self, epsilon: float = 1e-4, shape=(), device="cuda"):
+        assert shape == (), "only scalar statistics are used by the reference"
+        self.state = torch.tensor([0.0, 1.0, float(epsilon)], dtype=torch.float64, device=device)
+
+    mean = property(lambda self: float(self.state[0]))
+    var = property(lambda self: float(self.state[1]))
+    count = property(lambda self: float(self.state[2]))
+
+    def update_and_normalize(self, rewards: torch.Tensor) -> torch.Tensor:
+        """update(x) followed by normalize(x), as train_step does; float32 out."""
+        return nat.reward_normalize(rewards.contiguous().float(), self.state)
+
+    def update(self, x):
+        self.update_and_normalize(torch.as_tensor(np.asarray(x, dtype=np.float32)).to(self.state.device))
+
+    def normalize(self, x):
+        x = np.asarray(x)
+        return (x - self.mean) / np.sqrt(self.var + 1e-8)
+
+
+class BaseActiveInferenceAgent(ABC):
+    def __init__(self, env, config: ActiveInferenceConfig, training_config: TrainingConfig):
+        self.env, self.config, self.training_config = env, config, training_config
+        self.device = torch.device(config.device)
+        self._setup_dimensions()
+        self._build_models()
+        ai = self.active_inference
+        self.score_ema = EMAModel(ai.latent_score_network, decay=0.9999, device=self.device, arena=ai.arenas["score"], prefix="latent_score_network.")
+        self._setup_optimizers()
+        self.replay_buffer = self._create_replay_buffer()
+        self.total_steps, self.episode_count = 0, 0
+        self.exploration_noise = training_config.exploration_noise
+        self.reward_normalizer = RunningMeanStd(shape=(), device=self.device)
+
+    @abstractmethod
+    def _setup_dimensions(self): ...
+
+    @abstractmethod
+    def _build_models(self): ...
+
+    @abstractmethod
+    def _create_replay_buffer(self): ...
+
+    @abstractmethod
+    def _process_observation(self, observation: np.ndarray) -> torch.Tensor: ...
+
+    @abstractmethod
+    def _process_batch_observations(self, observations: torch.Tensor) -> torch.Tensor: ...
+
+    def _setup_optimizers(self):
+        """Four AdamW groups (state_agent.py:245-274): lr = config.learning_rate; weight decay 1e-5 on the score and policy
+        groups, torch's default 1e-2 on value and dynamics (the reference passes none); clip-by-global-norm = gradient_clip;
+        score-net EMA 0.9999 fused into the score step."""
+        a, lr, clip = self.active_inference.arenas, self.config.learning_rate, self.config.gradient_clip
+        self.score_optimizer = ArenaOptimizer(a["score"], lr, 1e-5, clip, ema_decay=0.9999)
+        self.policy_optimizer = ArenaOptimizer(a["policy"], lr, 1e-5, clip)
+        self.value_optimizer = ArenaOptimizer(a["value"], lr, 1e-2, clip)
+        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip)
+
+    def act(self, observation: np.ndarray, deterministic: bool = False) -> Tuple[np.ndarray, Dict[str, Any]]:
+        obs = self._process_observation(observation).to(self.device)
+        action_t, info = self.active_inference.act(obs, deterministic=deterministic)
+        action = action_t.cpu().numpy().squeeze()
+        if not deterministic and self.training and self.exploration_noise > 0:
+            action = np.clip(action + np.random.normal(0, self.exploration_noise, size=action.shape), -1, 1)
+        return action, info
+
+    def train_step(self) -> Dict[str, float]:
+        raise NotImplementedError
+
+    def update_exploration(self):
+        self.exploration_noise = max(self.exploration_noise * self.training_config.exploration_decay, self.training_config.min_exploration)
+
+    @property
+    def training(self) -> bool:
+        return self.active_inference.training

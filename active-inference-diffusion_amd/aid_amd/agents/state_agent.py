@@ -1,0 +1,89 @@
+"""DiffusionStateAgent (active_inference_diffusion/agents/state_agent.py:17-274): same constructor, `act`,
+`train_step`, optimiser attributes and metric keys; each phase of train_step is one fused HIP call."""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from ..core.active_inference import DiffusionActiveInference
+from ..utils.buffers import ReplayBuffer
+from .base_agent import BaseActiveInferenceAgent
+
+
+def _is_box(space) -> bool:
+    return hasattr(space, "shape") and space.shape is not None and len(space.shape) >= 1
+
+
+class DiffusionStateAgent(BaseActiveInferenceAgent):
+    def _setup_dimensions(self):
+        self.obs_space, self.action_space = self.env.observation_space, self.env.action_space
+        if not _is_box(self.obs_space):
+            raise ValueError(f"Unsupported observation space: {type(self.obs_space)}")
+        if not _is_box(self.action_space):
+            raise ValueError(f"Unsupported action space: {type(self.action_space)}")
+        self.observation_dim, self.action_dim = self.obs_space.shape[0], self.action_space.shape[0]
+        self.config.observation_dim, self.config.action_dim = self.observation_dim, self.action_dim   # the reference mutates config too
+
+    def _build_models(self):
+        self.active_inference = DiffusionActiveInference(observation_dim=self.observation_dim, action_dim=self.action_dim,
+                                                         latent_dim=self.config.latent_dim, config=self.config)
+
+    def _create_replay_buffer(self) -> ReplayBuffer:
+        return ReplayBuffer(capacity=self.training_config.buffer_size, obs_shape=(self.observation_dim,), action_dim=self.action_dim, device=self.device)
+
+    def _process_observation(self, observation: np.ndarray) -> torch.Tensor:
+        return torch.as_tensor(np.asarray(observation, dtype=np.float32)).unsqueeze(0)
+
+    def _process_batch_observations(self, observations: torch.Tensor) -> torch.Tensor:
+        return observations.to(self.device)
+
+    # ------------------------------------------------------------------------------------------------
+    def train_step(self) -> Dict[str, float]:
+        """One update of all four groups (state_agent.py:110-243).  Phases: minibatch gather -> reward normalisation ->
+        belief latents for obs and next_obs (ONE merged 2B-row reverse-diffusion loop) -> ELBO step (score group) ->
+        EFE step (policy) -> third belief update + lambda-returns + Huber (value) -> MSE (dynamics).
+        The epistemic-estimator training branch (`total_steps % 5 == 0`) cannot run in the reference and is
+        skipped.  Metrics are read back from the device once, at the end."""
+        cfg, ai = self.config, self.active_inference
+        B = cfg.batch_size
+        if len(self.replay_buffer) < B:
+            return {}
+        batch = self.replay_buffer.sample(B)
+        obs, actions, rewards = batch["observations"], batch["actions"], batch["rewards"]
+        next_obs, dones = batch["next_observations"], batch["dones"]
+        nrew = self.reward_normalizer.update_and_normalize(rewards)
+        # 1. latents via reverse diffusion (no gradients): obs and next_obs share one 2B-row loop
+        both = ai.denoise_pair(obs, next_obs)
+        latents = both[:B]
+        # 2. score / diffusion group
+        self.score_optimizer.zero_grad()
+        elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents)
+        self.score_optimizer.step()
+        # 3. policy
+        self.policy_optimizer.zero_grad()
+        efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
+        self.policy_optimizer.step()
+        # 4. value (targets from a re-sampled next-latent belief, state_agent.py:194-205)
+        self.value_optimizer.zero_grad()
+        next_latents = ai.denoise_only(next_obs)
+        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
+                                       cfg.discount_factor, 0.95, 5, ws=ai._ws)
+        self.value_optimizer.step()
+        # 5. dynamics
+        self.dynamics_optimizer.zero_grad()
+        dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
+        self.dynamics_optimizer.step()
+        self.total_steps += 1
+        # one device->host read for every metric
+        keys, vals = [], []
+        for k, v in {**elbo_info, "policy_loss": efe_info.pop("policy_loss"), **efe_info, "value_loss": value_loss, "dynamics_loss": dyn_loss}.items():
+            if torch.is_tensor(v):
+                keys.append(k); vals.append(v.reshape(1))
+        host = torch.cat(vals).cpu().tolist()
+        metrics = dict(zip(keys, host))
+        metrics.update({"num_trajectories": efe_info["num_trajectories"], "horizon": efe_info["horizon"]})
+        self._last = {"latents": latents, "next_latents": next_latents}
+        return metrics

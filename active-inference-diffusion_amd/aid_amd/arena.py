@@ -1,0 +1,121 @@
+"""Flat parameter arenas: every optimiser group lives in ONE contiguous float32 buffer on the GPU.
+
+Why (MI355X): clip_grad_norm_ -> AdamW -> EMA becomes a single HBM-streaming kernel over the arena
+(`aid_adamw_step`, 36-40 B/param) instead of ~300 tiny per-tensor kernels, the data-parallel gradient exchange
+is one RCCL all-reduce per group on a contiguous buffer (no bucketing copies), and the 13 adaLN modulation
+matrices sit back to back so they run as one GEMM.  The nn.Parameters keep their reference names and shapes
+(they are views into the arena), so state_dict()/load_state_dict() interchange with the reference.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _native as nat
+
+ALIGN = 64  # floats (256 B): keeps every tensor 16-B aligned for vector loads and LDS-DMA
+
+
+class ParamArena:
+    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]], device, with_ema: bool = False):
+        self.device = torch.device(device)
+        self.names: List[str] = [n for n, _ in named_params]
+        self.params: List[nn.Parameter] = [p for _, p in named_params]
+        self.offsets: Dict[str, Tuple[int, torch.Size]] = {}
+        off = 0
+        for n, p in named_params:
+            self.offsets[n] = (off, p.shape)
+            off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros_like(self.flat)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.ema = None
+        self.step_count = 0
+        self._scratch = torch.zeros(8192, dtype=torch.float32, device=self.device)
+        with torch.no_grad():
+            for n, p in named_params:
+                o, shp = self.offsets[n]
+                view = self.flat[o:o + p.numel()].view(shp)
+                view.copy_(p.data.to(self.device, torch.float32))
+                p.data = view
+                p.grad = self.grad[o:o + p.numel()].view(shp)
+        if with_ema:
+            self.ema = self.flat.clone()
+
+    # -- views ------------------------------------------------------------------------------------
+    def grad_views(self) -> Dict[str, torch.Tensor]:
+        return {n: self.grad[o:o + int(torch.Size(s).numel())].view(s) for n, (o, s) in self.offsets.items()}
+
+    def ema_views(self) -> Dict[str, torch.Tensor]:
+        assert self.ema is not None
+        return {n: self.ema[o:o + int(torch.Size(s).numel())].view(s) for n, (o, s) in self.offsets.items()}
+
+    def reset_ema(self):
+        if self.ema is not None:
+            self.ema.copy_(self.flat)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def rebind(self):
+        """Re-attach .grad views (torch optimizers / user code may have set them to None)."""
+        for n, p in zip(self.names, self.params):
+            o, shp = self.offsets[n]
+            if p.data.data_ptr() != self.flat.data_ptr() + 4 * o:
+                with torch.no_grad():
+                    self.flat[o:o + p.numel()].view(shp).copy_(p.data)
+                p.data = self.flat[o:o + p.numel()].view(shp)
+            p.grad = self.grad[o:o + p.numel()].view(shp)
+
+    # -- fused clip -> AdamW -> EMA -----------------------------------------------------------------
+    def step(self, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999):
+        self.step_count += 1
+        nat.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.ema, lr, weight_decay, self.step_count, clip_norm,
+                       self._scratch, ema_decay=ema_decay)
+
+    def grad_norm(self) -> torch.Tensor:
+        """Device scalar: the global L2 norm measured by the last step()."""
+        return self._scratch[0]
+
+    # -- optimiser state in torch.optim.AdamW's layout (checkpoint interchange) --------------------------
+    def state_dict(self) -> dict:
+        state = {}
+        for i, n in enumerate(self.names):
+            o, s = self.offsets[n]; k = int(torch.Size(s).numel())
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[o:o + k].view(s).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + k].view(s).clone()}
+        return {"state": state if self.step_count else {}, "param_groups": [{"params": list(range(len(self.names)))}]}
+
+    def load_state_dict(self, sd: dict):
+        for i, n in enumerate(self.names):
+            st = sd.get("state", {}).get(i)
+            if st is None:
+                continue
+            o, s = self.offsets[n]; k = int(torch.Size(s).numel())
+            self.exp_avg[o:o + k].view(s).copy_(st["exp_avg"]); self.exp_avg_sq[o:o + k].view(s).copy_(st["exp_avg_sq"])
+            self.step_count = int(float(st["step"]))
+
+
+class ArenaOptimizer:
+    """What callers see as `agent.score_optimizer` etc.: zero_grad / step / state_dict over one arena
+    (reference: torch.optim.AdamW groups of aid/agents/state_agent.py:245-274)."""
+
+    def __init__(self, arena: ParamArena, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999):
+        self.arena, self.lr, self.weight_decay, self.clip_norm, self.ema_decay = arena, lr, weight_decay, clip_norm, ema_decay
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": (0.9, 0.999), "eps": 1e-8}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()
+
+    def step(self):
+        self.arena.step(self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"], self.clip_norm, self.ema_decay)
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def load_state_dict(self, sd):
+        self.arena.load_state_dict(sd)

@@ -1,0 +1,319 @@
+"""DiffusionActiveInference — the reference's core module surface
+(active_inference_diffusion/core/active_inference.py:19-1063) on hand-written gfx950 kernels.
+
+Same constructor, sub-module names, state_dict keys and method names as the reference; every method body is a
+thin call into `aid_amd._native` (the C ABI of libaid_hip.so).  What differs by design (MI355X-first):
+  * forward AND backward of each optimiser phase are one fused native call that writes gradients straight
+    into the flat parameter arenas (`compute_diffusion_elbo` / `compute_expected_free_energy_diffusion(backward=True)`
+    accumulate `.grad`; the returned loss is a detached device scalar — there is no autograd graph to `.backward()`);
+  * metrics stay on the device (0-dim tensors) so a training step needs ONE device->host read, not ~40 `.item()`s;
+  * randomness comes from a `NoiseSource` (device Philox by default; parity tests inject the reference's draws).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _native as nat
+from ..arena import ParamArena
+from ..models import DiffusionConditionedPolicy, LatentDynamicsModel, LatentScoreNetwork, ValueNetwork
+from ..models._holders import TableCache, native_only, params_dict
+from ..noise import NoiseSource, PhiloxNoise
+from .diffusion import LatentDiffusionProcess
+
+
+class FunctionSpaceEpistemicEstimator(nn.Module):
+    """Parameter holder of the MINE estimator (active_inference.py:839-1063, state branch).  Evaluated inside
+    `aid_efe_step`; never trained in any runnable reference configuration."""
+
+    def __init__(self, decoder: nn.Module, latent_dim: int, observation_shape: int, hidden_dim: int = 256,
+                 spatial_aggregator_output_dim: int = 256, is_pixel_observation: bool = False, device="cuda"):
+        super().__init__()
+        if is_pixel_observation:
+            raise NotImplementedError("pixel-mode epistemic path (ConvDecoder / SpatialAttentionAggregator) is SURVEY §8(f) rank 1: next")
+        self.decoder, self.latent_dim, self.is_pixel = decoder, latent_dim, False
+        self.ntk_samples, self.alpha, self.state_dim = 4, 0.01, observation_shape
+        self.perturbation_scale = nn.Parameter(torch.tensor(0.1))
+        self.register_buffer("running_mean", torch.tensor(0.0))
+        self.feature_extractor = nn.Sequential(nn.Linear(observation_shape, 128), nn.ReLU(), nn.Linear(128, 256), nn.ReLU(), nn.Linear(256, 128))
+        self.jacobian_projector = nn.Sequential(nn.Linear(128 * self.ntk_samples, 512), nn.LayerNorm(512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 256))
+        self.latent_processor = nn.Sequential(nn.Linear(latent_dim, 128), nn.ReLU(), nn.Linear(128, 128))
+        self.mine_network = nn.Sequential(nn.Linear(spatial_aggregator_output_dim + 128, 512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 512),
+                                          nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 1))
+
+    forward = native_only("FunctionSpaceEpistemicEstimator")
+
+
+class EMAModel:
+    """Exponential moving average of the score-network weights (active_inference.py:779-813).  The average itself is
+    maintained by the fused optimiser kernel (arena.ema); this object exposes the reference's shadow/apply/restore API."""
+
+    def __init__(self, model: nn.Module, decay: float = 0.9999, device=None, arena: Optional[ParamArena] = None, prefix: str = ""):
+        self.model, self.decay, self.device, self.backup = model, decay, device, {}
+        self._arena, self._prefix = arena, prefix
+
+    @property
+    def shadow(self) -> Dict[str, torch.Tensor]:
+        views = self._arena.ema_views()
+        return {n: views[self._prefix + n] for n, _ in self.model.named_parameters()}
+
+    def update(self):
+        """No-op: `ema = decay*ema + (1-decay)*p` runs inside aid_adamw_step right after the parameter update."""
+
+    def apply_shadow(self):
+        sh = self.shadow
+        for n, p in self.model.named_parameters():
+            self.backup[n] = p.data.clone()
+            p.data.copy_(sh[n])
+
+    def restore(self):
+        for n, p in self.model.named_parameters():
+            p.data.copy_(self.backup[n])
+
+
+class DiffusionActiveInference(nn.Module):
+    def __init__(self, observation_dim: int, action_dim: int, latent_dim: int, config, pixel_shape: Optional[Tuple[int, int, int]] = None,
+                 noise: Optional[NoiseSource] = None):
+        super().__init__()
+        self.observation_dim, self.action_dim, self.latent_dim, self.config = observation_dim, action_dim, latent_dim, config
+        self.pixel_shape, self.is_pixel_observation = pixel_shape, bool(config.pixel_observation)
+        self.epistemic_dropout_rate = 0.2
+        self.device = torch.device(config.device)
+        if self.device.type != "cuda":
+            raise RuntimeError("aid_amd runs on an AMD GPU (torch device 'cuda' on ROCm); there is no CPU path. "
+                               f"Got config.device={config.device!r}.")
+        nat.lib()  # fail loudly before building anything if libaid_hip.so is missing
+        self.noise = noise or PhiloxNoise(seed=0xA1D)
+        self.store_trajectory = False
+        self._build_models()
+        self._to_device_and_flatten(self.device)
+        self.current_latent, self.latent_trajectory = None, []
+        self._ws = nat.Workspace(self.device)
+
+    # ------------------------------------------------------------------------------------------ construction
+    def _build_models(self):
+        c, L, D = self.config, self.latent_dim, self.config.hidden_dim
+        self.latent_diffusion = LatentDiffusionProcess(c.diffusion, latent_dim=L)
+        self.register_buffer("reward_mean", torch.tensor(0.0))
+        self.register_buffer("reward_var", torch.tensor(1.0))
+        self.register_buffer("preference_temperature", torch.tensor(float(c.preference_temperature)))
+        # The reference sizes the score net's obs encoder with latent_dim (active_inference.py:75-80) and then feeds it raw
+        # observations, which only works when latent_dim == observation_dim.  In state mode we size it with the
+        # true observation_dim: identical when the reference runs at all, and well-defined (parity unpinned) otherwise.
+        score_obs_dim = L if self.is_pixel_observation else self.observation_dim
+        self.latent_score_network = LatentScoreNetwork(latent_dim=L, observation_dim=score_obs_dim, hidden_dim=D, use_attention=True)
+        self.policy_network = DiffusionConditionedPolicy(latent_dim=L, action_dim=self.action_dim, hidden_dim=D, use_state_dependent_std=True)
+        self.value_network = ValueNetwork(state_dim=L, hidden_dim=D, time_embed_dim=128, num_layers=3)
+        self.latent_dynamics = LatentDynamicsModel(state_dim=L, action_dim=self.action_dim, hidden_dim=D, num_layers=3)
+        if self.is_pixel_observation:
+            raise NotImplementedError("pixel-mode DiffusionActiveInference (ConvDecoder, feature_decoder) lands with the DrQ-v2 encoder path")
+        p = self.epistemic_dropout_rate
+        stage = lambda i, o: nn.Sequential(nn.Linear(i, o), nn.LayerNorm(o), nn.SiLU(), nn.Dropout(p))
+        self.observation_decoder = nn.ModuleList([stage(L, 2 * D), stage(2 * D, 2 * D), stage(2 * D, D), nn.Linear(D, self.observation_dim)])
+        self.epistemic_estimator = FunctionSpaceEpistemicEstimator(self.observation_decoder, L, self.observation_dim, D,
+                                                                   self.config.spatial_aggregator_output_dim, False, self.device)
+        self.reward_predictor = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Linear(D, D // 2), nn.ReLU(), nn.Linear(D // 2, 2))
+
+    def _to_device_and_flatten(self, device):
+        """Move buffers, then re-home every parameter into its optimiser-group arena (see arena.py)."""
+        for mod in self.modules():
+            for k, b in list(mod._buffers.items()):
+                if b is not None:
+                    mod._buffers[k] = b.to(device)
+        sn, ld = self.latent_score_network, self.latent_diffusion
+        score_named = [("latent_score_network." + n, p) for n, p in sn.arena_order()] + [("latent_diffusion." + n, p) for n, p in ld.named_parameters()]
+        self.arenas = {
+            "score": ParamArena(score_named, device, with_ema=True),
+            "policy": ParamArena([("policy_network." + n, p) for n, p in self.policy_network.named_parameters()], device),
+            "value": ParamArena([("value_network." + n, p) for n, p in self.value_network.named_parameters()], device),
+            "dynamics": ParamArena([("latent_dynamics." + n, p) for n, p in self.latent_dynamics.named_parameters()], device),
+        }
+        frozen = [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
+        frozen += [("reward_predictor." + n, p) for n, p in self.reward_predictor.named_parameters()]
+        frozen += [("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters() if not n.startswith("decoder.")]
+        self.arenas["frozen"] = ParamArena(frozen, device)   # never stepped; an arena only for alignment + one-shot zeroing
+        self._dec_tab = TableCache(lambda: nat.decoder_table(params_dict(self.observation_decoder), ""))
+        self._rew_tab = TableCache(lambda: nat.reward_table(params_dict(self.reward_predictor), ""))
+        self._epi_tab = TableCache(lambda: nat.epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
+                                                                 if not n.startswith("decoder.")}, ""))
+        self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
+        self.device = torch.device(device)
+
+    def to(self, device, *a, **k):
+        device = torch.device(device) if not isinstance(device, torch.device) else device
+        if device.type != "cuda":
+            raise RuntimeError("aid_amd modules live on the GPU; no CPU path exists")
+        if device != self.device and not (device.index is None and self.device.type == "cuda"):
+            self._to_device_and_flatten(device)
+        return self
+
+    def state_dict(self, *a, **k):
+        self.epistemic_estimator.running_mean = self._running_mean.reshape(()).clone()
+        return super().state_dict(*a, **k)
+
+    def load_state_dict(self, sd, strict: bool = True):
+        out = super().load_state_dict(sd, strict=strict)
+        self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
+        self.arenas["score"].reset_ema()
+        self.latent_diffusion._coefs = None
+        return out
+
+    # ------------------------------------------------------------------------------------------ tables
+    def decoder_table(self):
+        return self._dec_tab.get(self.observation_decoder)
+
+    def reward_table(self):
+        return self._rew_tab.get(self.reward_predictor)
+
+    def epistemic_table(self):
+        return self._epi_tab.get(self.epistemic_estimator)
+
+    # ------------------------------------------------------------------------------------------ A4
+    def decode_observation(self, latent: torch.Tensor, decode_to_pixels: bool = True, masks=None) -> torch.Tensor:
+        latent = latent.to(self.device).contiguous().float()
+        if self.observation_decoder.training and masks is None:
+            D, B = self.config.hidden_dim, latent.shape[0]
+            masks = [torch.empty(B, w, device=self.device) for w in (2 * D, 2 * D, D)]
+            for m in masks:
+                nat.fill_dropout_mask(m, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(m.numel()))
+        return nat.decode_observation(self.decoder_table(), latent, masks if self.observation_decoder.training else None, self._ws)
+
+    def predict_reward_from_latent(self, latent: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        out = nat.reward_forward(self.reward_table(), latent.to(self.device).contiguous().float(), self._ws)
+        return out[:, 0], torch.exp(torch.clamp(out[:, 1], min=-5, max=2))
+
+    def update_belief_via_diffusion(self, observation: torch.Tensor, raw_observation: Optional[torch.Tensor] = None,
+                                    noise: Optional[dict] = None) -> Dict[str, torch.Tensor]:
+        """active_inference.py:256-312: reverse-diffusion belief + batch statistics + decoded reconstruction error."""
+        observation = observation.to(self.device).float()
+        if observation.dim() == 1:
+            observation = observation.unsqueeze(0)
+        observation = observation.contiguous()
+        B, L, N = observation.shape[0], self.latent_dim, self.config.diffusion.num_diffusion_steps
+        train = self.latent_score_network.training
+        if noise is None:
+            noise = self.noise.belief(B, L, self.config.hidden_dim, N, train) or {}
+        latent, stats = nat.belief_update(self.latent_score_network.table(), self.decoder_table(), self.latent_diffusion.coefs(), observation, N,
+                                          noise.get("z_init"), noise.get("step_noise"), noise.get("drop_masks"), noise.get("dec_masks"),
+                                          train=train, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+        self.current_latent, self.latent_trajectory = latent, [latent]
+        return {"latent": latent, "latent_mean": stats[:L], "latent_std": stats[L:2 * L], "trajectory_length": N + 1,
+                "reconstruction_error": stats[2 * L], "observation": observation, "raw_observation": raw_observation}
+
+    def denoise_only(self, observation: torch.Tensor, noise: Optional[dict] = None) -> torch.Tensor:
+        """The reverse loop without the diagnostic decode/statistics: what train_step needs (it discards the rest)."""
+        observation = observation.to(self.device).float().contiguous()
+        N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
+        if noise is None:
+            noise = self.noise.belief(observation.shape[0], self.latent_dim, self.config.hidden_dim, N, train) or {}
+        return nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), observation, N, noise.get("z_init"),
+                                noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
+                                offset=self.noise.next_offset(), ws=self._ws)
+
+    def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
+        """Two independent belief updates (state_agent.py:135-140) as ONE reverse loop over 2B rows: the batch-256 layers are
+        latency-bound, so doubling the rows per launch is nearly free.  Returns [2B, L] (rows of obs_a first)."""
+        B, N, train = obs_a.shape[0], self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
+        if noise_a is None:
+            noise_a = self.noise.belief(B, self.latent_dim, self.config.hidden_dim, N, train)
+            noise_b = self.noise.belief(B, self.latent_dim, self.config.hidden_dim, N, train)
+        noise = {}
+        if noise_a is not None:
+            for k, dim in (("z_init", 0), ("step_noise", 1), ("drop_masks", 1)):
+                if noise_a.get(k) is not None:
+                    noise[k] = torch.cat([noise_a[k], noise_b[k]], dim=dim).contiguous()
+        obs = torch.cat([obs_a.to(self.device).float(), obs_b.to(self.device).float()], dim=0).contiguous()
+        return nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), obs, N, noise.get("z_init"),
+                                noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
+                                offset=self.noise.next_offset(), ws=self._ws)
+
+    # ------------------------------------------------------------------------------------------ A8 / A10
+    def compute_expected_free_energy_diffusion(self, latent: torch.Tensor, horizon: int = 5, num_trajectories: int = 10,
+                                               num_ambiguity_samples: int = 10, noise: Optional[dict] = None, backward: bool = False
+                                               ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        latent = latent.to(self.device).contiguous().float()
+        c = self.config
+        if noise is None:
+            noise = self.noise.efe(latent.shape[0], self.latent_dim, self.action_dim, horizon, num_trajectories, num_ambiguity_samples)
+        efe, info = nat.efe_step(self.policy_network.table(), self.policy_network.grad_table() if backward else None, self.latent_dynamics.table(),
+                                 self.reward_table(), self.value_network.table(), self.decoder_table(), self.epistemic_table(), latent,
+                                 self._running_mean, horizon, num_trajectories, num_ambiguity_samples, noise=noise,
+                                 train=self.epistemic_estimator.training, epistemic_weight=c.epistemic_weight, pragmatic_weight=c.pragmatic_weight,
+                                 consistency_weight=c.consistency_weight, discount=c.discount_factor, temperature=float(c.preference_temperature),
+                                 mine_alpha=self.epistemic_estimator.alpha, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+        out = {k: info[i] for i, k in enumerate(nat.EFE_INFO) if k != "policy_loss"}
+        out.update({"num_trajectories": num_trajectories, "horizon": horizon, "epistemic/running_mean": self._running_mean[0],
+                    "policy_loss": info[0]})
+        return efe, out
+
+    def compute_epistemic_value(self, next_latent_mean, next_latent_logvar, num_samples: int = 5):
+        raise NotImplementedError("the MINE estimator is evaluated inside compute_expected_free_energy_diffusion (aid_efe_step)")
+
+    def train_epistemic_estimator(self, latents, actions, next_latents):
+        raise NotImplementedError("never runs in the reference either: `epistemic_optimizer` is not created by the concrete agents "
+                                  "(SURVEY Appendix A, D3); parity unpinned, scheduled after §8(a-e)")
+
+    def reparameterize(self, mean: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
+        eps = torch.empty_like(mean)
+        nat.fill_normal(eps, self.noise.seed, self.noise.next_offset(eps.numel()))
+        return mean + eps * torch.exp(0.5 * logvar)
+
+    def predict_next_latent(self, latent: torch.Tensor, action: torch.Tensor):
+        mean = self.latent_dynamics.predict_next_mean(latent.to(self.device), action.to(self.device))
+        return mean, torch.full_like(mean, float(np.log(0.1)))
+
+    # ------------------------------------------------------------------------------------------ A5 / A7
+    def compute_diffusion_elbo(self, observations: torch.Tensor, rewards: torch.Tensor, latents: Optional[torch.Tensor] = None,
+                               raw_observations: Optional[torch.Tensor] = None, noise: Optional[dict] = None
+                               ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """Forward + backward of -ELBO in one native call; gradients are ACCUMULATED into the score arena
+        (`agent.score_optimizer.zero_grad()` first, as the reference does)."""
+        observations = observations.to(self.device).contiguous().float()
+        rewards = rewards.to(self.device).contiguous().float()
+        if latents is None:
+            latents = self.update_belief_via_diffusion(observations, raw_observations)["latent"]
+        latents = latents.contiguous().float()
+        first = not hasattr(self, "time_importance_weights")
+        if first:
+            self.time_importance_weights = torch.ones(100, device=self.device)
+        c, B = self.config, observations.shape[0]
+        if noise is None:
+            noise = self.noise.elbo(B, self.latent_dim, c.hidden_dim, first, self.time_importance_weights)
+        metrics, t, per = nat.elbo_step(self.latent_score_network.table(), self.latent_score_network.grad_table(), self.latent_diffusion.table(),
+                                        self.latent_diffusion.grad_table(), self.decoder_table(), self.reward_table(), observations, rewards, latents,
+                                        self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training,
+                                        kl_weight=c.kl_weight, diffusion_weight=c.diffusion_weight, reward_weight=c.reward_weight, gp_weight=0.1,
+                                        seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+        info = {k: metrics[i] for i, k in enumerate(nat.ELBO_METRICS) if k != "loss"}
+        self._last_elbo = {"t": t, "per_sample_losses": per}
+        return metrics[8], info
+
+    def _compute_gradient_penalty(self, *a, **k):
+        raise NotImplementedError("the gradient penalty (value and double backward) is part of aid_elbo_step")
+
+    # ------------------------------------------------------------------------------------------ A11
+    def compute_lambda_returns(self, rewards, values, next_values, dones, lambda_: float = 0.95, n_steps: int = 5,
+                               exclude_immediate_rewards: bool = False) -> torch.Tensor:
+        if exclude_immediate_rewards:
+            raise NotImplementedError("exclude_immediate_rewards=True is never used by the reference (state_agent.py:198-205)")
+        f = lambda x: x.to(self.device).float().contiguous()
+        return nat.lambda_returns(f(rewards), f(next_values), f(dones), self.config.discount_factor, lambda_, n_steps)
+
+    # ------------------------------------------------------------------------------------------ act
+    def act(self, observation: torch.Tensor, deterministic: bool = False, raw_observation: Optional[torch.Tensor] = None):
+        """active_inference.py:478-531.  Returns (action on the host, info dict of floats)."""
+        belief = self.update_belief_via_diffusion(observation, raw_observation)
+        latent = belief["latent"]
+        efe, efe_info = self.compute_expected_free_energy_diffusion(latent, horizon=self.config.efe_horizon)
+        action, log_prob, dist = self.policy_network(latent, deterministic=deterministic)
+        action = action.cpu()
+        if action.dim() == 2 and action.shape[0] == 1:
+            action = action.squeeze(0)
+        info = {**belief, "expected_free_energy": float(efe.mean()), "action_log_prob": float(log_prob.mean()),
+                "policy_entropy": float(dist.entropy().sum(dim=-1).mean()),
+                **{k: (float(v) if torch.is_tensor(v) else v) for k, v in efe_info.items()}}
+        return action, info

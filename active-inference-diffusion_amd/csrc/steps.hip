@@ -112,6 +112,65 @@ __global__ void fokker_planck_kernel(double* __restrict__ mean, double* __restri
     if (ent) ent[b] = e;
 }
 
+// p_sample with a given score (diffusion.py:208-255): z0 = (z + c0 s) c1 ; mean = c2 z0 + c3 z ; + c4 eps for t > 0
+__global__ void p_sample_kernel(const float* __restrict__ z, const float* __restrict__ score, const float* __restrict__ eps,
+                                const float* __restrict__ coef, int step, float* __restrict__ out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float zt = z[i];
+    const float z0 = (zt + coef[0] * score[i]) * coef[1];
+    float v = coef[2] * z0 + coef[3] * zt;
+    if (step > 0 && eps) v += coef[4] * eps[i];
+    out[i] = v;
+}
+// RunningMeanStd.update + normalize (aid/agents/base_agent.py:24-52) in fp64 on device, no host round trip.
+// state: [3] doubles (mean, var, count).
+__global__ void reward_normalize_kernel(const float* __restrict__ r, int B, double* __restrict__ state, float* __restrict__ out) {
+    __shared__ double sh[16];
+    __shared__ double s_mean, s_var;
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) acc += (double)r[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w]; s_mean = t / B; }
+    __syncthreads();
+    const double bm = s_mean;
+    acc = 0.0;
+    for (int i = threadIdx.x; i < B; i += blockDim.x) { const double d = (double)r[i] - bm; acc += d * d; }
+    acc = wave_sum_d(acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0; for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sh[w];
+        const double bv = t / B, bc = (double)B;
+        const double mean = state[0], var = state[1], cnt = state[2];
+        const double delta = bm - mean, tot = cnt + bc;
+        const double new_mean = mean + delta * bc / tot;
+        const double m2 = var * cnt + bv * bc + delta * delta * cnt * bc / tot;
+        state[0] = new_mean; state[1] = m2 / tot; state[2] = tot;
+        s_mean = new_mean; s_var = m2 / tot;
+    }
+    __syncthreads();
+    const double mu = s_mean, sd = sqrt(s_var + 1e-8);
+    for (int i = threadIdx.x; i < B; i += blockDim.x) out[i] = (float)(((double)r[i] - mu) / sd);
+}
+
+// FreeEnergyComputation.compute_loss reductions (free_energy.py:62-78): out = mean_b sum_l of
+// (z-mu_p)^2, (o-z)^2, s^2
+__global__ void free_energy_terms_kernel(const float* __restrict__ z, const float* __restrict__ mu, const float* __restrict__ o,
+                                         const float* __restrict__ sc, int B, int L, float* __restrict__ out) {
+    __shared__ float sh[16];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int i = threadIdx.x; i < B * L; i += blockDim.x) {
+        const float d0 = z[i] - mu[i], d1 = o[i] - z[i], s_ = sc[i];
+        a0 += d0 * d0; a1 += d1 * d1; a2 += s_ * s_;
+    }
+    const float s0 = wgs(a0, sh); const float s1 = wgs(a1, sh); const float s2 = wgs(a2, sh);
+    if (threadIdx.x == 0) { out[0] = s0 / (float)B; out[1] = s1 / (float)B; out[2] = s2 / (float)B; }
+}
+
 }  // namespace aid
 
 using namespace aid;
@@ -193,6 +252,27 @@ int aid_reward_forward(const AidRewardNet* rew, int B, const float* z, float* ou
     Workspace ws(wsp, ws_bytes); RewardSave sv;
     AID_TRY(reward_fwd(*rew, B, z, rew->L, sv, ws, (hipStream_t)stream));
     return copy_f32(sv.out, out2, (size_t)B * 2, (hipStream_t)stream);
+}
+
+int aid_p_sample(const float* z, const float* score, const float* eps, const float* coefs, int step, int B, int L, float* out, void* stream) {
+    AID_REQUIRE(z && score && coefs && out, AID_E_NULL, "aid_p_sample: null tensor");
+    const int n = B * L;
+    if (n == 0) return AID_OK;
+    hipLaunchKernelGGL(p_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, z, score, eps, coefs + 5 * step, step, out, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+int aid_reward_normalize(const float* rewards, int B, double* state, float* out, void* stream) {
+    AID_REQUIRE(rewards && state && out, AID_E_NULL, "aid_reward_normalize: null tensor");
+    AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_reward_normalize: B=%d", B);
+    hipLaunchKernelGGL(reward_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, B, state, out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_free_energy_terms(const float* states, const float* prior_mean, const float* obs, const float* score, int B, int L, float* out3,
+                          void* stream) {
+    AID_REQUIRE(states && prior_mean && obs && score && out3, AID_E_NULL, "aid_free_energy_terms: null tensor");
+    hipLaunchKernelGGL(free_energy_terms_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, states, prior_mean, obs, score, B, L, out3);
+    AID_LAUNCH_CHECK(); return AID_OK;
 }
 
 int aid_replay_gather(const float* obs, const float* next_obs, const float* actions, const float* rewards, const float* dones,

@@ -243,6 +243,17 @@ int aid_predict_next_latent(const AidDynamicsNet* dyn, int B, const float* z, co
                             size_t ws_bytes, void* stream);
 int aid_reward_forward(const AidRewardNet* rew, int B, const float* z, float* out2, void* ws, size_t ws_bytes, void* stream);
 
+/* A15 FreeEnergyComputation.compute_loss reductions (aid/core/free_energy.py:62-78); obs must be [B,L] like states.
+ * out3 = mean_b sum_l of (z-mu_p)^2, (o-z)^2, score^2. */
+int aid_free_energy_terms(const float* states, const float* prior_mean, const float* obs, const float* score, int B, int L,
+                          float* out3, void* stream);
+/* p_sample with a caller-supplied score (aid/core/diffusion.py:208-255); eps may be NULL (deterministic / t = 0). */
+int aid_p_sample(const float* z, const float* score, const float* eps, const float* coefs, int step, int B, int L, float* out,
+                 void* stream);
+/* A0': RunningMeanStd.update + normalize (aid/agents/base_agent.py:24-52), fp64 on device.  state: [3] doubles
+ * (mean, var, count), updated in place; out[B] = (r - mean)/sqrt(var + 1e-8) with the UPDATED statistics. */
+int aid_reward_normalize(const float* rewards, int B, double* state, float* out, void* stream);
+
 /* ---- A0: ReplayBuffer.sample gather (aid/utils/buffers.py:83-111), device-resident ring arrays.
  * idx: [B] int64 row indices.  One coalesced pass over the 2*O + A + 2 floats of each transition. */
 int aid_replay_gather(const float* obs, const float* next_obs, const float* actions, const float* rewards, const float* dones,

@@ -1,0 +1,70 @@
+"""Test helper: a NoiseSource that replays the reference's draws (oracle.noise.NoiseStream, reference call order)
+into the layouts the native entry points take.  Lives under tests/ — the product never imports the oracle."""
+import numpy as np
+import torch
+
+from aid_amd.noise import NoiseSource
+from oracle import aid_oracle as orc
+from oracle.noise import NoiseStream
+
+
+def dev(x):
+    return torch.as_tensor(np.ascontiguousarray(x), dtype=torch.float32).cuda().contiguous()
+
+
+class ParityNoise(NoiseSource):
+    def __init__(self, key: int):
+        super().__init__(seed=0)
+        self.ns = NoiseStream(key)
+
+    def rekey(self, key: int):
+        self.ns = NoiseStream(key)
+
+    def replay_indices(self, size, batch):
+        return self.ns.randint(0, size, batch)
+
+    def belief(self, B, L, D, N, train):
+        ns = self.ns
+        z0 = ns.randn(B, L)
+        eps = np.zeros((N, B, L), np.float32)
+        masks = np.ones((N, B, D), np.float32) if train else None
+        for t in reversed(range(N)):
+            if train:
+                masks[t] = ns.dropout_mask((B, D), 0.1)
+            if t > 0:
+                eps[t] = ns.randn(B, L)
+        dec = [dev(ns.dropout_mask((B, w), 0.2)) for w in (2 * D, 2 * D, D)] if train else None   # decode_observation masks
+        return {"z_init": dev(z0), "step_noise": dev(eps), "drop_masks": dev(masks) if train else None, "dec_masks": dec}
+
+    def elbo(self, B, L, D, first_call, time_importance):
+        ns = self.ns
+        n = {"dec_mask0": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask1": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask2": ns.dropout_mask((B, D), 0.2)}
+        n["t"] = ns.rand(B) if first_call else orc.importance_sample_time(time_importance.detach().cpu(), B, ns).numpy()
+        n["eps"] = ns.randn(B, L); n["score_mask"] = ns.dropout_mask((B, D), 0.1); n["gp_mask"] = ns.dropout_mask((B, D), 0.1)
+        n["prior_eps"] = ns.randn(B, L)
+        return {k: dev(v) for k, v in n.items()}
+
+    def efe(self, B, L, A, H, K, S):
+        ns = self.ns
+        M, R = K * B, K * S * B
+        n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),
+             "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((H, 4, R, L), np.float32),
+             "proj_mask": np.zeros((H, R, 512), np.float32), "mine_mask": np.zeros((H, 4, R, 512), np.float32),
+             "perms": np.zeros((H, K, S, B), np.int32)}
+        for k in range(K):
+            rs = slice(k * S * B, (k + 1) * S * B)
+            for t in range(H):
+                n["policy_eps"][t, k * B:(k + 1) * B] = ns.randn(B, A)
+                n["reparam_eps"][t, k * B:(k + 1) * B] = ns.randn(B, L)
+                for s_ in range(S):
+                    n["mine_z_eps"][t, k * S * B + s_ * B:k * S * B + (s_ + 1) * B] = ns.randn(B, L)
+                for j in range(4):
+                    n["mine_delta"][t, j, rs] = ns.randn(S * B, L)
+                n["proj_mask"][t, rs] = ns.dropout_mask((S * B, 512), 0.1)
+                n["mine_mask"][t, 0, rs] = ns.dropout_mask((S * B, 512), 0.1)
+                n["mine_mask"][t, 1, rs] = ns.dropout_mask((S * B, 512), 0.1)
+                for s_ in range(S):
+                    n["perms"][t, k, s_] = ns.randperm(B)
+                n["mine_mask"][t, 2, rs] = ns.dropout_mask((S * B, 512), 0.1)
+                n["mine_mask"][t, 3, rs] = ns.dropout_mask((S * B, 512), 0.1)
+        return {k: (torch.from_numpy(v).cuda().contiguous() if k == "perms" else dev(v)) for k, v in n.items()}

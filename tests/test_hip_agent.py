@@ -1,0 +1,131 @@
+"""GPU: the drop-in surface (DiffusionStateAgent.train_step / act, state_dict layout) against the reference's own
+numbers (tests/golden, two full train_steps with K=10, S=10) and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import aid_oracle as orc
+from oracle.noise import NoiseStream
+from oracle.weights import draw_params, param_specs
+from parity_noise import ParityNoise
+
+
+class Box:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class FakeEnv:
+    def __init__(self, O, A):
+        self.observation_space, self.action_space = Box((O,)), Box((A,))
+
+
+def _agent(O, A, D, N, H, B, cap=64):
+    import aid_amd
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=O, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+    return aid_amd.DiffusionStateAgent(FakeEnv(O, A), cfg, aid_amd.TrainingConfig(buffer_size=cap))
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_state_dict_layout_and_golden_train_steps(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"state_{tag}.npz"))
+    O, A, L, D, N, B, H = (int(g[k]) for k in ("O", "A", "L", "D", "N", "B", "H"))
+    agent = _agent(O, A, D, N, H, B)
+    ai = agent.active_inference
+    specs = param_specs(O, A, L, D, N)
+    sd = ai.state_dict()
+    names = [k for k in sd if not k.startswith("epistemic_estimator.decoder.")]
+    assert names == [n for n, _ in specs]                                   # reference key order
+    assert all(tuple(sd[n].shape) == s for n, s in specs)
+    assert sum(1 for k in sd if k.startswith("epistemic_estimator.decoder.")) == 14   # aliases of observation_decoder.*
+    p = draw_params(specs, int(g["weights_key"]), orc.schedule_tables(N))
+    full = dict(p); full.update({k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd if k.startswith("epistemic_estimator.decoder.")})
+    ai.load_state_dict(full, strict=True)
+    bs = NoiseStream(int(g["store_key"])); cap = int(g["store_cap"])
+    store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32), "rewards": bs.randn(cap),
+             "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+    for i in range(cap):
+        agent.replay_buffer.add(store["observations"][i], store["actions"][i], float(store["rewards"][i]), store["next_observations"][i], bool(store["dones"][i]))
+    pn = ParityNoise(0)
+    ai.noise = pn; agent.replay_buffer.index_source = pn
+    for step in (1, 2):
+        pn.rekey(int(g[f"ts{step}_key"]))
+        m = agent.train_step()
+        for k in g.files:
+            if k.startswith(f"ts{step}_metric/"):
+                name = k.split("/", 1)[1]
+                if name in m:
+                    np.testing.assert_allclose(m[name], g[k], rtol=5e-3, atol=5e-5, err_msg=f"step {step} {name}")
+        sd = ai.state_dict()
+        for k in g.files:
+            if k.startswith(f"ts{step}_param/"):
+                np.testing.assert_allclose(sd[k.split("/", 1)[1]].cpu().numpy(), g[k], rtol=1e-3, atol=2e-6, err_msg=k)
+        # every parameter, via checksums of the reference's post-step state_dict
+        cs = np.array([float(sd[n].double().sum()) for n, _ in specs])
+        bad = np.abs(cs - g[f"ts{step}_checksum"]) > 2e-5 * g[f"ts{step}_abssum"] + 2e-5
+        assert not bad.any(), [specs[i][0] for i in np.nonzero(bad)[0]]
+        np.testing.assert_allclose(agent.score_ema.shadow["output_proj.2.weight"].cpu().numpy(),
+                                   g[f"ts{step}_ema/latent_score_network.output_proj.2.weight"], rtol=1e-4, atol=1e-7)
+    # decoder / reward predictor / estimator never move
+    for n in ("observation_decoder.3.weight", "reward_predictor.5.weight"):
+        np.testing.assert_array_equal(sd[n].cpu().numpy(), p[n].numpy())
+
+
+def test_train_step_full_width_vs_oracle():
+    """D=512 (the BASELINE width), small batch/horizon so the CPU oracle finishes in seconds: one whole train_step."""
+    O, A, D, N, H, B = 17, 6, 512, 3, 2, 16
+    agent = _agent(O, A, D, N, H, B)
+    ai = agent.active_inference
+    specs = param_specs(O, A, O, D, N)
+    p = draw_params(specs, 31, orc.schedule_tables(N))
+    sd0 = ai.state_dict()
+    ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+    bs = NoiseStream(8); cap = 64
+    store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32), "rewards": bs.randn(cap),
+             "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+    agent.replay_buffer.add_batch(store["observations"], store["actions"], store["rewards"], store["next_observations"], store["dones"])
+    pn = ParityNoise(555); ai.noise = pn; agent.replay_buffer.index_source = pn
+    m = agent.train_step()
+    st = orc.OracleAgentState(p, N)
+    ns = NoiseStream(555)
+    m_ref = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
+    for k, v in m_ref.items():
+        if k in m and isinstance(v, float):
+            np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=k)
+    sd = ai.state_dict()
+    for n, _ in specs:
+        if n == "epistemic_estimator.running_mean":
+            np.testing.assert_allclose(float(sd[n]), st.running_mean, rtol=1e-3); continue
+        ref = st.p[n].detach().numpy()
+        np.testing.assert_allclose(sd[n].cpu().numpy(), ref, rtol=1e-3, atol=2e-6, err_msg=n)
+
+
+def test_act_and_philox_train_step_run():
+    """Production mode (device Philox): act() returns a finite action of the right shape; train_step returns every
+    reference metric key and changes exactly the four trained groups."""
+    O, A = 17, 6
+    agent = _agent(O, A, 64, 4, 2, 8, cap=32)
+    assert agent.train_step() == {}                      # buffer smaller than the batch (state_agent.py:112-113)
+    rng = np.random.default_rng(0)
+    for _ in range(32):
+        agent.replay_buffer.add(rng.standard_normal(O), rng.uniform(-1, 1, A), float(rng.standard_normal()), rng.standard_normal(O), False)
+    before = {k: v.clone() for k, v in agent.active_inference.state_dict().items()}
+    m = agent.train_step(); m = agent.train_step(); m = agent.train_step()
+    want = {"reconstruction_loss", "kl_loss", "score_matching_loss", "elbo", "reward_loss", "grad_penalty", "mean_time", "loss_weight_mean",
+            "policy_loss", "epistemic_mean", "pragmatic_mean", "consistency_mean", "num_trajectories", "horizon", "epistemic/mi_estimate",
+            "epistemic/joint_term", "epistemic/marginal_term", "epistemic/running_mean", "value_loss", "dynamics_loss"}
+    assert want <= set(m) and all(np.isfinite(v) for v in m.values())
+    after = agent.active_inference.state_dict()
+    moved = {k.split(".")[0] for k in after if after[k].dtype.is_floating_point and not torch.equal(after[k], before[k])}
+    assert {"latent_score_network", "policy_network", "value_network", "latent_dynamics"} <= moved
+    assert "observation_decoder" not in moved and "reward_predictor" not in moved
+    action, info = agent.act(rng.standard_normal(O).astype(np.float32))
+    assert action.shape == (A,) and np.all(np.isfinite(action)) and np.all(np.abs(action) <= 1)
+    assert np.isfinite(info["expected_free_energy"]) and info["latent"].shape == (1, O)
+    import aid_amd.agents as ag
+    assert ag.StateBasedAgent is ag.DiffusionStateAgent

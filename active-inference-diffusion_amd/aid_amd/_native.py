@@ -122,7 +122,8 @@ class AidEfeCfg(C.Structure):
 
 class AidElboCfg(C.Structure):
     _fields_ = [("kl_weight", C.c_float), ("diffusion_weight", C.c_float), ("reward_weight", C.c_float), ("gp_weight", C.c_float),
-                ("train", C.c_int32), ("first_call", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+                ("train", C.c_int32), ("first_call", C.c_int32), ("seed", C.c_uint64), ("offset", C.c_uint64),
+                ("defer_time_importance", C.c_int32), ("_pad", C.c_int32)]
 
 
 def _lin(params, name) -> AidLinear:
@@ -363,7 +364,8 @@ ELBO_METRICS = ("reconstruction_loss", "kl_loss", "score_matching_loss", "elbo",
 
 def elbo_step(net: AidScoreNet, grads: AidScoreNet, dp: AidDiffusionParams, dgrads: AidDiffusionParams, dec: AidDecoderNet,
               rew: AidRewardNet, obs, rewards, latents, time_importance, first_call: bool, noise: dict = None, train=True,
-              kl_weight=0.1, diffusion_weight=1.0, reward_weight=0.5, gp_weight=0.1, seed=0, offset=0, ws: Workspace = None):
+              kl_weight=0.1, diffusion_weight=1.0, reward_weight=0.5, gp_weight=0.1, seed=0, offset=0, ws: Workspace = None,
+              defer_time_importance=False):
     """compute_diffusion_elbo forward+backward; gradients accumulate into the `grads`/`dgrads` tables.
     -> (metrics [16] device tensor, t [B], per_sample_losses [B])"""
     B = obs.shape[0]
@@ -371,7 +373,8 @@ def elbo_step(net: AidScoreNet, grads: AidScoreNet, dp: AidDiffusionParams, dgra
     noise = noise or {}
     for k, _ in AidElboNoise._fields_:
         setattr(nz, k, _ptr(noise.get(k)).value)
-    cfg = AidElboCfg(kl_weight, diffusion_weight, reward_weight, gp_weight, int(bool(train)), int(bool(first_call)), seed, offset)
+    cfg = AidElboCfg(kl_weight, diffusion_weight, reward_weight, gp_weight, int(bool(train)), int(bool(first_call)), seed, offset,
+                     int(bool(defer_time_importance)), 0)
     metrics = torch.zeros(16, device=obs.device, dtype=torch.float32)
     t_out = torch.empty(B, device=obs.device, dtype=torch.float32)
     per = torch.empty(B, device=obs.device, dtype=torch.float32)
@@ -533,4 +536,16 @@ def rowwise_sqdist_means(states, prior_mean, obs, score):
     out = torch.empty(3, device=states.device, dtype=torch.float32)
     check(lib().aid_free_energy_terms(_ptr(states), _ptr(prior_mean), _ptr(obs), _ptr(score), states.shape[0], states.shape[1], _ptr(out), _stream()),
           "aid_free_energy_terms")
+    return out
+
+
+def time_importance_update(time_importance, t, per_sample, first_call: bool):
+    check(lib().aid_time_importance_update(_ptr(time_importance), _ptr(t), _ptr(per_sample), t.shape[0], int(bool(first_call)), _stream()),
+          "aid_time_importance_update")
+
+
+def reward_normalize_global(stats_src, rewards, state):
+    out = torch.empty_like(rewards)
+    check(lib().aid_reward_normalize_global(_ptr(stats_src), stats_src.shape[0], _ptr(rewards), rewards.shape[0], C.c_void_p(state.data_ptr()),
+                                            _ptr(out), _stream()), "aid_reward_normalize_global")
     return out

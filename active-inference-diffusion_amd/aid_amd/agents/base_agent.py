@@ -26,8 +26,11 @@ class RunningMeanStd:
     var = property(lambda self: float(self.state[1]))
     count = property(lambda self: float(self.state[2]))
 
-    def update_and_normalize(self, rewards: torch.Tensor) -> torch.Tensor:
-        """update(x) followed by normalize(x), as train_step does; float32 out."""
+    def update_and_normalize(self, rewards: torch.Tensor, global_rewards: torch.Tensor = None) -> torch.Tensor:
+        """update(x) followed by normalize(x), as train_step does; float32 out.  Data parallel: pass the all-gathered
+        rewards of every rank so the statistics are those of the global batch."""
+        if global_rewards is not None:
+            return nat.reward_normalize_global(global_rewards.contiguous().float(), rewards.contiguous().float(), self.state)
         return nat.reward_normalize(rewards.contiguous().float(), self.state)
 
     def update(self, x):

@@ -14,6 +14,7 @@ import torch
 import torch.nn as nn
 
 from . import _native as nat
+from . import parallel
 
 ALIGN = 64  # floats (256 B): keeps every tensor 16-B aligned for vector loads and LDS-DMA
 
@@ -111,7 +112,17 @@ class ArenaOptimizer:
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
 
-    def step(self):
+    def allreduce_grads(self, async_op: bool = False):
+        """Data parallel: average this group's gradient arena over ranks (one RCCL all-reduce). No-op on one GPU."""
+        self._pending = parallel.allreduce_mean_(self.arena.grad, async_op=async_op)
+        return self._pending
+
+    def step(self, reduce: bool = True):
+        pend = getattr(self, "_pending", None)
+        if pend is not None:
+            pend.wait(); self._pending = None
+        elif reduce:
+            parallel.allreduce_mean_(self.arena.grad)
         self.arena.step(self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"], self.clip_norm, self.ema_decay)
 
     def state_dict(self):

@@ -20,6 +20,7 @@ import torch.nn as nn
 
 from .. import _native as nat
 from ..arena import ParamArena
+from .. import parallel
 from ..models import DiffusionConditionedPolicy, LatentDynamicsModel, LatentScoreNetwork, ValueNetwork
 from ..models._holders import TableCache, native_only, params_dict
 from ..noise import NoiseSource, PhiloxNoise
@@ -287,7 +288,10 @@ class DiffusionActiveInference(nn.Module):
                                         self.latent_diffusion.grad_table(), self.decoder_table(), self.reward_table(), observations, rewards, latents,
                                         self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training,
                                         kl_weight=c.kl_weight, diffusion_weight=c.diffusion_weight, reward_weight=c.reward_weight, gp_weight=0.1,
-                                        seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+                                        seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws,
+                                        defer_time_importance=parallel.is_dp())
+        if parallel.is_dp():   # one global, rank-major order for the order-dependent EMA
+            nat.time_importance_update(self.time_importance_weights, parallel.allgather_cat(t), parallel.allgather_cat(per), first)
         info = {k: metrics[i] for i, k in enumerate(nat.ELBO_METRICS) if k != "loss"}
         self._last_elbo = {"t": t, "per_sample_losses": per}
         return metrics[8], info

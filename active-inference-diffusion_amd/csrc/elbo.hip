@@ -249,6 +249,12 @@ int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, siz
     return AID_OK;
 }
 
+int aid_time_importance_update(float* time_importance, const float* t, const float* per_sample, int n, int first_call, void* stream) {
+    AID_REQUIRE(time_importance && t && per_sample, AID_E_NULL, "aid_time_importance_update: null tensor");
+    hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, time_importance, t, per_sample, n, first_call);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
 size_t aid_decode_workspace(const AidDecoderNet* dec, int B) { return dec && B > 0 ? decoder_ws_bytes(*dec, B) + 1024 : 0; }
 
 int aid_decode_observation(const AidDecoderNet* dec, int B, const float* z, const float* mask0, const float* mask1, const float* mask2,
@@ -401,8 +407,10 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
         ws.release(mk);
     }
     hipLaunchKernelGGL(elbo_metrics_kernel, dim3(1), dim3(64), 0, s, metrics, tmp, cfg->kl_weight, cfg->diffusion_weight, cfg->reward_weight, cfg->gp_weight);
-    hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(64), 0, s, time_importance, t, per, B, cfg->first_call);
-    AID_LAUNCH_CHECK();
+    if (!cfg->defer_time_importance) {
+        hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(64), 0, s, time_importance, t, per, B, cfg->first_call);
+        AID_LAUNCH_CHECK();
+    }
     if (t_out) AID_TRY(copy_f32(t, t_out, B, s));
     if (per_sample_out) AID_TRY(copy_f32(per, per_sample_out, B, s));
     return AID_OK;

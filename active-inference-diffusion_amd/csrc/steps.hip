@@ -125,7 +125,8 @@ __global__ void p_sample_kernel(const float* __restrict__ z, const float* __rest
 }
 // RunningMeanStd.update + normalize (aid/agents/base_agent.py:24-52) in fp64 on device, no host round trip.
 // state: [3] doubles (mean, var, count).
-__global__ void reward_normalize_kernel(const float* __restrict__ r, int B, double* __restrict__ state, float* __restrict__ out) {
+__global__ void reward_normalize_kernel(const float* __restrict__ r, int B, double* __restrict__ state, float* __restrict__ out,
+                                        const float* __restrict__ loc, int Bloc) {
     __shared__ double sh[16];
     __shared__ double s_mean, s_var;
     double acc = 0.0;
@@ -154,7 +155,7 @@ __global__ void reward_normalize_kernel(const float* __restrict__ r, int B, doub
     }
     __syncthreads();
     const double mu = s_mean, sd = sqrt(s_var + 1e-8);
-    for (int i = threadIdx.x; i < B; i += blockDim.x) out[i] = (float)(((double)r[i] - mu) / sd);
+    for (int i = threadIdx.x; i < Bloc; i += blockDim.x) out[i] = (float)(((double)loc[i] - mu) / sd);
 }
 
 // FreeEnergyComputation.compute_loss reductions (free_energy.py:62-78): out = mean_b sum_l of
@@ -264,7 +265,13 @@ int aid_p_sample(const float* z, const float* score, const float* eps, const flo
 int aid_reward_normalize(const float* rewards, int B, double* state, float* out, void* stream) {
     AID_REQUIRE(rewards && state && out, AID_E_NULL, "aid_reward_normalize: null tensor");
     AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_reward_normalize: B=%d", B);
-    hipLaunchKernelGGL(reward_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, B, state, out);
+    hipLaunchKernelGGL(reward_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, rewards, B, state, out, rewards, B);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+int aid_reward_normalize_global(const float* stats_src, int n_stats, const float* rewards, int B, double* state, float* out, void* stream) {
+    AID_REQUIRE(stats_src && rewards && state && out, AID_E_NULL, "aid_reward_normalize_global: null tensor");
+    AID_REQUIRE(B > 0 && n_stats > 0, AID_E_SHAPE, "aid_reward_normalize_global: B=%d n=%d", B, n_stats);
+    hipLaunchKernelGGL(reward_normalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, stats_src, n_stats, state, out, rewards, B);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 

@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: full DiffusionStateAgent.train_step on synthetic replay.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1 directly; N>1 under torch.distributed.run)
+
+Workload (BASELINE.json configs[1]): HalfCheetah-v4 state dims (O=17, A=6, latent=17), batch 256 PER GPU, EFE horizon 5,
+K=10 trajectories, S=10 ambiguity samples, 50 denoise steps, hidden 512, fp32.  A "step" is one complete train_step
+(replay gather, reward normalisation, 3 reverse-diffusion belief updates, ELBO fwd+bwd with gradient penalty, EFE/MINE
+rollout + policy BPTT, value and dynamics updates, four fused clip/AdamW/EMA steps).  Multi-GPU is weak-scaling data
+parallel: every rank owns a replay shard and a 256-row minibatch, gradients are averaged with one RCCL all-reduce per
+optimiser group.  `value` = batch-256 train steps per second summed over ranks.
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the fp32-MFMA GEMM family, measured live with HIP events
+through aid_prof_*), `cpu_baseline` (the oracle's train_step timed on the host cores, rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "active-inference-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np
+import torch
+
+O, A, D, BATCH, HORIZON, NSTEPS = 17, 6, 512, 256, 5, 50
+PEAK_F32_MFMA = 157.3e12       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+# algorithmic FLOPs of one cfg-2 train_step, dead work removed, shared-t time embedding hoisted
+ALGO_FLOP_PER_STEP = 4.54e12
+ALGO_FLOP_PER_DENOISE_ROW_STEP = 46.4e6
+
+
+class _Box:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+class _Env:
+    observation_space, action_space = _Box((O,)), _Box((A,))
+
+
+def make_agent(device, seed=0):
+    import aid_amd
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=BATCH, efe_horizon=HORIZON, latent_dim=O, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
+    torch.manual_seed(seed)
+    agent = aid_amd.DiffusionStateAgent(_Env(), cfg, aid_amd.TrainingConfig(buffer_size=8192))
+    rng = np.random.default_rng(seed)
+    n = 4096
+    agent.replay_buffer.add_batch(rng.standard_normal((n, O)).astype(np.float32), rng.uniform(-1, 1, (n, A)).astype(np.float32),
+                                  rng.standard_normal(n).astype(np.float32), rng.standard_normal((n, O)).astype(np.float32),
+                                  (rng.random(n) < 0.01).astype(np.float32))
+    return agent
+
+
+def host_cores() -> int:
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box exposes 256 logical
+    CPUs but grants a 16-core share; running 256 threads on that quota is slower than 16)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0]); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except Exception:
+            continue
+    return n
+
+
+def cpu_baseline(max_seconds=120.0):
+    """The oracle (oracle/aid_oracle.py, the CPU restatement pinned to the reference) timed on this box's host cores:
+    one full cfg-2 train_step after building state; torch CPU threads = all cores."""
+    from oracle import aid_oracle as orc
+    from oracle.noise import TorchNoise
+    from oracle.weights import draw_params, param_specs
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle train_step on {cores} host cores ...", file=sys.stderr, flush=True)
+    p = draw_params(param_specs(O, A, O, D, NSTEPS), 3, orc.schedule_tables(NSTEPS))
+    st = orc.OracleAgentState(p, NSTEPS)
+    rng = np.random.default_rng(0)
+    batch = {"observations": rng.standard_normal((BATCH, O)).astype(np.float32), "actions": rng.uniform(-1, 1, (BATCH, A)).astype(np.float32),
+             "rewards": rng.standard_normal(BATCH).astype(np.float32), "next_observations": rng.standard_normal((BATCH, O)).astype(np.float32),
+             "dones": np.zeros(BATCH, bool)}
+    t0 = time.time()
+    orc.train_step(st, batch, TorchNoise(0), horizon=HORIZON)
+    dt = time.time() - t0
+    return {"value": 1.0 / dt, "unit": "train steps/s (batch=256)", "cores": cores, "kind": "port",
+            "sample": f"1 full cfg-2 train_step of the oracle (B=256,H=5,K=10,S=10,N=50,D=512), {dt:.1f} s, torch CPU fp32"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+    from aid_amd import _native as nat
+    agent = make_agent(device, seed=rank)
+    if world > 1:
+        agent.enable_data_parallel()
+
+    def sync():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):      # >= 2: the zero-initialised score head makes step-1 gradients degenerate
+        agent.train_step()
+    sync(); t0 = time.perf_counter()
+    for _ in range(args.steps):
+        agent.train_step()
+    sync(); elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt)
+    # ---- outside the timed region: denoise-only rate and the live GEMM roofline (event-bracketed launches)
+    ai = agent.active_inference
+    obs = torch.randn(BATCH, O, device=device)
+    for _ in range(2):
+        ai.denoise_only(obs)
+    torch.cuda.synchronize(); t1 = time.perf_counter(); reps = 5
+    for _ in range(reps):
+        ai.denoise_only(obs)
+    torch.cuda.synchronize(); dn = (time.perf_counter() - t1) / reps
+    nat.prof_enable(True); nat.prof_reset()
+    agent.train_step(); torch.cuda.synchronize()
+    g = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
+    nat.prof_enable(False); nat.prof_reset()
+    if rank != 0:
+        return
+    steps_per_s = args.steps / elapsed
+    achieved = g["flops"] / (g["ms"] * 1e-3) if g["ms"] > 0 else 0.0
+    out = {
+        "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
+        "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "HalfCheetah-v4 state obs (O=17,A=6,L=17), batch=256/GPU, EFE horizon=5, K=10, S=10, 50 denoise steps, hidden=512 "
+                               "(BASELINE configs[1]); full DiffusionStateAgent.train_step", "global_batch": BATCH * world,
+                   "parallelism": f"dp{world}" if world > 1 else "single", "rng": "device Philox4x32-10"},
+        "denoise_steps_per_s": NSTEPS / dn, "denoise_row_steps_per_s": NSTEPS * BATCH / dn,
+        "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
+        "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * steps_per_s / 1e12,
+        "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
+        "roofline": {"bound": "mfma", "kernel": "aid::gemm_{panel,tile}_kernel (fp32 MFMA GEMM family, all launches of one train_step)",
+                     "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA,
+                     "traffic": None, "launches_per_step": g["launches"], "gemm_ms_per_step": g["ms"], "flop_per_step": g["flops"],
+                     "optimizer_GBps": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -176,7 +176,11 @@ typedef struct AidElboCfg {
     float kl_weight, diffusion_weight, reward_weight, gp_weight;
     int32_t train, first_call;
     uint64_t seed, offset;
+    int32_t defer_time_importance, _pad;   /* 1: leave time_importance untouched (data-parallel: caller applies the
+                                              sequential EMA over the all-gathered (t, loss) pairs in global order) */
 } AidElboCfg;
+/* the sequential time-importance EMA of active_inference.py:750-771 over n (t, per-sample loss) pairs, in order */
+int aid_time_importance_update(float* time_importance, const float* t, const float* per_sample, int n, int first_call, void* stream);
 size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B);
 int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDiffusionParams* dp,
                   const AidDiffusionParams* dgrads, const AidDecoderNet* dec, const AidRewardNet* rew, int B,
@@ -253,6 +257,10 @@ int aid_p_sample(const float* z, const float* score, const float* eps, const flo
 /* A0': RunningMeanStd.update + normalize (aid/agents/base_agent.py:24-52), fp64 on device.  state: [3] doubles
  * (mean, var, count), updated in place; out[B] = (r - mean)/sqrt(var + 1e-8) with the UPDATED statistics. */
 int aid_reward_normalize(const float* rewards, int B, double* state, float* out, void* stream);
+/* data-parallel form: statistics are updated from `stats_src` (the rewards of ALL ranks, all-gathered, n_stats of
+ * them), `rewards` (this rank's B) are normalised with the updated statistics. */
+int aid_reward_normalize_global(const float* stats_src, int n_stats, const float* rewards, int B, double* state, float* out,
+                                void* stream);
 
 /* ---- A0: ReplayBuffer.sample gather (aid/utils/buffers.py:83-111), device-resident ring arrays.
  * idx: [B] int64 row indices.  One coalesced pass over the 2*O + A + 2 floats of each transition. */

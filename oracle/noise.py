@@ -76,3 +76,36 @@ class NullNoise:
 
     def __getattr__(self, name):
         raise RuntimeError(f"NullNoise cannot serve '{name}' draws")
+
+
+class TorchNoise:
+    """Fast host RNG with the NoiseStream interface (torch's multi-threaded CPU generators).  Used ONLY by the
+    cpu_baseline leg of bench.py, where the draw VALUES are irrelevant and numpy's single-threaded Philox would dominate
+    the timing (a cfg-2 train_step consumes ~3e9 draws, mostly MINE dropout masks)."""
+
+    def __init__(self, seed: int = 0):
+        import torch
+        self.t = torch
+        self.g = torch.Generator().manual_seed(seed)
+
+    def randn(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        return self.t.randn(*shape, generator=self.g)
+
+    def rand(self, *shape):
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list)):
+            shape = tuple(shape[0])
+        return self.t.rand(*shape, generator=self.g)
+
+    def randperm(self, n):
+        return self.t.randperm(int(n), generator=self.g)
+
+    def randint(self, low, high, n):
+        return self.t.randint(int(low), int(high), (int(n),), generator=self.g).numpy()
+
+    def multinomial(self, probs, n):
+        return self.t.multinomial(self.t.as_tensor(probs, dtype=self.t.float32), int(n), replacement=True, generator=self.g)
+
+    def dropout_mask(self, shape, p):
+        return (self.t.rand(*shape, generator=self.g) >= p).float() / (1.0 - p)

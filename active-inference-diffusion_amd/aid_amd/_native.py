@@ -549,3 +549,8 @@ def reward_normalize_global(stats_src, rewards, state):
     check(lib().aid_reward_normalize_global(_ptr(stats_src), stats_src.shape[0], _ptr(rewards), rewards.shape[0], C.c_void_p(state.data_ptr()),
                                             _ptr(out), _stream()), "aid_reward_normalize_global")
     return out
+
+
+def gemm_force_kernel(k: int):
+    """0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk (benches/tests only)."""
+    check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")

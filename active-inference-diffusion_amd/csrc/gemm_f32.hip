@@ -370,6 +370,139 @@ __global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ring kernel: BMxBN output tile (64x64 with 128-deep stages, or 128x128 with 64-deep stages), 4 waves as 2x2, each
+// wave a (BM/2)x(BN/2) block of 32x32 MFMA tiles over the FULL K (no in-workgroup reduction).  Operand stages arrive
+// by LDS-DMA into a 2-slot ring exactly like the panel kernel (16 x 1-KiB global_load_lds per wave per stage, counted
+// vmcnt, raw barriers), but a workgroup now moves (BM+BN)/(BM*BN) = 1/32 .. 1/64 operand bytes per MAC instead of 1/16:
+// at ~30 GB/s of DMA ingest per CU that is what keeps the fp32 MFMA pipe (614 GFLOP/s per CU) fed.
+// LDS image, k-contiguous operand: rows are stored in groups of RPI = 256/KS rows (one 1-KiB DMA each) + 4 floats pad;
+// k-major operand: [k][rows] unpadded (b32 fragment reads across consecutive lanes, conflict-free).
+// Requirements: K % KS == 0, 16-B aligned rows; k-major operands need rows % BM == 0.
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int KSTAGE, bool KMAJOR>
+struct Ring {
+    static constexpr int RPI = 256 / KSTAGE;                                   // rows per DMA instruction (k-contiguous)
+    static constexpr int GROUP = RPI * KSTAGE + 4;                             // floats per row group incl. pad
+    static constexpr int FLOATS = KMAJOR ? KSTAGE * ROWS : (ROWS / RPI) * GROUP;
+    static constexpr int INSTR = ROWS * KSTAGE / 256;                          // DMA instructions per stage (all waves)
+    __device__ static __forceinline__ int row_off(int r) { return (r / RPI) * GROUP + (r % RPI) * KSTAGE; }
+};
+
+template <int ROWS, int KSTAGE, bool KMAJOR>
+__device__ __forceinline__ void ring_dma(const float* __restrict__ G, int ld, int r0, int R, int k0, float* slot, int wave, int lane) {
+    using RG = Ring<ROWS, KSTAGE, KMAJOR>;
+    constexpr int PER_WAVE = RG::INSTR / 4;
+#pragma unroll
+    for (int j = 0; j < PER_WAVE; ++j) {
+        const int ins = wave * PER_WAVE + j;
+        const float* src; float* dst;
+        if (!KMAJOR) {
+            constexpr int LPR = KSTAGE / 4;                                    // lanes per row
+            const int r = ins * RG::RPI + lane / LPR;
+            int gr = r0 + r; gr = gr < R ? gr : R - 1;
+            src = G + (size_t)gr * ld + k0 + 4 * (lane % LPR);
+            dst = slot + (ins) * RG::GROUP;                                    // group `ins` = rows ins*RPI ..
+        } else {
+            constexpr int LPK = ROWS / 4;                                      // lanes per k-row
+            constexpr int KPI = 64 / LPK;                                      // k-rows per instruction
+            const int kb = ins * KPI;
+            src = G + (size_t)(k0 + kb + lane / LPK) * ld + r0 + 4 * (lane % LPK);
+            dst = slot + kb * ROWS;
+        }
+        __builtin_amdgcn_global_load_lds((gbl_vptr)src, (lds_vptr)dst, 16, 0, 0);
+    }
+}
+
+template <int ROWS, int KSTAGE, bool KMAJOR>
+__device__ __forceinline__ f32x4 ring_frag(const float* __restrict__ slot, int r, int k, int h) {
+    using RG = Ring<ROWS, KSTAGE, KMAJOR>;
+    if (!KMAJOR) return *reinterpret_cast<const f32x4*>(slot + RG::row_off(r) + k + 4 * h);
+    f32x4 v;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) v[q] = slot[(k + 4 * h + q) * ROWS + r];
+    return v;
+}
+
+template <int BM, int BN, int KSTAGE, bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    using RA = Ring<BM, KSTAGE, AKM>; using RB = Ring<BN, KSTAGE, BKM>;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    static_assert((RA::INSTR + RB::INSTR) / 4 == 16, "vmcnt(16) below assumes 16 DMA instructions per wave per stage");
+    float* As = smem; float* Bs = smem + 2 * RA::FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int tile = blockIdx.x;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int ns = g.K / KSTAGE;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    ring_dma<BM, KSTAGE, AKM>(g.A, g.lda, m0, g.M, 0, As, wave, lane);
+    ring_dma<BN, KSTAGE, BKM>(g.B, g.ldb, n0, g.N, 0, Bs, wave, lane);
+    if (ns > 1) {
+        ring_dma<BM, KSTAGE, AKM>(g.A, g.lda, m0, g.M, KSTAGE, As + RA::FLOATS, wave, lane);
+        ring_dma<BN, KSTAGE, BKM>(g.B, g.ldb, n0, g.N, KSTAGE, Bs + RB::FLOATS, wave, lane);
+    }
+    for (int st = 0; st < ns; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < ns) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* a_s = As + cur * RA::FLOATS;
+        const float* b_s = Bs + cur * RB::FLOATS;
+#pragma unroll 2
+        for (int g8 = 0; g8 < KSTAGE / 8; ++g8) {
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = ring_frag<BM, KSTAGE, AKM>(a_s, wm + 32 * i + li, 8 * g8, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = ring_frag<BN, KSTAGE, BKM>(b_s, wn + 32 * j + li, 8 * g8, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (st + 2 < ns) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ring_dma<BM, KSTAGE, AKM>(g.A, g.lda, m0, g.M, (st + 2) * KSTAGE, As + cur * RA::FLOATS, wave, lane);
+            ring_dma<BN, KSTAGE, BKM>(g.B, g.ldb, n0, g.N, (st + 2) * KSTAGE, Bs + cur * RB::FLOATS, wave, lane);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                epilogue_store(g, m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + wn + 32 * j + li, acc[i][j][r]);
+}
+
+template <int BM, int BN, int KSTAGE, bool AKM, bool BKM>
+static int launch_ring(const GemmArgs& g, hipStream_t s) {
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * (Ring<BM, KSTAGE, AKM>::FLOATS + Ring<BN, KSTAGE, BKM>::FLOATS);
+    static bool done = false;
+    if (!done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_ring_kernel<BM, BN, KSTAGE, AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_ring_kernel<BM, BN, KSTAGE, AKM, BKM>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    return AID_OK;
+}
+
 template <bool AKM, bool BKM>
 static int launch_panel(const GemmArgs& g, hipStream_t s) {
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
@@ -410,12 +543,36 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     else     hipLaunchKernelGGL((gemm_splitk_kernel<AKM, BKM, false>), dim3(tm * tn), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
+static int g_force_kernel = 0;   // 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk  (aid_gemm_force_kernel)
+
 template <bool AKM, bool BKM>
 static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
+    {
+        const bool r64_ok = vec && g.K >= 128 && g.K % 128 == 0 && (!AKM || g.M % 64 == 0) && (!BKM || g.N % 64 == 0);
+        const bool r128_ok = vec && g.K >= 64 && g.K % 64 == 0 && (!AKM || g.M % 128 == 0) && (!BKM || g.N % 128 == 0);
+        const bool p32_ok = vec && g.K >= KS && g.K % KS == 0 && (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0);
+        switch (g_force_kernel) {
+            case 1: if (p32_ok) return launch_panel<AKM, BKM>(g, s); break;
+            case 2: if (r64_ok) return launch_ring<64, 64, 128, AKM, BKM>(g, s); break;
+            case 3: if (r128_ok) return launch_ring<128, 128, 64, AKM, BKM>(g, s); break;
+            case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+            case 5: return launch_tile<128, 128, AKM, BKM>(g, vec, s);
+            case 6: return launch_splitk<AKM, BKM>(g, vec, s);
+            default: break;
+        }
+    }
+    // Automatic selection, set by measurement on MI355X (profiles/gemm_shapes_r01.txt): the register-staged 64x64 tile at
+    // 4 workgroups/CU (16 waves hide the global-load latency behind the slow fp32 MFMA) wins whenever it yields >= ~160
+    // tiles; below that the grid cannot fill the chip and the 32x32 LDS-DMA panel kernel (whole K in flight at once,
+    // 4-way in-workgroup split-K) has the shortest critical path.
+    const long t64a = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    if (g_force_kernel == 0 && t64a >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+    {
     const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
                           (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0) && t32 <= 1536;
     if (panel_ok) return launch_panel<AKM, BKM>(g, s);
+    }
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     if (t128 >= 384) return launch_tile<128, 128, AKM, BKM>(g, vec, s);
@@ -424,6 +581,8 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+void gemm_force_kernel(int k) { g_force_kernel = k; }
 
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     AID_REQUIRE(g.A && g.B && g.C, AID_E_NULL, "gemm_f32: null operand");

@@ -16,8 +16,12 @@ int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int a
            float* stats, int M, int D, hipStream_t s);
 
 // cond = LN(x)*gamma+beta + temb[row*ld_temb + c] ; sc = silu(cond).   (score_networks.py:145-153 + adaLN's SiLU)
+// x_mod > 0: row r reads x row (r % x_mod) (obs embedding shared by every step); temb_div > 0: row r adds temb row (r / temb_div)
+// (per-step time embedding), else temb row stride ld_temb (0 = one shared row).
 int ln_cond(const float* x, int ldx, const float* gamma, const float* beta, const float* temb, int ld_temb, float* cond,
-            float* sc, float* stats, int M, int D, hipStream_t s);
+            float* sc, float* stats, int M, int D, hipStream_t s, int x_mod = 0, int temb_div = 0);
+// out[r, :] = a[r % a_rows, :] * mask[r, :]
+int mul_rows_mod(const float* a, int a_rows, const float* mask, float* out, size_t R, int D, hipStream_t s);
 
 // y = LN(x)*(1+scale)+shift, scale = mod[row*ldmod + c], shift = mod[row*ldmod + D + c]  (score_networks.py:257-270)
 int adaln(const float* x, int ldx, const float* mod, int ldmod, float* y, int ldy, float* stats, int M, int D, hipStream_t s);

@@ -60,10 +60,12 @@ int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int a
 
 __global__ void ln_cond_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                                const float* __restrict__ beta, const float* __restrict__ temb, int ld_temb,
-                               float* __restrict__ cond, float* __restrict__ sc, float* __restrict__ stats, int M, int D) {
+                               float* __restrict__ cond, float* __restrict__ sc, float* __restrict__ stats, int M, int D,
+                               int x_mod, int temb_div) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= M) return;
-    const float* xr = x + (size_t)row * ldx;
+    const float* xr = x + (size_t)(x_mod > 0 ? row % x_mod : row) * ldx;
+    if (temb_div > 0) temb += (size_t)(row / temb_div) * D - (size_t)row * ld_temb;
     float mean, rstd; row_stats(xr, D, lane, mean, rstd);
     if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
     for (int c = lane; c < D; c += 64) {
@@ -74,9 +76,9 @@ __global__ void ln_cond_kernel(const float* __restrict__ x, int ldx, const float
     }
 }
 int ln_cond(const float* x, int ldx, const float* gamma, const float* beta, const float* temb, int ld_temb, float* cond,
-            float* sc, float* stats, int M, int D, hipStream_t s) {
+            float* sc, float* stats, int M, int D, hipStream_t s, int x_mod, int temb_div) {
     hipLaunchKernelGGL(ln_cond_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, gamma, beta,
-                       temb, ld_temb, cond, sc, stats, M, D);
+                       temb, ld_temb, cond, sc, stats, M, D, x_mod, temb_div);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -91,7 +93,49 @@ __global__ void adaln_kernel(const float* __restrict__ x, int ldx, const float* 
     for (int c = lane; c < D; c += 64)
         y[(size_t)row * ldy + c] = (xr[c] - mean) * rstd * (1.0f + mr[c]) + mr[D + c];
 }
+// D = 256*NV: each lane keeps NV float4 of the row in registers -> one global read of x, 16-B accesses everywhere
+template <int NV>
+__global__ void adaln_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ mod, int ldmod,
+                                 float* __restrict__ y, int ldy, float* __restrict__ stats, int M) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * ldx);
+    const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
+    const f4* sh = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod + D);
+    f4 v[NV], a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = xr[lane + 64 * i]; a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i]; }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    f4* yr = reinterpret_cast<f4*>(y + (size_t)row * ldy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + b[i][j];
+        yr[lane + 64 * i] = o;
+    }
+}
 int adaln(const float* x, int ldx, const float* mod, int ldmod, float* y, int ldy, float* stats, int M, int D, hipStream_t s) {
+    const bool al = (((uintptr_t)x | (uintptr_t)mod | (uintptr_t)y) & 15) == 0 && ldx % 4 == 0 && ldmod % 4 == 0 && ldy % 4 == 0;
+    const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    if (al && (D == 256 || D == 512 || D == 1024)) {
+        if (D == 256) hipLaunchKernelGGL(adaln_vec_kernel<1>, grid, dim3(256), 0, s, x, ldx, mod, ldmod, y, ldy, stats, M);
+        else if (D == 512) hipLaunchKernelGGL(adaln_vec_kernel<2>, grid, dim3(256), 0, s, x, ldx, mod, ldmod, y, ldy, stats, M);
+        else hipLaunchKernelGGL(adaln_vec_kernel<4>, grid, dim3(256), 0, s, x, ldx, mod, ldmod, y, ldy, stats, M);
+        AID_LAUNCH_CHECK(); return AID_OK;
+    }
     hipLaunchKernelGGL(adaln_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, mod, ldmod, y,
                        ldy, stats, M, D);
     AID_LAUNCH_CHECK(); return AID_OK;
@@ -178,6 +222,18 @@ int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s
     if (n == 0) return AID_OK;
     const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
     hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(256), 0, s, a, b, out, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+__global__ void mul_rows_mod_kernel(const float* __restrict__ a, int a_rows, const float* __restrict__ m, float* __restrict__ o, size_t n, int D) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { const size_t r = i / D; o[i] = a[(r % a_rows) * D + i % D] * m[i]; }
+}
+int mul_rows_mod(const float* a, int a_rows, const float* mask, float* out, size_t R, int D, hipStream_t s) {
+    const size_t n = R * D;
+    if (n == 0) return AID_OK;
+    const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    hipLaunchKernelGGL(mul_rows_mod_kernel, dim3(blocks), dim3(256), 0, s, a, a_rows, mask, out, n, D);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 int copy_f32(const float* a, float* out, size_t n, hipStream_t s) {

@@ -133,7 +133,7 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
     return score_cond_mod(n, B, temb, ld_temb, a, s);
 }
 
-int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s) {
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
     AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     for (int i = 0; i < n.n_blocks; ++i) {
@@ -141,8 +141,12 @@ int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool 
         ScoreBlockActs& b = a.blk[i];
         float* h_out = (i + 1 < n.n_blocks) ? a.blk[i + 1].h_in : a.h_last;
         AID_TRY(adaln(b.h_in, D, a.mod + (size_t)(2 * i) * 2 * D, ldmod, b.nx1, D, b.st1, B, D, s));
-        AID_TRY(linear_fwd(b.nx1, D, w.in_proj_w + (size_t)2 * D * D, w.in_proj_b + 2 * D, b.v, D, B, D, D, ACT_NONE, s));
-        AID_TRY(linear_fwd(b.v, D, w.out_proj_w, w.out_proj_b, b.h_mid, D, B, D, D, ACT_NONE, s, nullptr, b.h_in, D));
+        if (fused) {   // out_proj(V_proj(x)) = x (Wo Wv)^T + (Wo bv + bo): one GEMM (inference paths; weights fixed during the loop)
+            AID_TRY(linear_fwd(b.nx1, D, fused->wov[i], fused->bov[i], b.h_mid, D, B, D, D, ACT_NONE, s, nullptr, b.h_in, D));
+        } else {
+            AID_TRY(linear_fwd(b.nx1, D, w.in_proj_w + (size_t)2 * D * D, w.in_proj_b + 2 * D, b.v, D, B, D, D, ACT_NONE, s));
+            AID_TRY(linear_fwd(b.v, D, w.out_proj_w, w.out_proj_b, b.h_mid, D, B, D, D, ACT_NONE, s, nullptr, b.h_in, D));
+        }
         AID_TRY(adaln(b.h_mid, D, a.mod + (size_t)(2 * i + 1) * 2 * D, ldmod, b.nx2, D, b.st2, B, D, s));
         AID_TRY(linear_fwd(b.nx2, D, w.mlp0_w, w.mlp0_b, b.u, 4 * D, B, 4 * D, D, ACT_GELU, s, keep ? b.a1 : nullptr));
         AID_TRY(linear_fwd(b.u, 4 * D, w.mlp2_w, w.mlp2_b, h_out, D, B, D, 4 * D, ACT_NONE, s, nullptr, b.h_mid, D));
@@ -150,6 +154,25 @@ int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool 
     AID_TRY(adaln(a.h_last, D, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.nxf, D, a.st_f, B, D, s));
     AID_TRY(linear_fwd(a.nxf, D, n.op0_w, n.op0_b, a.p0, D / 2, B, D / 2, D, ACT_SILU, s, a.p0_pre));
     AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
+    return AID_OK;
+}
+
+// Wov = Wo Wv, bov = Wo bv + bo for every block (12 small GEMMs, once per reverse loop)
+int score_fuse_attention(const AidScoreNet& n, Workspace& ws, ScoreFused& f, hipStream_t s) {
+    const int D = n.D;
+    for (int i = 0; i < n.n_blocks; ++i) {
+        f.wov[i] = ws.f32((size_t)D * D); f.bov[i] = ws.f32(D);
+    }
+    AID_WS_OK(ws);
+    for (int i = 0; i < n.n_blocks; ++i) {
+        const AidDiTBlock& w = n.blk[i];
+        GemmArgs g = gemm_args(w.out_proj_w, D, w.in_proj_w + (size_t)2 * D * D, D, f.wov[i], D, D, D, D);   // C[i,j] = sum_k Wo[i,k] Wv[k,j]
+        g.b_kmajor = 1;
+        AID_TRY(gemm_f32(g, s));
+        GemmArgs v = gemm_args(w.in_proj_b + 2 * D, D, w.out_proj_w, D, f.bov[i], D, 1, D, D);               // [1,D] = bv Wo^T + bo
+        v.bias = w.out_proj_b;
+        AID_TRY(gemm_f32(v, s));
+    }
     return AID_OK;
 }
 
@@ -187,10 +210,23 @@ int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const flo
     return AID_OK;
 }
 
+static size_t denoise_chunk_steps(const AidScoreNet& n, int B, int N) {
+    // steps whose (z-independent) conditioning is precomputed together: bound the [C*B, 26D] modulation buffer to ~1.5 GB
+    const size_t per_step = (size_t)B * (2 * n.n_blocks + 1) * 2 * n.D * sizeof(float);
+    size_t c = ((size_t)3 << 29) / (per_step ? per_step : 1);
+    if (c < 1) c = 1;
+    if (c > (size_t)N) c = N;
+    return c;
+}
+
 size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     if (!net || B <= 0 || n_steps <= 0) return 0;
-    const int R = B > n_steps ? B : n_steps;
-    return score_acts_bytes(*net, R, false) + sizeof(float) * ((size_t)n_steps * (net->D + 1) + (size_t)B * (3 * net->L + net->D)) + 8192;
+    const size_t D = net->D, L = net->L, C = denoise_chunk_steps(*net, B, n_steps), NA = 2 * net->n_blocks + 1;
+    size_t n = score_acts_bytes(*net, B > n_steps ? B : n_steps, false);
+    n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D));
+    n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
+    n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
+    return n + (1 << 16);
 }
 
 int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, const float* obs, const float* z_init,
@@ -201,51 +237,85 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, c
     AID_REQUIRE(B > 0 && N > 0, AID_E_SHAPE, "aid_denoise_loop: B=%d N=%d", B, N);
     hipStream_t s = (hipStream_t)stream;
     const AidScoreNet& n = *net;
-    const int D = n.D, L = n.L;
+    const int D = n.D, L = n.L, NA = 2 * n.n_blocks + 1, ldmod = NA * 2 * D;
+    const int C = (int)denoise_chunk_steps(n, B, N);
     Workspace ws(wsp, ws_bytes);
     float* times = ws.f32(N);
     float* temb_table = ws.f32((size_t)N * D);
     float* zA = ws.f32((size_t)B * L);
     float* zB = ws.f32((size_t)B * L);
     float* eps_buf = ws.f32((size_t)B * L);
-    float* mask_buf = ws.f32((size_t)B * D);
+    float* o2_shared = ws.f32((size_t)B * D);
+    float* mask_all = ws.f32((size_t)C * B * D);
+    float* actA = ws.f32((size_t)C * B * D);
+    float* actB = ws.f32((size_t)C * B * D);
+    float* sc_all = ws.f32((size_t)C * B * D);
+    float* mod_all = ws.f32((size_t)C * B * ldmod);
+    ScoreFused fused;
+    AID_TRY(score_fuse_attention(n, ws, fused, s));
     ScoreActs a;
-    const int R = B > N ? B : N;
-    AID_TRY(score_acts_alloc(n, R, false, ws, a));
+    AID_TRY(score_acts_alloc(n, B > N ? B : N, false, ws, a));
+    float* mod_own = a.mod;
 
-    // per-loop invariants: [N,D] time-embedding table (steps 0,1 on the continuous branch), obs head
+    // ---- per-loop invariants: [N,D] time-embedding table (steps 0,1 on the continuous branch, D8), obs-encoder head
     hipLaunchKernelGGL(iota_kernel, dim3((N + 255) / 256), dim3(256), 0, s, times, N);
     AID_LAUNCH_CHECK();
     AID_TRY(score_time_embed(n, N, times, 2, a, s));
     AID_TRY(copy_f32(a.temb, temb_table, (size_t)N * D, s));
     AID_TRY(score_obs_stage0(n, B, obs, a, s));
-    if (!train) AID_TRY(score_cond(n, B, nullptr, temb_table, 0, a, s));  // fills o2 once; cond redone per step
-
+    if (!train) {   // eval: the obs embedding (pre-LN) is the same for every step
+        AID_TRY(linear_fwd(a.x1n, D, n.oe4_w, n.oe4_b, a.o1, D, B, D, D, ACT_NONE, s));
+        AID_TRY(ln_act(a.o1, D, n.oe5_g, n.oe5_b, ACT_SILU, nullptr, a.x2, D, nullptr, B, D, s));
+        AID_TRY(linear_fwd(a.x2, D, n.oe7_w, n.oe7_b, o2_shared, D, B, D, D, ACT_NONE, s));
+    }
     uint64_t ctr = offset;
     if (z_init) AID_TRY(copy_f32(z_init, zA, (size_t)B * L, s));
     else { AID_TRY(philox_fill(zA, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; }
     if (traj) AID_TRY(copy_f32(zA, traj, (size_t)B * L, s));
     float* z = zA; float* zn = zB;
-    for (int t = N - 1; t >= 0; --t) {
-        const float* temb = temb_table + (size_t)t * D;
+    for (int t_hi = N - 1; t_hi >= 0;) {
+        const int cs = t_hi + 1 < C ? t_hi + 1 : C;      // steps in this chunk: t_lo .. t_hi
+        const int t_lo = t_hi - cs + 1;
+        const int R = cs * B;
+        // ---- everything that does not depend on z, for all steps of the chunk at once (row j*B + b <-> step t_lo + j):
+        //      obs-encoder tail under each step's dropout mask, cond = temb[t] + obs_emb, SiLU, all 13 adaLN modulations
         if (train) {
-            const float* mask = drop_masks ? drop_masks + (size_t)t * B * D : nullptr;
-            if (!mask) { AID_TRY(philox_fill(mask_buf, (size_t)B * D, 2, 0.1f, seed, ctr, s)); ctr += ((size_t)B * D + 3) / 4; mask = mask_buf; }
-            AID_TRY(score_cond(n, B, mask, temb, 0, a, s));
+            const float* masks = drop_masks ? drop_masks + (size_t)t_lo * B * D : nullptr;
+            if (!masks) { AID_TRY(philox_fill(mask_all, (size_t)R * D, 2, 0.1f, seed, ctr, s)); ctr += ((size_t)R * D + 3) / 4; masks = mask_all; }
+            AID_TRY(mul_rows_mod(a.x1n, B, masks, actA, (size_t)R, D, s));
+            AID_TRY(linear_fwd(actA, D, n.oe4_w, n.oe4_b, actB, D, R, D, D, ACT_NONE, s));
+            AID_TRY(ln_act(actB, D, n.oe5_g, n.oe5_b, ACT_SILU, nullptr, actA, D, nullptr, R, D, s));
+            AID_TRY(linear_fwd(actA, D, n.oe7_w, n.oe7_b, actB, D, R, D, D, ACT_NONE, s));
+            AID_TRY(ln_cond(actB, D, n.oe8_g, n.oe8_b, temb_table + (size_t)t_lo * D, 0, nullptr, sc_all, nullptr, R, D, s, 0, B));
         } else {
-            AID_TRY(score_cond_mod(n, B, temb, 0, a, s));
+            AID_TRY(ln_cond(o2_shared, D, n.oe8_g, n.oe8_b, temb_table + (size_t)t_lo * D, 0, nullptr, sc_all, nullptr, R, D, s, B, B));
         }
-        AID_TRY(score_trunk(n, B, z, a, false, s));
-        const float* eps = nullptr;
-        if (t > 0) {
-            eps = step_noise ? step_noise + (size_t)t * B * L : nullptr;
-            if (!eps) { AID_TRY(philox_fill(eps_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; eps = eps_buf; }
+        if (score_ada_contiguous(n)) {
+            AID_TRY(linear_fwd(sc_all, D, n.blk[0].ada1_w, n.blk[0].ada1_b, mod_all, ldmod, R, ldmod, D, ACT_NONE, s));
+        } else {
+            for (int i = 0; i < NA; ++i) {
+                const float* w = i == NA - 1 ? n.adaf_w : ((i & 1) ? n.blk[i / 2].ada2_w : n.blk[i / 2].ada1_w);
+                const float* b = i == NA - 1 ? n.adaf_b : ((i & 1) ? n.blk[i / 2].ada2_b : n.blk[i / 2].ada1_b);
+                AID_TRY(linear_fwd(sc_all, D, w, b, mod_all + (size_t)i * 2 * D, ldmod, R, 2 * D, D, ACT_NONE, s));
+            }
         }
-        float* dst = (t == 0) ? z_out : zn;
-        AID_TRY(head_p_sample(a.raw, n.output_multiplier, (float)t, t <= 1, coefs + 5 * t, t, z, eps, dst,
-                              traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
-        float* tmp = z; z = zn; zn = tmp;
+        // ---- the z-dependent part, step by step
+        for (int t = t_hi; t >= t_lo; --t) {
+            a.mod = mod_all + (size_t)(t - t_lo) * B * ldmod;
+            AID_TRY(score_trunk(n, B, z, a, false, s, &fused));
+            const float* eps = nullptr;
+            if (t > 0) {
+                eps = step_noise ? step_noise + (size_t)t * B * L : nullptr;
+                if (!eps) { AID_TRY(philox_fill(eps_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; eps = eps_buf; }
+            }
+            float* dst = (t == 0) ? z_out : zn;
+            AID_TRY(head_p_sample(a.raw, n.output_multiplier, (float)t, t <= 1, coefs + 5 * t, t, z, eps, dst,
+                                  traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
+            float* tmp = z; z = zn; zn = tmp;
+        }
+        t_hi = t_lo - 1;
     }
+    a.mod = mod_own;
     return AID_OK;
 }
 
@@ -257,6 +327,8 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
     g.alpha = alpha; g.accumulate = accumulate;
     return gemm_f32(g, (hipStream_t)stream);
 }
+
+int aid_gemm_force_kernel(int k) { gemm_force_kernel(k); return AID_OK; }
 
 int aid_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
     return philox_fill(out, n, 0, 0.f, seed, offset, (hipStream_t)stream);

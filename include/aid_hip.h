@@ -57,6 +57,9 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
                  int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha,
                  int accumulate, void* stream);
 
+/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk */
+int aid_gemm_force_kernel(int k);
+
 /* ---- Philox fills (production RNG; parity tests pass explicit tensors instead) ---------------- */
 int aid_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 int aid_fill_uniform(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);

@@ -24,7 +24,7 @@ int la_alloc(int M, int out, bool need_pre, Workspace& ws, LaSave& sv);
 int la_fwd(const AidLinear& l, int act, const float* mask, const float* x, int ldx, int M, LaSave& sv, int ldy, hipStream_t s);
 // dy is overwritten (multiplied by act'(pre)*mask).
 int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, const float* x, int ldx, int M, const LaSave& sv,
-           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx = 0);
+           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx = 0, Workspace* ws = nullptr);
 
 // ---- observation decoder (state branch), aid/core/active_inference.py:237-242
 struct DecoderSave { LlaSave s0, s1, s2; float* h2; };

@@ -47,10 +47,10 @@ int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidL
     float* dyeff = gln ? ws.f32((size_t)M * l.out) : nullptr;
     AID_WS_OK(ws);
     AID_TRY(ln_bwd_rows(dy, l.out, sv.lin, l.out, sv.stats, ln.g, ln.b, act, mask, dlin, l.out, dyeff, M, l.out, s));
-    if (gln) AID_TRY(ln_param_grad(dyeff, sv.lin, l.out, sv.stats, gln->g, gln->b, M, l.out, s));
+    if (gln) AID_TRY(ln_param_grad(dyeff, sv.lin, l.out, sv.stats, gln->g, gln->b, M, l.out, s, &ws));
     if (gl) {
         AID_TRY(linear_bwd_weight(dlin, l.out, x, ldx, gl->w, M, l.out, l.in, s, 1));
-        if (gl->b) AID_TRY(colsum(dlin, l.out, gl->b, M, l.out, 1, s));
+        if (gl->b) AID_TRY(colsum(dlin, l.out, gl->b, M, l.out, 1, s, &ws));
     }
     if (dx) AID_TRY(linear_bwd_data(dlin, l.out, l.w, l.in, dx, lddx, M, l.out, s));
     ws.release(mark);
@@ -66,13 +66,13 @@ int la_fwd(const AidLinear& l, int act, const float* mask, const float* x, int l
     return linear_fwd(x, ldx, l.w, l.b, sv.y, ldy, M, l.out, l.in, act, s, sv.pre, nullptr, 0, mask);
 }
 int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, const float* x, int ldx, int M, const LaSave& sv,
-           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx) {
+           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx, Workspace* ws) {
     AID_REQUIRE(lddy == l.out, AID_E_SHAPE, "la_bwd: dy must be contiguous");
     if (mask) AID_TRY(mul_elem(dy, mask, dy, (size_t)M * l.out, s));
     if (act != ACT_NONE) AID_TRY(act_bwd_dual(sv.pre, dy, nullptr, nullptr, act, (size_t)M * l.out, s));
     if (gl) {
         AID_TRY(linear_bwd_weight(dy, l.out, x, ldx, gl->w, M, l.out, l.in, s, 1));
-        if (gl->b) AID_TRY(colsum(dy, l.out, gl->b, M, l.out, 1, s));
+        if (gl->b) AID_TRY(colsum(dy, l.out, gl->b, M, l.out, 1, s, ws));
     }
     if (dx) AID_TRY(linear_bwd_data(dy, l.out, l.w, l.in, dx, lddx, M, l.out, s, accumulate_dx));
     return AID_OK;
@@ -274,20 +274,20 @@ int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float*
     AID_LAUNCH_CHECK();
     // heads
     if (g) {
-        AID_TRY(linear_bwd_weight(dmean, A, sv.m0.y, H, g->mean2.w, M, A, H, s, 1)); AID_TRY(colsum(dmean, A, g->mean2.b, M, A, 1, s));
-        AID_TRY(linear_bwd_weight(dlstd, A, sv.s0.y, H, g->lstd2.w, M, A, H, s, 1)); AID_TRY(colsum(dlstd, A, g->lstd2.b, M, A, 1, s));
+        AID_TRY(linear_bwd_weight(dmean, A, sv.m0.y, H, g->mean2.w, M, A, H, s, 1)); AID_TRY(colsum(dmean, A, g->mean2.b, M, A, 1, s, &ws));
+        AID_TRY(linear_bwd_weight(dlstd, A, sv.s0.y, H, g->lstd2.w, M, A, H, s, 1)); AID_TRY(colsum(dlstd, A, g->lstd2.b, M, A, 1, s, &ws));
     }
     AID_TRY(linear_bwd_data(dmean, A, p.mean2.w, H, dm0, H, M, A, s));
     AID_TRY(linear_bwd_data(dlstd, A, p.lstd2.w, H, ds0, H, M, A, s));
-    AID_TRY(la_bwd(p.mean0, g ? &g->mean0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.m0, dm0, H, dh2, D, s, 0));
-    AID_TRY(la_bwd(p.lstd0, g ? &g->lstd0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.s0, ds0, H, dh2, D, s, 1));
+    AID_TRY(la_bwd(p.mean0, g ? &g->mean0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.m0, dm0, H, dh2, D, s, 0, &ws));
+    AID_TRY(la_bwd(p.lstd0, g ? &g->lstd0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.s0, ds0, H, dh2, D, s, 1, &ws));
     // h2 = h + trunk(h)
     AID_TRY(lla_bwd(p.trunk[2], p.trunk_ln[2], g ? &g->trunk[2] : nullptr, g ? &g->trunk_ln[2] : nullptr, ACT_RELU, nullptr, sv.tr[1].y, D, M, sv.tr[2], dh2, dA, D, ws, s));
     AID_TRY(lla_bwd(p.trunk[1], p.trunk_ln[1], g ? &g->trunk[1] : nullptr, g ? &g->trunk_ln[1] : nullptr, ACT_RELU, nullptr, sv.tr[0].y, D, M, sv.tr[1], dA, dB, D, ws, s));
     AID_TRY(lla_bwd(p.trunk[0], p.trunk_ln[0], g ? &g->trunk[0] : nullptr, g ? &g->trunk_ln[0] : nullptr, ACT_RELU, nullptr, sv.h, D, M, sv.tr[0], dB, dA, D, ws, s));
     AID_TRY(add_inplace(dA, dh2, (size_t)M * D, s));   // dh
     if (g) {
-        AID_TRY(linear_bwd_weight(dA, D, sv.e0.y, D, g->enc3.w, M, D, D, s, 1)); AID_TRY(colsum(dA, D, g->enc3.b, M, D, 1, s));
+        AID_TRY(linear_bwd_weight(dA, D, sv.e0.y, D, g->enc3.w, M, D, D, s, 1)); AID_TRY(colsum(dA, D, g->enc3.b, M, D, 1, s, &ws));
     }
     AID_TRY(linear_bwd_data(dA, D, p.enc3.w, D, dB, D, M, D, s));
     AID_TRY(lla_bwd(p.enc0, p.enc_ln, g ? &g->enc0 : nullptr, g ? &g->enc_ln : nullptr, ACT_RELU, nullptr, z, ldz, M, sv.e0, dB, dz, lddz, ws, s));

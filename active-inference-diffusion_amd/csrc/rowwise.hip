@@ -51,8 +51,52 @@ __global__ void ln_act_kernel(const float* __restrict__ x, int ldx, const float*
         y[(size_t)row * ldy + c] = v;
     }
 }
+template <int NV>
+__global__ void ln_act_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  int act, const float* __restrict__ mask, float* __restrict__ y, int ldy, float* __restrict__ stats, int M) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const f4* xr = reinterpret_cast<const f4*>(x + (size_t)row * ldx);
+    f4 v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = xr[lane + 64 * i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+    const f4* g4 = reinterpret_cast<const f4*>(gamma); const f4* b4 = reinterpret_cast<const f4*>(beta);
+    const f4* m4 = mask ? reinterpret_cast<const f4*>(mask + (size_t)row * D) : nullptr;
+    f4* yr = reinterpret_cast<f4*>(y + (size_t)row * ldy);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f4 o, gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f}, mm = {1.f, 1.f, 1.f, 1.f};
+        if (gamma) { gg = g4[lane + 64 * i]; bb = b4[lane + 64 * i]; }
+        if (m4) mm = m4[lane + 64 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * gg[j] + bb[j], act) * mm[j];
+        yr[lane + 64 * i] = o;
+    }
+}
 int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
            float* stats, int M, int D, hipStream_t s) {
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mask) & 15) == 0 && ldx % 4 == 0 && ldy % 4 == 0;
+    if (al && (D == 256 || D == 512 || D == 1024 || D == 2048)) {
+        const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        if (D == 256) hipLaunchKernelGGL(ln_act_vec_kernel<1>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
+        else if (D == 512) hipLaunchKernelGGL(ln_act_vec_kernel<2>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
+        else if (D == 1024) hipLaunchKernelGGL(ln_act_vec_kernel<4>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
+        else hipLaunchKernelGGL(ln_act_vec_kernel<8>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
+        AID_LAUNCH_CHECK(); return AID_OK;
+    }
     hipLaunchKernelGGL(ln_act_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, gamma, beta,
                        act, mask, y, ldy, stats, M, D);
     AID_LAUNCH_CHECK(); return AID_OK;

@@ -5,13 +5,14 @@
 namespace aid {
 
 // out[c] (+)= sum_r a[r*lda + c]                       (bias gradients; deterministic)
-int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hipStream_t s);
+int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hipStream_t s, Workspace* ws = nullptr);
 
 // LayerNorm(+affine)(+activation)(+dropout mask) backward, rows:  dx = T(dyeff*gamma), dyeff = dy*mask*act'(xhat*gamma+beta)
 int ln_bwd_rows(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                 int act, const float* mask, float* dx, int lddx, float* dyeff, int M, int D, hipStream_t s);
 // dgamma[c] += sum_r dyeff*xhat ; dbeta[c] += sum_r dyeff
-int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s);
+int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s,
+                  Workspace* ws = nullptr);
 
 // adaLN backward carrying the primal adjoint (mu) and, optionally, the tangent adjoint (lam):
 //   y = xhat*(1+scale)+shift ;  yd = T(h)[hd]*(1+scale)

@@ -5,6 +5,37 @@ namespace aid {
 constexpr int RPB = 4;
 
 // ---------------------------------------------------------------------------------------------- colsum
+// Column sums over M rows.  Two deterministic stages so that tall inputs (M = K*B = 2560 rows in the EFE backward) use the
+// whole chip instead of N/64 workgroups: stage 1 reduces 256-row slabs into a [slabs][N] partial buffer (a fixed piece of the
+// caller's workspace), stage 2 folds the slabs in order.  No atomics: bias gradients are bitwise reproducible.
+constexpr int SLAB = 256;
+__global__ void colsum_slab_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                   const float* __restrict__ stats, float* __restrict__ part0, float* __restrict__ part1, int M, int N) {
+    // part0[slab][c] = sum_r a[r,c] * (b ? xhat(b[r,c]) : 1) ; part1[slab][c] = sum_r a[r,c]   (part1 only with b)
+    __shared__ float r0[4][64], r1[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const int rbeg = slab * SLAB, rend = min(M, rbeg + SLAB);
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) for (int r = rbeg + w; r < rend; r += 4) {
+        const float e = a[(size_t)r * lda + c];
+        if (b) { s0 += e * (b[(size_t)r * ldb + c] - stats[2 * r]) * stats[2 * r + 1]; s1 += e; }
+        else s0 += e;
+    }
+    r0[w][lane] = s0; r1[w][lane] = s1;
+    __syncthreads();
+    if (w == 0 && c < N) {
+        part0[(size_t)slab * N + c] = r0[0][lane] + r0[1][lane] + r0[2][lane] + r0[3][lane];
+        if (b) part1[(size_t)slab * N + c] = r1[0][lane] + r1[1][lane] + r1[2][lane] + r1[3][lane];
+    }
+}
+__global__ void colsum_fold_kernel(const float* __restrict__ part, int slabs, float* __restrict__ out, int N, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= N) return;
+    float s = 0.f;
+    for (int i = 0; i < slabs; ++i) s += part[(size_t)i * N + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
 __global__ void colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int accumulate) {
     __shared__ float red[4][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -18,7 +49,19 @@ __global__ void colsum_kernel(const float* __restrict__ a, int lda, float* __res
         out[c] = accumulate ? out[c] + v : v;
     }
 }
-int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hipStream_t s) {
+int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hipStream_t s, Workspace* ws) {
+    if (ws && M > 2 * SLAB) {
+        const int slabs = (M + SLAB - 1) / SLAB;
+        const size_t mark = ws->mark();
+        float* part = ws->f32((size_t)slabs * N);
+        if (!ws->overflow) {
+            hipLaunchKernelGGL(colsum_slab_kernel, dim3((N + 63) / 64, slabs), dim3(256), 0, s, a, lda, (const float*)nullptr, 0,
+                               (const float*)nullptr, part, (float*)nullptr, M, N);
+            hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, slabs, out, N, accumulate);
+            AID_LAUNCH_CHECK(); ws->release(mark); return AID_OK;
+        }
+        ws->overflow = false; ws->release(mark);
+    }
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, a, lda, out, M, N, accumulate);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
@@ -78,7 +121,20 @@ __global__ void ln_param_grad_kernel(const float* __restrict__ dyeff, const floa
         dbeta[c] += rb[0][lane] + rb[1][lane] + rb[2][lane] + rb[3][lane];
     }
 }
-int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s) {
+int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s,
+                  Workspace* ws) {
+    if (ws && M > 2 * SLAB) {
+        const int slabs = (M + SLAB - 1) / SLAB;
+        const size_t mark = ws->mark();
+        float* p0 = ws->f32((size_t)slabs * D); float* p1 = ws->f32((size_t)slabs * D);
+        if (!ws->overflow) {
+            hipLaunchKernelGGL(colsum_slab_kernel, dim3((D + 63) / 64, slabs), dim3(256), 0, s, dyeff, D, x, ldx, stats, p0, p1, M, D);
+            hipLaunchKernelGGL(colsum_fold_kernel, dim3((D + 255) / 256), dim3(256), 0, s, p0, slabs, dgamma, D, 1);
+            hipLaunchKernelGGL(colsum_fold_kernel, dim3((D + 255) / 256), dim3(256), 0, s, p1, slabs, dbeta, D, 1);
+            AID_LAUNCH_CHECK(); ws->release(mark); return AID_OK;
+        }
+        ws->overflow = false; ws->release(mark);
+    }
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dyeff, x, ldx, stats, dgamma, dbeta, M, D);
     AID_LAUNCH_CHECK(); return AID_OK;
 }

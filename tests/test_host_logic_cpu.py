@@ -1,0 +1,100 @@
+"""CPU: host-side logic of the drop-in surface — config dataclasses, module tree / state_dict layout, parameter arenas,
+noise-source bookkeeping.  (Arithmetic needs the GPU and is covered by the -m gpu tests.)"""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.weights import param_specs
+
+
+def test_config_surface_matches_reference_defaults():
+    import aid_amd
+    c = aid_amd.ActiveInferenceConfig()
+    # values from active_inference_diffusion/configs/config.py:38-86
+    expect = dict(env_name="HalfCheetah-v4", observation_dim=17, action_dim=6, precision_init=1.0, expected_free_energy_horizon=5, efe_horizon=5,
+                  epistemic_weight=0.1, extrinsic_weight=1.0, pragmatic_weight=1.0, consistency_weight=0.1, discount_factor=0.99,
+                  contrastive_weight=0.5, kl_weight=0.1, diffusion_weight=1.0, reward_weight=0.5, hidden_dim=512, latent_dim=128,
+                  spatial_aggregator_output_dim=256, num_layers=3, pixel_observation=False, batch_size=256, learning_rate=5e-5, gradient_clip=0.5,
+                  preference_temperature=1.0, preference_learning_rate=0.01, min_preference_temperature=0.1, max_preference_temperature=10.0,
+                  temperature_decay=0.995, use_reward_preferences=True, baseline_reward=0.0, preference_momentum=0.9)
+    for k, v in expect.items():
+        assert getattr(c, k) == v, k
+    assert [f.name for f in dataclasses.fields(c)][-3:] == ["diffusion", "belief_dynamics", "device"]
+    d = aid_amd.DiffusionConfig()
+    assert (d.num_diffusion_steps, d.beta_start, d.beta_end, d.beta_schedule, d.gradient_clip_val) == (1000, 1e-4, 0.02, "cosine", 0.1)
+    b = aid_amd.BeliefDynamicsConfig()
+    assert (b.dt, b.diffusion_coefficient, b.learning_rate, b.noise_scale, b.min_variance, b.max_variance, b.use_full_covariance) == (0.01, 0.1, 0.1, 0.01, 1e-6, 10.0, False)
+    t = aid_amd.TrainingConfig()
+    assert (t.buffer_size, t.exploration_noise, t.exploration_decay, t.min_exploration, t.gradient_steps) == (100_000, 0.1, 0.999, 0.01, 4)
+    p = aid_amd.PixelObservationConfig()
+    assert (p.image_shape, p.frame_stack, p.encoder_feature_dim, p.random_shift_pad) == ((3, 84, 84), 3, 80, 4)
+
+
+def _specs_for(prefix, O=17, A=6, D=64, N=4):
+    return [(n[len(prefix):], s) for n, s in param_specs(O, A, O, D, N) if n.startswith(prefix)]
+
+
+def test_module_trees_reproduce_reference_state_dict_names():
+    from aid_amd.models import DiffusionConditionedPolicy, LatentDynamicsModel, LatentScoreNetwork, ValueNetwork
+    for mod, prefix in ((LatentScoreNetwork(17, 17, 64), "latent_score_network."), (DiffusionConditionedPolicy(17, 6, 64), "policy_network."),
+                        (ValueNetwork(17, 64), "value_network."), (LatentDynamicsModel(17, 6, 64), "latent_dynamics.")):
+        sd = mod.state_dict()
+        assert [(k, tuple(v.shape)) for k, v in sd.items()] == _specs_for(prefix), prefix
+    sn = LatentScoreNetwork(17, 17, 64)
+    assert float(sn.output_proj[2].weight.abs().max()) == 0.0                       # zero-initialised head (score_networks.py:99)
+    assert float(sn.norm_final.adaLN_modulation[1].weight.abs().max()) == 0.0        # identity modulation (:254-255)
+    assert float(sn.output_multiplier) == pytest.approx(1e-3)
+    with pytest.raises(RuntimeError, match="parameter holder"):
+        sn.transformer_blocks[0](torch.zeros(1, 64), torch.zeros(1, 64))
+
+
+def test_param_arena_flattens_in_place_and_keeps_adaLN_contiguous():
+    from aid_amd.arena import ALIGN, ParamArena
+    from aid_amd.models import LatentScoreNetwork
+    sn = LatentScoreNetwork(17, 17, 64)
+    before = {n: p.detach().clone() for n, p in sn.named_parameters()}
+    arena = ParamArena(sn.arena_order(), "cpu", with_ema=True)
+    for n, p in sn.named_parameters():
+        assert torch.equal(p.data, before[n])
+        o, _ = arena.offsets[n]
+        assert o % ALIGN == 0 and p.data.data_ptr() == arena.flat.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == arena.grad.data_ptr() + 4 * o
+    D = 64
+    names = [f"transformer_blocks.{i}.norm{j}.adaLN_modulation.1.weight" for i in range(6) for j in (1, 2)] + ["norm_final.adaLN_modulation.1.weight"]
+    offs = [arena.offsets[n][0] for n in names]
+    assert all(b - a == 2 * D * D for a, b in zip(offs, offs[1:]))                    # 13 modulation matrices back to back -> one GEMM
+    # load_state_dict copies into the views: the arena sees the new values
+    sd = {k: torch.full_like(v, 0.5) for k, v in sn.state_dict().items()}
+    sn.load_state_dict(sd)
+    o, shp = arena.offsets["latent_proj.weight"]
+    assert float(arena.flat[o]) == 0.5
+    arena.grad.fill_(2.0)
+    assert float(sn.latent_proj.weight.grad.mean()) == 2.0
+    arena.zero_grad()
+    assert float(sn.latent_proj.weight.grad.abs().max()) == 0.0
+    assert set(arena.ema_views()) == set(arena.names)
+    st = arena.state_dict()
+    assert st["param_groups"][0]["params"] == list(range(len(arena.names)))
+
+
+def test_noise_source_hands_out_disjoint_counter_ranges():
+    from aid_amd.noise import NoiseSource, PhiloxNoise
+    n = PhiloxNoise(seed=3)
+    a, b = n.next_offset(), n.next_offset(100)
+    assert b > a and n.next_offset() == b + 100
+    assert n.belief(8, 17, 64, 4, True) is None and n.elbo(8, 17, 64, True, None) is None and n.efe(8, 17, 6, 2, 2, 2) is None
+
+
+def test_cpu_device_is_rejected_loudly():
+    import aid_amd
+
+    class Box:
+        def __init__(self, s): self.shape = s
+
+    class Env:
+        observation_space, action_space = Box((17,)), Box((6,))
+    cfg = aid_amd.ActiveInferenceConfig(device="cpu", latent_dim=17, hidden_dim=64)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=8))

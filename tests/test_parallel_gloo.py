@@ -1,0 +1,72 @@
+"""CPU, world_size 2, gloo: the data-parallel host logic (aid_amd/parallel.py) and the equivalence it relies on —
+averaging per-shard gradients of mean-losses equals the gradient of the global batch (checked with the oracle)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    try:
+        from aid_amd import parallel
+        from oracle import aid_oracle as orc
+        from oracle.weights import draw_params, param_specs
+        assert parallel.is_dp() and parallel.world() == world and parallel.rank() == rank
+        # all-reduce mean of a flat arena
+        g = torch.full((1000,), float(rank + 1))
+        parallel.allreduce_mean_(g)
+        assert torch.allclose(g, torch.full((1000,), 1.5))
+        # rank-major all-gather, broadcast, disjoint index shards
+        x = torch.arange(4, dtype=torch.float32) + 10 * rank
+        assert parallel.allgather_cat(x).tolist() == [0, 1, 2, 3, 10, 11, 12, 13]
+        w = torch.full((8,), float(rank)); parallel.broadcast_arena_(w); assert float(w.sum()) == 0.0
+        idx = np.arange(16); mine = parallel.shard_indices(idx)
+        assert mine.tolist() == list(range(8 * rank, 8 * rank + 8))
+        with pytest.raises(ValueError):
+            parallel.shard_indices(np.arange(15))
+        # DP equivalence on the dynamics + value losses (mean over the batch): grad(global) == mean_r grad(shard_r)
+        O, A, D, N, B = 11, 3, 32, 4, 8
+        p = draw_params(param_specs(O, A, O, D, N), 5, orc.schedule_tables(N))
+        rng = np.random.default_rng(0)
+        z, a, zn = (torch.from_numpy(rng.standard_normal(s).astype(np.float32)) for s in ((B, O), (B, A), (B, O)))
+        names = orc.group_names(p, "dynamics")
+        for n in names: p[n].requires_grad_(True)
+        def loss(sl):
+            pred, _ = orc.predict_next_latent(p, z[sl], a[sl]); return torch.nn.functional.mse_loss(pred, zn[sl])
+        full = torch.autograd.grad(loss(slice(0, B)), [p[n] for n in names])
+        half = B // world
+        mine = torch.autograd.grad(loss(slice(rank * half, (rank + 1) * half)), [p[n] for n in names])
+        flat = torch.cat([t.reshape(-1) for t in mine]); parallel.allreduce_mean_(flat)
+        assert torch.allclose(flat, torch.cat([t.reshape(-1) for t in full]), rtol=1e-5, atol=1e-7)
+        # global reward-normaliser moments == moments of the gathered batch
+        r = torch.from_numpy(rng.standard_normal(B).astype(np.float32))
+        allr = parallel.allgather_cat(r[rank * half:(rank + 1) * half].contiguous())
+        assert torch.equal(allr, r)
+        q.put((rank, "ok"))
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_data_parallel_host_logic_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs: p.join(timeout=60)
+    assert all(v == "ok" for _, v in res), res

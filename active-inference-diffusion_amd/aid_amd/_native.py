@@ -554,3 +554,23 @@ def reward_normalize_global(stats_src, rewards, state):
 def gemm_force_kernel(k: int):
     """0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk (benches/tests only)."""
     check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")
+
+
+def gemm_ksplit_add(A, W, C_out, bias, ksplit):
+    M, K = A.shape; N = W.shape[0]
+    check(lib().aid_gemm_ksplit_add(_ptr(A), K, _ptr(W), K, _ptr(C_out), N, M, N, K, _ptr(bias), int(ksplit), _stream()), "aid_gemm_ksplit_add")
+
+
+def collector_sampling(table: AidScoreNet, coefs, obs, num_steps: int, max_index: int, z_init=None, step_noise=None, drop_masks=None,
+                       reinit_noise=None, train=False, seed=0, offset=0, ws: Workspace = None):
+    """AsyncGPUInference._batch_diffusion_sampling. -> (z [B,L], reinit_count device int32[1])"""
+    B = obs.shape[0]
+    out = torch.empty(B, table.L, device=obs.device, dtype=torch.float32)
+    cnt = torch.zeros(1, device=obs.device, dtype=torch.int32)
+    ws = ws or Workspace(obs.device)
+    buf = ws.get(lib().aid_denoise_loop_workspace(C.byref(table), B, num_steps))
+    check(lib().aid_collector_sampling(C.byref(table), B, int(num_steps), int(max_index), _ptr(coefs), _ptr(obs), _ptr(z_init), _ptr(step_noise),
+                                       _ptr(drop_masks), _ptr(reinit_noise), int(bool(train)), C.c_uint64(seed), C.c_uint64(offset), _ptr(out),
+                                       C.c_void_p(cnt.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_collector_sampling")
+    return out, cnt

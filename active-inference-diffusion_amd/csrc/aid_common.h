@@ -72,6 +72,9 @@ struct GemmArgs {
     const float* mask;       // optional [M,N] multiplicative mask applied after act (dropout), stride ldc
     const float* dact_pre;   // optional [M,N] (stride ldc): multiply by act'(dact_pre) of kind `dact` (tangent /
     int dact;                //   backward through an activation whose pre-activation was saved)
+    int ksplit;              // >1: panel kernel splits K over `ksplit` workgroups which atomically ADD into C (C must already hold
+                             //     the residual / initial value; bias added by split 0; act must be NONE).  Order of the float adds,
+                             //     hence the last bit, is not reproducible run to run.
 };
 inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K) {
     GemmArgs g; memset(&g, 0, sizeof(g));

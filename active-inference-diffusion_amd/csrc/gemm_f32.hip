@@ -101,6 +101,15 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ S, int r, i
     return v;
 }
 
+// blockIdx -> output tile.  Workgroups are dealt round-robin over the 8 XCDs (b % 8 labels the XCD group: speed only, never
+// correctness).  When the N-tile count is a multiple of 8, all M-tiles of one weight panel (same tn) are given consecutive
+// slots of ONE XCD group, so the panel is fetched from the Infinity Cache once per GEMM and the other M-tiles hit that XCD's L2
+// (batch-256 layers stream ~55 MB of weights per denoise step through 4 MB L2s).  Bijective for any grid.
+__device__ __forceinline__ void tile_coords(int b, int tiles_m, int tiles_n, int& tm, int& tn) {
+    if ((tiles_n & 7) == 0) { const int x = b & 7, q = b >> 3; tn = x + 8 * (q / tiles_m); tm = q % tiles_m; }
+    else { tm = b / tiles_n; tn = b % tiles_n; }
+}
+
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, float v) {
     if (row >= g.M || col >= g.N) return;
     v *= g.alpha;
@@ -131,8 +140,8 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int tm_, tn_; tile_coords(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -209,8 +218,8 @@ __global__ void __launch_bounds__(256) gemm_splitk_kernel(GemmArgs g, int tiles_
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int tm_, tn_; tile_coords(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -305,6 +314,13 @@ __device__ __forceinline__ f32x4 panel_frag(const float* __restrict__ slot, int 
     return v;
 }
 
+__device__ __forceinline__ void epilogue_atomic(const GemmArgs& g, int row, int col, float v, bool lead) {
+    if (row >= g.M || col >= g.N) return;
+    v *= g.alpha;
+    if (lead && g.bias) v += g.bias[col];
+    atomicAdd(g.C + (size_t)row * g.ldc + col, v);
+}
+
 template <bool AKM, bool BKM>
 __global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -314,19 +330,21 @@ __global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * 32, n0 = (tile % tiles_n) * 32;
-    const int ns = g.K / KS;
+    int tm_, tn_; tile_coords(blockIdx.x, (g.M + 32 - 1) / 32, tiles_n, tm_, tn_);
+    const int m0 = tm_ * 32, n0 = tn_ * 32;
+    const int nsplit = gridDim.y, split = blockIdx.y;
+    const int ns = g.K / KS / nsplit;              // stages handled by this workgroup
+    const int kbase = split * ns * KS;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     // prologue: up to two stages in flight
-    panel_dma<AKM>(g.A, g.lda, m0, g.M, 0, As, wave, lane);
-    panel_dma<BKM>(g.B, g.ldb, n0, g.N, 0, Bs, wave, lane);
+    panel_dma<AKM>(g.A, g.lda, m0, g.M, kbase, As, wave, lane);
+    panel_dma<BKM>(g.B, g.ldb, n0, g.N, kbase, Bs, wave, lane);
     if (ns > 1) {
-        panel_dma<AKM>(g.A, g.lda, m0, g.M, KS, As + FA, wave, lane);
-        panel_dma<BKM>(g.B, g.ldb, n0, g.N, KS, Bs + FB, wave, lane);
+        panel_dma<AKM>(g.A, g.lda, m0, g.M, kbase + KS, As + FA, wave, lane);
+        panel_dma<BKM>(g.B, g.ldb, n0, g.N, kbase + KS, Bs + FB, wave, lane);
     }
     for (int st = 0; st < ns; ++st) {
         const int cur = st & 1;
@@ -348,8 +366,8 @@ __global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n
         if (st + 2 < ns) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // every wave finished reading slot `cur`
-            panel_dma<AKM>(g.A, g.lda, m0, g.M, (st + 2) * KS, As + cur * FA, wave, lane);
-            panel_dma<BKM>(g.B, g.ldb, n0, g.N, (st + 2) * KS, Bs + cur * FB, wave, lane);
+            panel_dma<AKM>(g.A, g.lda, m0, g.M, kbase + (st + 2) * KS, As + cur * FA, wave, lane);
+            panel_dma<BKM>(g.B, g.ldb, n0, g.N, kbase + (st + 2) * KS, Bs + cur * FB, wave, lane);
         }
     }
     // cross-wave reduction through LDS (slot memory is dead after this barrier)
@@ -365,7 +383,8 @@ __global__ void __launch_bounds__(256) gemm_panel_kernel(GemmArgs g, int tiles_n
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = acc[r] + red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane];
-            epilogue_store(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v);
+            if (nsplit > 1) epilogue_atomic(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v, split == 0);
+            else epilogue_store(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v);
         }
     }
 }
@@ -435,8 +454,8 @@ __global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 31, h = lane >> 5;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    const int tile = blockIdx.x;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    int tm_, tn_; tile_coords(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
     const int ns = g.K / KSTAGE;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -512,7 +531,9 @@ static int launch_panel(const GemmArgs& g, hipStream_t s) {
         AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_panel_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done = true;
     }
-    hipLaunchKernelGGL((gemm_panel_kernel<AKM, BKM>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    int ks = g.ksplit > 1 ? g.ksplit : 1;
+    while (ks > 1 && (g.K / KS) % ks) --ks;
+    hipLaunchKernelGGL((gemm_panel_kernel<AKM, BKM>), dim3(tm * tn, ks), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
 
@@ -588,6 +609,8 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     AID_REQUIRE(g.A && g.B && g.C, AID_E_NULL, "gemm_f32: null operand");
     AID_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0, AID_E_SHAPE, "gemm_f32: negative dim");
     AID_REQUIRE(!(g.accumulate && g.act != ACT_NONE), AID_E_SHAPE, "gemm_f32: accumulate with activation");
+    AID_REQUIRE(g.ksplit <= 1 || (g.act == ACT_NONE && !g.preact && !g.mask && !g.dact_pre && !g.residual && !g.accumulate), AID_E_SHAPE,
+                "gemm_f32: ksplit needs a plain epilogue (C pre-initialised by the caller)");
     if (g.M == 0 || g.N == 0) return AID_OK;
     // vector (16-B) global loads need every row start 16-B aligned along the contiguous dim
     bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);

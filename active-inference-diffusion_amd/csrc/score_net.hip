@@ -229,10 +229,48 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     return n + (1 << 16);
 }
 
+// any non-finite entry of z -> flag[0] = 1 ; then (second kernel) z = 0.1 * noise for the WHOLE batch (async_collector.py:591-593)
+__global__ void nonfinite_flag_kernel(const float* __restrict__ z, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float v = z[i]; if (!(fabsf(v) <= 3.4028234e38f)) atomicOr(flag, 1); }
+}
+__global__ void reinit_if_flag_kernel(float* __restrict__ z, const float* __restrict__ noise, int n, const int* __restrict__ flag, int* __restrict__ count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (flag[0] && i < n) z[i] = 0.1f * noise[i];
+    if (i == 0 && flag[0] && count) count[0] += 1;
+}
+__global__ void scaled_iota_kernel(float* t, int n, float div) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = (float)i / div;
+}
+
+static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs, const float* obs, const float* z_init,
+                        const float* step_noise, const float* drop_masks, int train, uint64_t seed, uint64_t offset,
+                        float* z_out, float* traj, void* wsp, size_t ws_bytes, void* stream, int collector_max_index,
+                        const float* reinit_noise, int* reinit_count);
+
 int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, const float* obs, const float* z_init,
                      const float* step_noise, const float* drop_masks, int train, uint64_t seed, uint64_t offset,
                      float* z_out, float* traj, void* wsp, size_t ws_bytes, void* stream) {
+    return denoise_impl(net, B, N, coefs, obs, z_init, step_noise, drop_masks, train, seed, offset, z_out, traj, wsp, ws_bytes, stream, 0,
+                        nullptr, nullptr);
+}
+
+int aid_collector_sampling(const AidScoreNet* net, int B, int num_steps, int max_index, const float* coefs, const float* obs,
+                           const float* z_init, const float* step_noise, const float* drop_masks, const float* reinit_noise, int train,
+                           uint64_t seed, uint64_t offset, float* z_out, int* reinit_count, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(max_index >= 1 && num_steps >= 1 && num_steps <= max_index + 1, AID_E_SHAPE,
+                "aid_collector_sampling: num_steps=%d must lie in [1, max_index+1=%d]", num_steps, max_index + 1);
+    return denoise_impl(net, B, num_steps, coefs, obs, z_init, step_noise, drop_masks, train, seed, offset, z_out, nullptr, wsp, ws_bytes, stream,
+                        max_index, reinit_noise, reinit_count);
+}
+
+static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs, const float* obs, const float* z_init,
+                        const float* step_noise, const float* drop_masks, int train, uint64_t seed, uint64_t offset,
+                        float* z_out, float* traj, void* wsp, size_t ws_bytes, void* stream, int collector_max_index,
+                        const float* reinit_noise, int* reinit_count) {
     AID_TRY(score_validate(net));
+    const bool collector = collector_max_index > 0;
     AID_REQUIRE(coefs && obs && z_out, AID_E_NULL, "aid_denoise_loop: null tensor");
     AID_REQUIRE(B > 0 && N > 0, AID_E_SHAPE, "aid_denoise_loop: B=%d N=%d", B, N);
     hipStream_t s = (hipStream_t)stream;
@@ -245,6 +283,8 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, c
     float* zA = ws.f32((size_t)B * L);
     float* zB = ws.f32((size_t)B * L);
     float* eps_buf = ws.f32((size_t)B * L);
+    float* re_buf = ws.f32((size_t)B * L);
+    int* nan_flag = (int*)ws.raw(256);
     float* o2_shared = ws.f32((size_t)B * D);
     float* mask_all = ws.f32((size_t)C * B * D);
     float* actA = ws.f32((size_t)C * B * D);
@@ -258,7 +298,10 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, c
     float* mod_own = a.mod;
 
     // ---- per-loop invariants: [N,D] time-embedding table (steps 0,1 on the continuous branch, D8), obs-encoder head
-    hipLaunchKernelGGL(iota_kernel, dim3((N + 255) / 256), dim3(256), 0, s, times, N);
+    // score-net time input per step: the integer step (train_step / act: steps 0,1 fall on the continuous branch, D8) or, for the
+    // collector's loop, step/(N_config-1) in [0,1] (always continuous; async_collector.py:575-579)
+    if (collector) hipLaunchKernelGGL(scaled_iota_kernel, dim3((N + 255) / 256), dim3(256), 0, s, times, N, (float)collector_max_index);
+    else hipLaunchKernelGGL(iota_kernel, dim3((N + 255) / 256), dim3(256), 0, s, times, N);
     AID_LAUNCH_CHECK();
     AID_TRY(score_time_embed(n, N, times, 2, a, s));
     AID_TRY(copy_f32(a.temb, temb_table, (size_t)N * D, s));
@@ -309,8 +352,17 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int N, const float* coefs, c
                 if (!eps) { AID_TRY(philox_fill(eps_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; eps = eps_buf; }
             }
             float* dst = (t == 0) ? z_out : zn;
-            AID_TRY(head_p_sample(a.raw, n.output_multiplier, (float)t, t <= 1, coefs + 5 * t, t, z, eps, dst,
+            const float tval = collector ? (float)t / (float)collector_max_index : (float)t;
+            AID_TRY(head_p_sample(a.raw, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
                                   traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
+            if (collector) {   // whole-batch NaN/Inf re-initialisation, decided on device (a host sync in the reference)
+                const float* rn = reinit_noise ? reinit_noise + (size_t)t * B * L : nullptr;
+                if (!rn) { AID_TRY(philox_fill(re_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; rn = re_buf; }
+                AID_CHECK_HIP(hipMemsetAsync(nan_flag, 0, sizeof(int), s));
+                hipLaunchKernelGGL(nonfinite_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, dst, B * L, nan_flag);
+                hipLaunchKernelGGL(reinit_if_flag_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, dst, rn, B * L, nan_flag, reinit_count);
+                AID_LAUNCH_CHECK();
+            }
             float* tmp = z; z = zn; zn = tmp;
         }
         t_hi = t_lo - 1;
@@ -325,6 +377,13 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K);
     g.a_kmajor = a_kmajor; g.b_kmajor = b_kmajor; g.bias = bias; g.act = act; g.residual = residual; g.ldr = ldr;
     g.alpha = alpha; g.accumulate = accumulate;
+    return gemm_f32(g, (hipStream_t)stream);
+}
+
+int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
+                        int ksplit, void* stream) {
+    GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K);
+    g.bias = bias; g.ksplit = ksplit;
     return gemm_f32(g, (hipStream_t)stream);
 }
 

@@ -57,6 +57,10 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
                  int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha,
                  int accumulate, void* stream);
 
+/* C[M,N] += A[M,K] W[N,K]^T + bias with K split over `ksplit` workgroups that atomically add into C (C holds the residual).
+ * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
+int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
+                        int ksplit, void* stream);
 /* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk */
 int aid_gemm_force_kernel(int k);
 
@@ -115,6 +119,15 @@ int aid_denoise_loop(const AidScoreNet* net, int B, int n_steps, const float* co
                      uint64_t seed, uint64_t offset, float* z_out, float* traj, void* ws, size_t ws_bytes,
                      void* stream);
 
+
+/* A6: AsyncGPUInference._batch_diffusion_sampling (aid/utils/async_collector.py:530-595): `num_steps` <= max_index+1 reverse
+ * steps; the score net is fed t = step/max_index (always the continuous branch), p_sample the integer step; after every step a
+ * whole-batch NaN/Inf test re-initialises z = 0.1*N(0,1) (reinit_noise [num_steps,B,L] or NULL = Philox; reinit_count, optional
+ * device int, counts the re-initialisations).  Other arguments as aid_denoise_loop.  Workspace: aid_denoise_loop_workspace. */
+int aid_collector_sampling(const AidScoreNet* net, int B, int num_steps, int max_index, const float* coefs, const float* obs,
+                           const float* z_init, const float* step_noise, const float* drop_masks, const float* reinit_noise,
+                           int train, uint64_t seed, uint64_t offset, float* z_out, int* reinit_count, void* ws, size_t ws_bytes,
+                           void* stream);
 
 /* ---- small networks (A4/A9/A10): parameter tables named after the reference modules -----------
  * aid/models/policy_networks.py:42-71, value_networks.py:24-45, dynamics_models.py:28-45,

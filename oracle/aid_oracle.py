@@ -219,6 +219,23 @@ def generate_latent_trajectory(p: Params, tab: Dict[str, Tensor], obs: Tensor, n
     return (z, traj) if keep else z
 
 
+def collector_sampling(p: Params, tab: Dict[str, Tensor], obs: Tensor, noise, num_steps: int, n_config_steps: int,
+                       train: bool = False) -> Tensor:
+    """AsyncGPUInference._batch_diffusion_sampling, aid/utils/async_collector.py:530-595 (continuous_time=True branch).
+    Draw order: randn[B,L]; per step s=num_steps-1..0: score dropout mask (train), randn[B,L] if s>0; on NaN/Inf randn[B,L]."""
+    B, L = obs.shape[0], p[SCORE + "latent_proj.weight"].shape[1]
+    max_index = n_config_steps - 1
+    z = _t(noise.randn(B, L))
+    for step in reversed(range(num_steps)):
+        t_cont = torch.full((B,), float(step)) / max_index
+        s = score_forward(p, z, t_cont, obs, noise, train)
+        eps = _t(noise.randn(B, L)) if step > 0 else None
+        z = p_sample(tab, z, step, s, eps)
+        if torch.isnan(z).any() or torch.isinf(z).any():
+            z = _t(noise.randn(B, L)) * 0.1
+    return z
+
+
 # ---------------------------------------------------------------------------------------------
 # A4/A9 small networks
 # ---------------------------------------------------------------------------------------------

@@ -230,6 +230,18 @@ def main():
         g.update(belief_eval_key=7, belief_eval_latent=bi["latent"].numpy())
         ai.train()
 
+        # ---- A6 collector loop (AsyncGPUInference._batch_diffusion_sampling called on a stand-in `self`; eval mode as the collector sets)
+        from active_inference_diffusion.utils.async_collector import AsyncGPUInference
+        ai.eval()
+        fake = types.SimpleNamespace(agent=agent, max_diffusion_steps=3)
+        tape.use(9)
+        with torch.no_grad():
+            zc_ref = AsyncGPUInference._batch_diffusion_sampling(fake, T(obs), num_steps=3)
+        zc = orc.collector_sampling(p, tab, T(obs), NoiseStream(9), 3, N, False)
+        report[f"{tag}/collector"] = close(zc, zc_ref, 1e-5, 1e-6, "collector sampling")
+        g.update(collector_key=9, collector_steps=3, collector_z=zc_ref.numpy())
+        ai.train()
+
         # ---- A9 small nets
         with torch.no_grad():
             tape.use(8); a_ref, lp_ref, dist = ai.policy_network(T(z))

@@ -157,3 +157,29 @@ def test_errors_are_reported_not_thrown(nat):
     import ctypes as C
     rc = nat.lib().aid_gemm_f32(None, 1, 0, None, 1, 0, None, 1, 4, 4, 4, None, 0, None, 0, C.c_float(1.0), 0, None)
     assert rc == -1 and b"null" in nat.lib().aid_last_error()
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_collector_sampling_golden(nat, golden_dir, tag):
+    """A6: AsyncGPUInference._batch_diffusion_sampling (reference output in tests/golden) + the NaN/Inf re-initialisation."""
+    g, p, pd = _golden(golden_dir, tag)
+    L, D, B, N = int(g["L"]), int(g["D"]), int(g["B"]), int(g["N"])
+    tab = nat.score_net_table(pd, "latent_score_network.", L, L, D)
+    coefs = orc.p_sample_coefs(orc.schedule_tables(N)).cuda().contiguous()
+    steps = int(g["collector_steps"])
+    ns = NoiseStream(int(g["collector_key"]))
+    z0 = ns.randn(B, L); eps = np.zeros((steps, B, L), np.float32)
+    for s_ in reversed(range(steps)):
+        if s_ > 0:
+            eps[s_] = ns.randn(B, L)
+    out, cnt = nat.collector_sampling(tab, coefs, dev(g["obs"]), steps, N - 1, dev(z0), dev(eps), None, dev(np.zeros((steps, B, L), np.float32)), train=False)
+    np.testing.assert_allclose(out.cpu().numpy(), g["collector_z"], rtol=1e-3, atol=1e-5)
+    assert int(cnt) == 0
+    # a NaN in the start state poisons the step-(steps-1) iterate -> whole batch re-initialised to 0.1*noise at that step
+    z_bad = z0.copy(); z_bad[0, 0] = np.nan
+    rn = np.random.default_rng(0).standard_normal((steps, B, L)).astype(np.float32)
+    out2, cnt2 = nat.collector_sampling(tab, coefs, dev(g["obs"]), steps, N - 1, dev(z_bad), dev(eps), None, dev(rn), train=False)
+    assert int(cnt2) == 1 and np.all(np.isfinite(out2.cpu().numpy()))
+    ref = orc.collector_sampling(p, orc.schedule_tables(N), torch.from_numpy(g["obs"]),
+                                 type("R", (), {"randn": staticmethod(lambda *s, _it=iter([z_bad, eps[2], rn[2], eps[1]]): next(_it))})(), steps, N, False)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5)

@@ -740,3 +740,78 @@ def replay_sample(store: Dict[str, np.ndarray], size: int, batch_size: int, nois
     return {"observations": store["observations"][idx], "actions": store["actions"][idx],
             "rewards": store["rewards"][idx], "next_observations": store["next_observations"][idx],
             "dones": store["dones"][idx], "indices": idx}
+
+
+# =============================================================================================
+# A13  pixel path: DrQV2Encoder, SpatialAttention, RandomShiftAugmentation, InfoNCE, feature decoder
+#      aid/encoder/visual_encoders.py:13-225,471-492 ; aid/agents/pixel_agent.py:166-199,413-437
+# =============================================================================================
+ENC_CHANNELS = (32, 64, 128, 256)
+ENC_DROPOUT2D = (0.0, 0.025, 0.05)
+
+
+def spectral_norm_weight(w_orig: Tensor, u: Tensor, v: Tensor, train: bool, eps: float = 1e-12):
+    """Legacy torch.nn.utils.spectral_norm (dim=0, 1 power iteration): in train mode u, v are updated in place under no_grad,
+    then sigma = u.(W v) with u, v treated as constants; W_eff = W_orig / sigma.  Returns (W_eff, u_new, v_new)."""
+    wm = w_orig.reshape(w_orig.shape[0], -1)
+    if train:
+        with torch.no_grad():
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=eps)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=eps)
+    sigma = torch.dot(u, torch.mv(wm, v))
+    return w_orig / sigma, u, v
+
+
+def random_shift(x: Tensor, pad: int, noise) -> Tensor:
+    """RandomShiftAugmentation.forward (train mode), visual_encoders.py:471-492.  Draw order: randint[n] (h), randint[n] (w)."""
+    n, c, h, w = x.shape
+    xp = F.pad(x, (pad,) * 4, mode="reflect")
+    ho = noise.randint(0, 2 * pad + 1, n); wo = noise.randint(0, 2 * pad + 1, n)
+    return torch.stack([xp[i, :, int(ho[i]):int(ho[i]) + h, int(wo[i]):int(wo[i]) + w] for i in range(n)])
+
+
+def spatial_attention(p: Params, pre: str, x: Tensor) -> Tensor:
+    """SpatialAttention.forward, visual_encoders.py:210-225 (channel_reduce is dead weight)."""
+    pool = torch.cat([x.mean(dim=1, keepdim=True), x.max(dim=1, keepdim=True)[0]], dim=1)
+    a = F.conv2d(pool, p[pre + "spatial_conv.weight"], p[pre + "spatial_conv.bias"], padding=3)
+    att = torch.sigmoid(a / p[pre + "temperature"])
+    return x + x * att
+
+
+def encoder_forward(p: Params, x: Tensor, noise=None, train: bool = False, pre: str = "", update_uv: bool = True) -> Tensor:
+    """DrQV2Encoder.forward, visual_encoders.py:135-189, on an already frame-stacked [B, 9, 84, 84] float input.
+    Draw order (train): Dropout2d channel masks [B,C,1,1] for layers 1 and 2 (p=0.025, 0.05; layer 0 has p=0), then the
+    Dropout(0.1) mask [B, 2L].  Mutates p[...weight_u/_v] in train mode like the reference's buffers."""
+    for i in range(4):
+        w, u, v = spectral_norm_weight(p[pre + f"convs.{i}.weight_orig"], p[pre + f"convs.{i}.weight_u"], p[pre + f"convs.{i}.weight_v"], train)
+        if train and update_uv:
+            p[pre + f"convs.{i}.weight_u"], p[pre + f"convs.{i}.weight_v"] = u, v
+        x = F.conv2d(x, w, None, stride=2 if i == 0 else 1, padding=1)
+        C = x.shape[1]
+        x = F.group_norm(x, min(32, C // 4), p[pre + f"norms.{i}.weight"], p[pre + f"norms.{i}.bias"], 1e-5)
+        x = F.mish(x)
+        if i < 3 and train and ENC_DROPOUT2D[i] > 0:
+            m = _t(noise.dropout_mask((x.shape[0], C), ENC_DROPOUT2D[i]))
+            x = x * m[:, :, None, None]
+    x = spatial_attention(p, pre + "attention.", x)
+    x = x.reshape(x.shape[0], -1)
+    x = F.layer_norm(x, (x.shape[1],), p[pre + "ln.weight"], p[pre + "ln.bias"], 1e-5)
+    x = F.mish(_ln(p, pre + "output_layers.1", _lin(p, pre + "output_layers.0", x)))
+    x = _drop(x, noise, 0.1, train)
+    return torch.tanh(_ln(p, pre + "output_layers.5", _lin(p, pre + "output_layers.4", x)))
+
+
+def representation_loss(p: Params, next_enc: Tensor, actions: Tensor, latents: Tensor) -> Tensor:
+    """DiffusionPixelAgent.compute_representation_loss (InfoNCE), pixel_agent.py:413-437."""
+    pred, logvar = predict_next_latent(p, latents, actions)
+    std = torch.exp(0.5 * logvar)
+    pn, tn = F.normalize(pred, dim=-1), F.normalize(next_enc, dim=-1)
+    uw = 1.0 / (1.0 + std.mean(dim=-1, keepdim=True))
+    logits = torch.matmul(pn, tn.T) / 0.1 * uw
+    return F.cross_entropy(logits, torch.arange(next_enc.shape[0]))
+
+
+def feature_decoder(p: Params, z: Tensor, noise=None, train: bool = False, pre: str = "feature_decoder.") -> Tensor:
+    """Pixel-mode feature decoder, active_inference.py:142-149: Linear, LN, ReLU, Dropout(.2), Linear, Tanh."""
+    x = F.relu(_ln(p, pre + "1", _lin(p, pre + "0", z)))
+    return torch.tanh(_lin(p, pre + "4", _drop(x, noise, 0.2, train)))

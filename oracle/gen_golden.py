@@ -82,6 +82,7 @@ class Tape:
         o["randn"], o["randn_like"], o["rand"] = torch.randn, torch.randn_like, torch.rand
         o["randperm"], o["multinomial"] = torch.randperm, torch.multinomial
         o["std_normal"], o["dropout"], o["np_randint"] = tdn._standard_normal, Fn.dropout, np.random.randint
+        o["dropout2d"], o["randint"] = Fn.dropout2d, torch.randint
         T = self
 
         def randn(*size, **kw):
@@ -115,9 +116,18 @@ class Tape:
         def np_randint(low, high=None, size=None, **kw):
             return T.ns.randint(low, high, size)
 
+        def dropout2d(x, p=0.5, training=True, inplace=False):
+            if not training or p == 0.0:
+                return x
+            return x * torch.from_numpy(T.ns.dropout_mask((x.shape[0], x.shape[1]), p)).to(x.dtype)[:, :, None, None]
+
+        def t_randint(low, high, size, **kw):
+            return torch.from_numpy(T.ns.randint(low, high, int(size[0])))
+
         torch.randn, torch.randn_like, torch.rand = randn, randn_like, rand
         torch.randperm, torch.multinomial = randperm, multinomial
         tdn._standard_normal, Fn.dropout, np.random.randint = std_normal, dropout, np_randint
+        Fn.dropout2d, torch.randint = dropout2d, t_randint
 
     def use(self, key):
         self.ns = NoiseStream(key)
@@ -388,6 +398,77 @@ def main():
             g[f"ts{step}_abssum"] = np.array([float(sd[n].double().abs().sum()) for n, _ in specs], dtype=np.float64)
         g["store_key"] = 50 + O; g["store_cap"] = cap
         np.savez_compressed(os.path.join(args.out, f"state_{tag}.npz"), **g)
+
+    # ============================================================== pixel path (A13): encoder fwd/bwd, augmentation, InfoNCE
+    from active_inference_diffusion.encoder.visual_encoders import DrQV2Encoder, RandomShiftAugmentation
+    from oracle.encoder_weights import draw_encoder_params, encoder_specs
+    FD, PB = 16, 3
+    torch.manual_seed(0)
+    tape.use(998)
+    enc = DrQV2Encoder(obs_shape=(3, 84, 84), feature_dim=FD, frame_stack=3, num_layers=4, num_filters=32)
+    especs = encoder_specs(FD)
+    esd = enc.state_dict()
+    assert [(k, tuple(v.shape)) for k, v in esd.items()] == especs, "encoder_specs differ from the reference state_dict"
+    ep = draw_encoder_params(especs, 4321)
+    enc.load_state_dict(ep)
+    pg = {"feature_dim": FD, "B": PB, "weights_key": 4321}
+    xin = NoiseStream(70).rand(PB, 3, 3, 84, 84)
+    pg["x"] = xin
+    x4 = torch.from_numpy(xin).view(PB, 9, 84, 84)
+    aug = RandomShiftAugmentation(pad=4); aug.train()
+    tape.use(71); xa_ref = aug(x4)
+    xa = orc.random_shift(x4, 4, NoiseStream(71))
+    close(xa, xa_ref, 0, 0, "random shift"); pg["aug_key"] = 71; pg["aug_checksum"] = np.float64(xa_ref.double().sum())
+    # eval forward
+    enc.eval()
+    with torch.no_grad():
+        f_ref = enc(x4)
+    po = {k: v.clone() for k, v in ep.items()}
+    report["pixel/encoder_eval"] = close(orc.encoder_forward(po, x4, None, False), f_ref, 1e-5, 1e-6, "encoder eval")
+    pg["feat_eval"] = f_ref.numpy()
+    # train forward + backward (two consecutive passes: the spectral-norm u/v state advances)
+    enc.train()
+    po = {k: v.clone() for k, v in ep.items()}
+    gnames = [k for k in ep if not k.endswith(("weight_u", "weight_v")) and "channel_reduce" not in k]
+    for k in gnames: po[k].requires_grad_(True)
+    cot = NoiseStream(72).randn(2, PB, FD)
+    for pas in (0, 1):
+        enc.zero_grad(); tape.use(73 + pas)
+        f_ref = enc(xa_ref if pas == 0 else x4)
+        (f_ref * torch.from_numpy(cot[pas])).sum().backward()
+        f_m = orc.encoder_forward(po, xa_ref if pas == 0 else x4, NoiseStream(73 + pas), True)
+        report[f"pixel/encoder_train{pas}"] = close(f_m, f_ref, 1e-5, 1e-6, "encoder train fwd")
+        gm = torch.autograd.grad((f_m * torch.from_numpy(cot[pas])).sum(), [po[k] for k in gnames], allow_unused=True)
+        refp = dict(enc.named_parameters())
+        for k, g_ in zip(gnames, gm):
+            close(g_, refp[k].grad, 2e-3, 1e-6 * max(1.0, float(refp[k].grad.abs().max())), f"encoder grad {k}")
+        pg[f"feat_train{pas}"] = f_ref.detach().numpy(); pg[f"train{pas}_key"] = 73 + pas
+        for k in gnames:
+            gr = refp[k].grad
+            if gr.numel() <= 300000:
+                pg[f"grad{pas}/{k}"] = gr.numpy().copy()
+            else:   # giant tensors: checksums + a strided sample
+                flat = gr.reshape(-1)
+                pg[f"gradsum{pas}/{k}"] = np.array([float(flat.double().sum()), float(flat.double().abs().sum())])
+                pg[f"gradsample{pas}/{k}"] = flat[::9973].numpy().copy()
+        for i in range(4):
+            pg[f"u{pas}/{i}"] = enc.state_dict()[f"convs.{i}.weight_u"].numpy().copy()
+            close(po[f"convs.{i}.weight_u"], enc.state_dict()[f"convs.{i}.weight_u"], 1e-5, 1e-7, "power-iteration u")
+    pg["cotangent_key"] = 72
+    # InfoNCE (compute_representation_loss called on a stand-in self) + its gradient wrt the target features
+    from active_inference_diffusion.agents.pixel_agent import DiffusionPixelAgent
+    O_, A_, D_, N_ = 17, 6, 64, 4
+    agent, ai, specs, params = build(O_, A_, D_, N_, 2, 8, 1234 + O_)
+    ins = NoiseStream(75); nf = ins.randn(8, O_); lat = ins.randn(8, O_); act_ = np.tanh(ins.randn(8, A_)).astype(np.float32)
+    nft = torch.from_numpy(nf).requires_grad_(True)
+    fake = types.SimpleNamespace(active_inference=ai)
+    li_ref = DiffusionPixelAgent.compute_representation_loss(fake, torch.from_numpy(nf), nft, torch.from_numpy(act_), torch.from_numpy(lat), None)
+    li_ref.backward()
+    nfm = torch.from_numpy(nf).requires_grad_(True)
+    li_m = orc.representation_loss(params, nfm, torch.from_numpy(act_), torch.from_numpy(lat))
+    close(li_m, li_ref, 1e-6, 1e-7, "infonce"); close(torch.autograd.grad(li_m, nfm)[0], nft.grad, 1e-4, 1e-8, "infonce grad")
+    pg.update(nce_next=nf, nce_lat=lat, nce_act=act_, nce_loss=li_ref.detach().numpy(), nce_grad=nft.grad.numpy())
+    np.savez_compressed(os.path.join(args.out, "pixel.npz"), **pg)
 
     # ============================================================== misc goldens
     m = {}

@@ -102,6 +102,13 @@ class AidEpistemicNet(C.Structure):
                 ("lp0", AidLinear), ("lp2", AidLinear), ("mn0", AidLinear), ("mn3", AidLinear), ("mn6", AidLinear)]
 
 
+class AidEncoderNet(C.Structure):
+    _fields_ = [("feature_dim", C.c_int32), ("in_ch", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("conv_w", C.c_void_p * 4), ("conv_u", C.c_void_p * 4), ("conv_v", C.c_void_p * 4), ("gn_g", C.c_void_p * 4), ("gn_b", C.c_void_p * 4),
+                ("att_temperature", C.c_void_p), ("att_conv_w", C.c_void_p), ("att_conv_b", C.c_void_p), ("ln_g", C.c_void_p), ("ln_b", C.c_void_p),
+                ("out0", AidLinear), ("out1", AidLN), ("out4", AidLinear), ("out5", AidLN)]
+
+
 class AidDiffusionParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("prior_mean", "prior_log_std", "log_snr_min", "log_snr_max")]
 
@@ -221,7 +228,7 @@ def lib() -> C.CDLL:
     L.aid_version.restype = C.c_int
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
-                 "aid_small_net_workspace"):
+                 "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -574,3 +581,51 @@ def collector_sampling(table: AidScoreNet, coefs, obs, num_steps: int, max_index
                                        C.c_void_p(cnt.data_ptr()), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
           "aid_collector_sampling")
     return out, cnt
+
+
+def encoder_table(params, feature_dim: int, in_ch: int = 9, hw: int = 84, prefix: str = "") -> AidEncoderNet:
+    """Table over DrQV2Encoder state_dict tensors (or their gradient twins; missing u/v entries become NULL)."""
+    t = AidEncoderNet(); t.feature_dim, t.in_ch, t.H, t.W = feature_dim, in_ch, hw, hw
+    g = lambda k: _ptr(params.get(prefix + k)).value
+    for i in range(4):
+        t.conv_w[i], t.conv_u[i], t.conv_v[i] = g(f"convs.{i}.weight_orig"), g(f"convs.{i}.weight_u"), g(f"convs.{i}.weight_v")
+        t.gn_g[i], t.gn_b[i] = g(f"norms.{i}.weight"), g(f"norms.{i}.bias")
+    t.att_temperature, t.att_conv_w, t.att_conv_b = g("attention.temperature"), g("attention.spatial_conv.weight"), g("attention.spatial_conv.bias")
+    t.ln_g, t.ln_b = g("ln.weight"), g("ln.bias")
+    t.out0 = _lin(params, prefix + "output_layers.0"); t.out1 = _ln(params, prefix + "output_layers.1")
+    t.out4 = _lin(params, prefix + "output_layers.4"); t.out5 = _ln(params, prefix + "output_layers.5")
+    return t
+
+
+def _i32ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda and t.dtype == torch.int32 and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def encoder_forward(enc: AidEncoderNet, x, shift_h=None, shift_w=None, pad=4, drop2d_1=None, drop2d_2=None, drop_out=None, train=False,
+                    saved=None, ws: Workspace = None):
+    """-> (features [B, L], saved activation buffer for encoder_backward)"""
+    B = x.shape[0]
+    x = x.reshape(B, enc.in_ch, enc.H, enc.W).contiguous().float()
+    feat = torch.empty(B, enc.feature_dim, device=x.device, dtype=torch.float32)
+    nb = lib().aid_encoder_saved_bytes(C.byref(enc), B)
+    if saved is None or saved.numel() < nb:
+        saved = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    ws = ws or Workspace(x.device)
+    buf = ws.get(lib().aid_encoder_workspace(C.byref(enc), B))
+    check(lib().aid_encoder_forward(C.byref(enc), B, _ptr(x), _i32ptr(shift_h), _i32ptr(shift_w), int(pad), _ptr(drop2d_1), _ptr(drop2d_2), _ptr(drop_out),
+                                    int(bool(train)), _ptr(feat), C.c_void_p(saved.data_ptr()), C.c_size_t(saved.numel()),
+                                    C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_encoder_forward")
+    return feat, saved
+
+
+def encoder_backward(enc: AidEncoderNet, grads: AidEncoderNet, d_features, saved, drop2d_1=None, drop2d_2=None, drop_out=None, train=False,
+                     ws: Workspace = None):
+    B = d_features.shape[0]
+    ws = ws or Workspace(d_features.device)
+    buf = ws.get(lib().aid_encoder_workspace(C.byref(enc), B))
+    check(lib().aid_encoder_backward(C.byref(enc), C.byref(grads), B, _ptr(d_features.contiguous()), _ptr(drop2d_1), _ptr(drop2d_2), _ptr(drop_out),
+                                     int(bool(train)), C.c_void_p(saved.data_ptr()), C.c_size_t(saved.numel()), C.c_void_p(buf.data_ptr()),
+                                     C.c_size_t(buf.numel()), _stream()), "aid_encoder_backward")

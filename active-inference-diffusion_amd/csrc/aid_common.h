@@ -53,7 +53,7 @@ struct Workspace {
                 (ws).off, (ws).bytes)
 
 // ---- activation ids (GEMM epilogue + row-wise kernels) -----------------------------------------
-enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3 };
+enum Act : int { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_GELU = 3, ACT_MISH = 4, ACT_TANH = 5 };
 
 // ---- GEMM:  C[M,N] = act(alpha * sum_k A(m,k) B(n,k) + bias[n]) (+ residual) (+ beta*C) ---------
 // a_kmajor = 0: A stored [M][K] (k contiguous, lda = row stride);  1: stored [K][M] (m contiguous)
@@ -72,6 +72,9 @@ struct GemmArgs {
     const float* mask;       // optional [M,N] multiplicative mask applied after act (dropout), stride ldc
     const float* dact_pre;   // optional [M,N] (stride ldc): multiply by act'(dact_pre) of kind `dact` (tangent /
     int dact;                //   backward through an activation whose pre-activation was saved)
+    float* slab;             // non-null: deterministic split-K for tiny-output / huge-K contractions (conv weight gradients, the
+    int nslab;               //   451 584-wide Linear): the 64x64 tile kernel runs `nslab` K-slices per tile, each storing its raw partial
+                             //   tile into slab[slice][M][N]; gemm_f32 then folds the slices in order (+bias, +C if accumulate)
     int ksplit;              // >1: panel kernel splits K over `ksplit` workgroups which atomically ADD into C (C must already hold
                              //     the residual / initial value; bias added by split 0; act must be NONE).  Order of the float adds,
                              //     hence the last bit, is not reproducible run to run.
@@ -119,6 +122,8 @@ __device__ __forceinline__ float act_apply(float x, int act) {
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_SILU: return x / (1.f + expf(-x));
         case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+        case ACT_MISH: return x * tanhf(log1pf(expf(x)));      // F.mish
+        case ACT_TANH: return tanhf(x);
         default: return x;
     }
 }
@@ -129,6 +134,8 @@ __device__ __forceinline__ float act_grad(float x, int act) {
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case ACT_SILU: { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
         case ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
+        case ACT_MISH: { const float t = tanhf(log1pf(expf(x))); return t + x * sigmoidf_(x) * (1.f - t * t); }
+        case ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
         default: return 1.f;
     }
 }

@@ -1,0 +1,521 @@
+// DrQ-v2 pixel encoder on gfx950: forward and backward (aid/encoder/visual_encoders.py:13-225, 471-492).
+//
+// Layout: activations live as C-N-HW ("CNHW": [channel][sample][h][w]) between the convolutions, so that
+//   * conv3x3 = ONE fp32-MFMA GEMM  out[Cout][N*HW] = W_eff[Cout][Cin*9] x col[Cin*9][N*HW]  with the weight in torch's own
+//     flatten order (no permutation) and the im2col matrix k-major (coalesced along w);
+//   * a channel plane [N][HW] is contiguous: GroupNorm / per-channel reductions / spatial pooling stream it at HBM rate.
+// First version: explicit im2col / col2im buffers (<= 2.1 GB at batch 256 - there are 288 GB); implicit GEMM is the follow-up.
+// The 451 584-wide LayerNorm + Linear use a deterministic split-K ("slab") GEMM; conv weight gradients do too.
+// Spectral normalisation follows the LEGACY torch.nn.utils.spectral_norm semantics the reference uses: one power iteration per
+// training forward mutating u/v, sigma = u.(W v) with u, v constant in the backward.
+#include "mlp.h"
+
+namespace aid {
+
+constexpr int ENC_LAYERS = 4;
+
+__device__ __forceinline__ float wg_sum256(float v, float* sh) {   // any blockDim multiple of 64 up to 1024; result valid in thread 0.. (broadcast via sh[0])
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+    const int nw = blockDim.x >> 6;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    __syncthreads();
+    return t;
+}
+
+// ---- RandomShiftAugmentation (reflect pad + per-sample crop) fused with NCHW -> CNHW ----------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * (n - 1) - i : i); }
+__global__ void aug_to_cnhw_kernel(const float* __restrict__ x, const int32_t* __restrict__ sh, const int32_t* __restrict__ sw, int pad,
+                                   float* __restrict__ out, int B, int C, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t n = (size_t)B * C * H * W;
+    if (i >= n) return;
+    const int w = i % W, h = (i / W) % H, b = (i / ((size_t)W * H)) % B, c = i / ((size_t)W * H * B);
+    int hs = h, ws = w;
+    if (sh) { hs = reflect_idx(h + sh[b] - pad, H); ws = reflect_idx(w + sw[b] - pad, W); }
+    out[i] = x[(((size_t)b * C + c) * H + hs) * W + ws];
+}
+
+// ---- legacy spectral norm: one workgroup, W [Cout][K] (K <= 1152, Cout <= 256) ------------------------------------------------
+// save layout: u_used[Cout] | v_used[K] | sigma
+__global__ void spectral_norm_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ v, int Cout, int K, int Kp,
+                                     int power_iter, int write_uv, float* __restrict__ w_eff, float* __restrict__ save) {
+    __shared__ float us[256], vs[1152], t2[256], sh[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int c = tid; c < Cout; c += blockDim.x) us[c] = u[c];
+    for (int k = tid; k < K; k += blockDim.x) vs[k] = v[k];
+    __syncthreads();
+    if (power_iter) {
+        // v = normalize(W^T u)
+        float loc = 0.f;
+        for (int k = tid; k < K; k += blockDim.x) {
+            float s = 0.f;
+            for (int c = 0; c < Cout; ++c) s += w[(size_t)c * K + k] * us[c];
+            vs[k] = s; loc += s * s;
+        }
+        const float nv = fmaxf(sqrtf(wg_sum256(loc, sh)), 1e-12f);
+        for (int k = tid; k < K; k += blockDim.x) vs[k] /= nv;
+        __syncthreads();
+    }
+    // t2 = W v  (one wave per row)
+    for (int c = wave; c < Cout; c += nw) {
+        float s = 0.f;
+        for (int k = lane; k < K; k += 64) s += w[(size_t)c * K + k] * vs[k];
+        s = wave_sum(s);
+        if (lane == 0) t2[c] = s;
+    }
+    __syncthreads();
+    if (power_iter) {
+        float loc = 0.f;
+        for (int c = tid; c < Cout; c += blockDim.x) loc += t2[c] * t2[c];
+        const float nu = fmaxf(sqrtf(wg_sum256(loc, sh)), 1e-12f);
+        for (int c = tid; c < Cout; c += blockDim.x) us[c] = t2[c] / nu;
+        __syncthreads();
+    }
+    float loc = 0.f;
+    for (int c = tid; c < Cout; c += blockDim.x) loc += us[c] * t2[c];
+    const float sigma = wg_sum256(loc, sh);
+    for (int i = tid; i < Cout * Kp; i += blockDim.x) { const int c = i / Kp, k = i % Kp; w_eff[i] = k < K ? w[(size_t)c * K + k] / sigma : 0.f; }
+    for (int c = tid; c < Cout; c += blockDim.x) { save[c] = us[c]; if (write_uv) u[c] = us[c]; }
+    for (int k = tid; k < K; k += blockDim.x) { save[Cout + k] = vs[k]; if (write_uv) v[k] = vs[k]; }
+    if (tid == 0) save[Cout + K] = sigma;
+}
+// dW_orig += (dW_eff - <dW_eff, W_eff> u v^T) / sigma
+__global__ void spectral_norm_bwd_kernel(const float* __restrict__ dw_eff, const float* __restrict__ w_eff, const float* __restrict__ save,
+                                         int Cout, int K, int Kp, float* __restrict__ dw_orig) {
+    __shared__ float sh[16];
+    float loc = 0.f;
+    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) { const int c = i / K, k = i % K; loc += dw_eff[(size_t)c * Kp + k] * w_eff[(size_t)c * Kp + k]; }
+    const float dot = wg_sum256(loc, sh);
+    const float sigma = save[Cout + K];
+    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) {
+        const int c = i / K, k = i % K;
+        dw_orig[i] += (dw_eff[(size_t)c * Kp + k] - dot * save[c] * save[Cout + k]) / sigma;
+    }
+}
+
+// ---- im2col / col2im for 3x3, pad 1, stride s; x CNHW [Cin][B][Hi][Wi]; col [Kp][B*Ho*Wo], k = ci*9 + kh*3 + kw ------------------
+__global__ void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int Cin, int B, int Hi, int Wi, int Ho, int Wo, int stride,
+                               int K, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t N = (size_t)B * Ho * Wo;
+    const int k = i / N; const size_t n = i % N;
+    float v = 0.f;
+    if (k < K) {
+        const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
+        const int wo = n % Wo, ho = (n / Wo) % Ho, b = n / ((size_t)Wo * Ho);
+        const int hi = ho * stride + kh - 1, wi = wo * stride + kw - 1;
+        if (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v = x[(((size_t)ci * B + b) * Hi + hi) * Wi + wi];
+    }
+    col[i] = v;
+}
+// dx[ci][b][hi][wi] = sum_{kh,kw} dcol[(ci,kh,kw)][(b,ho,wo)] over valid (ho,wo) with ho*s+kh-1 = hi (gather form, no atomics)
+__global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int Cin, int B, int Hi, int Wi, int Ho, int Wo, int stride,
+                               size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t N = (size_t)B * Ho * Wo;
+    const int wi = i % Wi, hi = (i / Wi) % Hi, b = (i / ((size_t)Wi * Hi)) % B, ci = i / ((size_t)Wi * Hi * B);
+    float s = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int th = hi + 1 - kh;
+        if (th < 0 || th % stride) continue;
+        const int ho = th / stride;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int tw = wi + 1 - kw;
+            if (tw < 0 || tw % stride) continue;
+            const int wo = tw / stride;
+            if (wo >= Wo) continue;
+            s += dcol[(size_t)(ci * 9 + kh * 3 + kw) * N + ((size_t)b * Ho + ho) * Wo + wo];
+        }
+    }
+    dx[i] = s;
+}
+
+// ---- GroupNorm + Mish + Dropout2d, one workgroup per (sample, group); x/y CNHW [C][B][HW] -----------------------------------------
+__global__ void gn_mish_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ mask /*[B][C] or null*/, float* __restrict__ stats /*[B][G][2]*/, float* __restrict__ y,
+                               int C, int B, int HW, int G) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+    const int n = cpg * HW;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const int c = g * cpg + i / HW; s += x[((size_t)c * B + b) * HW + i % HW]; }
+    const float mean = wg_sum256(s, sh) / (float)n;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { const int c = g * cpg + i / HW; const float d = x[((size_t)c * B + b) * HW + i % HW] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)n + 1e-5f);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = g * cpg + i / HW; const size_t o = ((size_t)c * B + b) * HW + i % HW;
+        float v = act_apply((x[o] - mean) * rstd * gamma[c] + beta[c], ACT_MISH);
+        if (mask) v *= mask[(size_t)b * C + c];
+        y[o] = v;
+    }
+}
+// backward rows: dx = rstd (g - mean g - xhat mean(g xhat)), g = dy*mask*mish'(yhat)*gamma; also writes e = dy*mask*mish'(yhat) into dy (in place)
+__global__ void gn_mish_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mask, const float* __restrict__ stats, float* __restrict__ dy /*in: dL/dy, out: e*/,
+                                   float* __restrict__ dx, int C, int B, int HW, int G) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, cpg = C / G;
+    const int n = cpg * HW;
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    float sg = 0.f, sgx = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = g * cpg + i / HW; const size_t o = ((size_t)c * B + b) * HW + i % HW;
+        const float xh = (x[o] - mean) * rstd;
+        float e = dy[o] * act_grad(xh * gamma[c] + beta[c], ACT_MISH);
+        if (mask) e *= mask[(size_t)b * C + c];
+        dy[o] = e;
+        const float gg = e * gamma[c];
+        sg += gg; sgx += gg * xh;
+    }
+    const float mg = wg_sum256(sg, sh) / (float)n, mgx = wg_sum256(sgx, sh) / (float)n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int c = g * cpg + i / HW; const size_t o = ((size_t)c * B + b) * HW + i % HW;
+        const float xh = (x[o] - mean) * rstd;
+        dx[o] = rstd * (dy[o] * gamma[c] - mg - xh * mgx);
+    }
+}
+// per-channel affine grads: dgamma[c] += sum_{b,hw} e*xhat ; dbeta[c] += sum e      (channel plane [B][HW] contiguous)
+__global__ void gn_param_grad_kernel(const float* __restrict__ e, const float* __restrict__ x, const float* __restrict__ stats,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int B, int HW, int G) {
+    __shared__ float sh[16];
+    const int c = blockIdx.x, g = c / (C / G);
+    float s0 = 0.f, s1 = 0.f;
+    for (size_t i = threadIdx.x; i < (size_t)B * HW; i += blockDim.x) {
+        const int b = i / HW; const size_t o = (size_t)c * B * HW + i;
+        const float ee = e[o];
+        s0 += ee * (x[o] - stats[2 * (b * G + g)]) * stats[2 * (b * G + g) + 1]; s1 += ee;
+    }
+    const float a0 = wg_sum256(s0, sh), a1 = wg_sum256(s1, sh);
+    if (threadIdx.x == 0) { dgamma[c] += a0; dbeta[c] += a1; }
+}
+
+// ---- SpatialAttention (visual_encoders.py:210-225) -------------------------------------------------------------------------------
+__global__ void attn_pool_kernel(const float* __restrict__ x /*CNHW*/, float* __restrict__ pool /*[B][2][HW]*/, int32_t* __restrict__ amax /*[B][HW]*/,
+                                 int C, int B, int HW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * HW) return;
+    float s = 0.f, m = -3.4e38f; int am = 0;
+    for (int c = 0; c < C; ++c) { const float v = x[(size_t)c * B * HW + i]; s += v; if (v > m) { m = v; am = c; } }
+    const int b = i / HW, p = i % HW;
+    pool[((size_t)b * 2) * HW + p] = s / (float)C; pool[((size_t)b * 2 + 1) * HW + p] = m; amax[i] = am;
+}
+__global__ void attn_conv_kernel(const float* __restrict__ pool, const float* __restrict__ w /*[2][7][7]*/, const float* __restrict__ bias,
+                                 const float* __restrict__ temp, float* __restrict__ apre, float* __restrict__ att, int B, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int x0 = i % W, y0 = (i / W) % H, b = i / (W * H);
+    float s = bias[0];
+    for (int ch = 0; ch < 2; ++ch)
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = y0 + ky - 3; if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 7; ++kx) { const int xx = x0 + kx - 3; if (xx < 0 || xx >= W) continue;
+                s += pool[(((size_t)b * 2 + ch) * H + yy) * W + xx] * w[(ch * 7 + ky) * 7 + kx]; }
+        }
+    apre[i] = s; att[i] = 1.f / (1.f + expf(-s / temp[0]));
+}
+// out (NCHW-flattened [B][C*HW]) = x * (1 + att)
+__global__ void attn_apply_kernel(const float* __restrict__ x, const float* __restrict__ att, float* __restrict__ out, int C, int B, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * B * HW) return;
+    const int p = i % HW, b = (i / HW) % B, c = i / ((size_t)HW * B);
+    out[((size_t)b * C + c) * HW + p] = x[i] * (1.f + att[(size_t)b * HW + p]);
+}
+// backward A: per (b,p): datt = sum_c dout*x ; da = datt*att(1-att)/T ; tpart[i] = -datt*att(1-att)*a/T^2 ; dxa (CNHW) = dout*(1+att)
+__global__ void attn_bwd_a_kernel(const float* __restrict__ dout /*[B][C][HW]*/, const float* __restrict__ x /*CNHW*/, const float* __restrict__ att,
+                                  const float* __restrict__ apre, const float* __restrict__ temp, float* __restrict__ dx /*CNHW*/,
+                                  float* __restrict__ da, float* __restrict__ tpart, int C, int B, int HW) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * HW) return;
+    const int b = i / HW, p = i % HW;
+    const float a = att[i], T = temp[0];
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float d = dout[((size_t)b * C + c) * HW + p];
+        s += d * x[(size_t)c * B * HW + i];
+        dx[(size_t)c * B * HW + i] = d * (1.f + a);
+    }
+    const float g = s * a * (1.f - a);
+    da[i] = g / T; tpart[i] = -g * apre[i] / (T * T);
+}
+// backward B: dpool = conv_transpose(da, w); then route: dx[c] += dpool_avg / C  (+ dpool_max at the argmax channel)
+__global__ void attn_bwd_b_kernel(const float* __restrict__ da, const float* __restrict__ w, const int32_t* __restrict__ amax, float* __restrict__ dx,
+                                  int C, int B, int H, int W) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * H * W) return;
+    const int x0 = i % W, y0 = (i / W) % H, b = i / (W * H);
+    float d0 = 0.f, d1 = 0.f;
+    for (int ky = 0; ky < 7; ++ky) {
+        const int yy = y0 - ky + 3; if (yy < 0 || yy >= H) continue;
+        for (int kx = 0; kx < 7; ++kx) { const int xx = x0 - kx + 3; if (xx < 0 || xx >= W) continue;
+            const float g = da[((size_t)b * H + yy) * W + xx];
+            d0 += g * w[(0 * 7 + ky) * 7 + kx]; d1 += g * w[(1 * 7 + ky) * 7 + kx]; }
+    }
+    const float avg = d0 / (float)C; const int am = amax[i];
+    for (int c = 0; c < C; ++c) dx[(size_t)c * B * H * W + i] += avg + (c == am ? d1 : 0.f);
+}
+// backward C (one workgroup): dW[2][7][7], dbias, dtemperature
+__global__ void attn_bwd_c_kernel(const float* __restrict__ da, const float* __restrict__ pool, const float* __restrict__ tpart, float* __restrict__ dw,
+                                  float* __restrict__ dbias, float* __restrict__ dtemp, int B, int H, int W) {
+    __shared__ float sh[16];
+    const int n = B * H * W;
+    for (int t = 0; t < 98; ++t) {
+        const int ch = t / 49, ky = (t % 49) / 7, kx = t % 7;
+        float s = 0.f;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int x0 = i % W, y0 = (i / W) % H, b = i / (W * H);
+            const int yy = y0 + ky - 3, xx = x0 + kx - 3;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += da[i] * pool[(((size_t)b * 2 + ch) * H + yy) * W + xx];
+        }
+        const float tot = wg_sum256(s, sh);
+        if (threadIdx.x == 0) dw[t] += tot;
+    }
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { s0 += da[i]; s1 += tpart[i]; }
+    const float a0 = wg_sum256(s0, sh), a1 = wg_sum256(s1, sh);
+    if (threadIdx.x == 0) { dbias[0] += a0; dtemp[0] += a1; }
+}
+
+// ---- LayerNorm over F = 451 584 features, one workgroup per row -----------------------------------------------------------------------
+__global__ void bigln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                             float* __restrict__ stats, size_t F) {
+    __shared__ float sh[16];
+    const float* xr = x + (size_t)blockIdx.x * F; float* yr = y + (size_t)blockIdx.x * F;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
+    const float mean = wg_sum256(s, sh) / (float)F;
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+}
+__global__ void bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                 const float* __restrict__ stats, float* __restrict__ dx, size_t F) {
+    __shared__ float sh[16];
+    const float* xr = x + (size_t)blockIdx.x * F; const float* dyr = dy + (size_t)blockIdx.x * F; float* dxr = dx + (size_t)blockIdx.x * F;
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    float sg = 0.f, sgx = 0.f;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += g; sgx += g * (xr[i] - mean) * rstd; }
+    const float mg = wg_sum256(sg, sh) / (float)F, mgx = wg_sum256(sgx, sh) / (float)F;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr[i] - mean) * rstd * mgx);
+}
+__global__ void bigln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
+                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, size_t F) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= F) return;
+    float s0 = 0.f, s1 = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = dy[(size_t)b * F + i]; s0 += d * (x[(size_t)b * F + i] - stats[2 * b]) * stats[2 * b + 1]; s1 += d; }
+    dgamma[i] += s0; dbeta[i] += s1;
+}
+
+#define L1D(kern, n, s, ...)                                                                                                \
+    do {                                                                                                                    \
+        if ((n) > 0) { hipLaunchKernelGGL(kern, dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, s, __VA_ARGS__); AID_LAUNCH_CHECK(); } \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------------------------------------------
+struct EncGeom { int cin[ENC_LAYERS], cout[ENC_LAYERS], hi[ENC_LAYERS], ho[ENC_LAYERS], stride[ENC_LAYERS], K[ENC_LAYERS], Kp[ENC_LAYERS], G[ENC_LAYERS]; int HW; size_t F; };
+static EncGeom enc_geom(const AidEncoderNet& e) {
+    EncGeom g; int h = e.H, c = e.in_ch;
+    const int ch[ENC_LAYERS] = {32, 64, 128, 256};
+    for (int i = 0; i < ENC_LAYERS; ++i) {
+        g.cin[i] = c; g.cout[i] = ch[i]; g.stride[i] = i == 0 ? 2 : 1; g.hi[i] = h; g.ho[i] = (h + 2 - 3) / g.stride[i] + 1;
+        g.K[i] = c * 9; g.Kp[i] = (g.K[i] + 3) / 4 * 4; g.G[i] = ch[i] / 4 < 32 ? ch[i] / 4 : 32;
+        h = g.ho[i]; c = ch[i];
+    }
+    g.HW = h * h; g.F = (size_t)256 * g.HW;
+    return g;
+}
+
+// activation store that must survive from the forward to the backward (caller-owned, aid_encoder_saved_bytes)
+struct EncSaved {
+    float* x0;                                   // augmented input, CNHW
+    float* conv_out[ENC_LAYERS]; float* act[ENC_LAYERS]; float* gn_stats[ENC_LAYERS]; float* w_eff[ENC_LAYERS]; float* sn[ENC_LAYERS];
+    float *pool, *apre, *att; int32_t* amax;
+    float *xf, *ln_stats, *xln;
+    LlaSave s0; float* o4; float* st5; float* feat;
+};
+static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSaved& sv) {
+    const EncGeom g = enc_geom(e);
+    sv.x0 = ws.f32((size_t)e.in_ch * B * e.H * e.W);
+    for (int i = 0; i < ENC_LAYERS; ++i) {
+        const size_t n = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i];
+        sv.conv_out[i] = ws.f32(n); sv.act[i] = ws.f32(n); sv.gn_stats[i] = ws.f32((size_t)B * g.G[i] * 2);
+        sv.w_eff[i] = ws.f32((size_t)g.cout[i] * g.Kp[i]); sv.sn[i] = ws.f32(g.cout[i] + g.K[i] + 4);
+    }
+    sv.pool = ws.f32((size_t)B * 2 * g.HW); sv.apre = ws.f32((size_t)B * g.HW); sv.att = ws.f32((size_t)B * g.HW);
+    sv.amax = (int32_t*)ws.raw(sizeof(int32_t) * (size_t)B * g.HW);
+    sv.xf = ws.f32((size_t)B * g.F); sv.ln_stats = ws.f32((size_t)B * 2); sv.xln = ws.f32((size_t)B * g.F);
+    lla_alloc(B, e.out0.out, ws, sv.s0);
+    sv.o4 = ws.f32((size_t)B * e.out4.out); sv.st5 = ws.f32((size_t)B * 2); sv.feat = ws.f32((size_t)B * e.out4.out);
+}
+
+static int conv_slabs(size_t N) { int s = (int)(N / 8192); return s < 1 ? 1 : (s > 96 ? 96 : s); }
+
+}  // namespace aid
+
+using namespace aid;
+
+extern "C" {
+
+size_t aid_encoder_saved_bytes(const AidEncoderNet* enc, int B) {
+    if (!enc || B <= 0) return 0;
+    Workspace ws(nullptr, 0); EncSaved sv; enc_saved_layout(*enc, B, ws, sv); return ws.off + 4096;
+}
+size_t aid_encoder_workspace(const AidEncoderNet* enc, int B) {
+    if (!enc || B <= 0) return 0;
+    const EncGeom g = enc_geom(*enc);
+    const size_t N = (size_t)B * g.HW;
+    size_t col = 0, act = 0;
+    for (int i = 0; i < ENC_LAYERS; ++i) { const size_t c = (size_t)g.Kp[i] * B * g.ho[i] * g.ho[i]; if (c > col) col = c;
+                                            const size_t a = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i]; if (a > act) act = a; }
+    size_t n = sizeof(float) * (2 * col + 3 * act + 2 * (size_t)B * g.F + 4 * N + 96 * (size_t)256 * 1152 + (size_t)96 * B * enc->out0.out + (1 << 20));
+    return n + (1 << 20);
+}
+
+// forward.  x: [B, in_ch, H, W] float (frame-stacked, already in [0,1]); shift_h/shift_w: per-sample crop offsets in [0, 2*pad] or NULL
+// (no augmentation); drop2d_1 [B,64], drop2d_2 [B,128], drop_out [B, 2*feature_dim]: scaled keep masks or NULL (eval / Philox)
+int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const int32_t* shift_h, const int32_t* shift_w, int pad,
+                        const float* drop2d_1, const float* drop2d_2, const float* drop_out, int train, float* features, void* saved,
+                        size_t saved_bytes, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(enc && x && features && saved, AID_E_NULL, "aid_encoder_forward: null argument");
+    AID_REQUIRE(B > 0 && enc->H == enc->W && enc->in_ch * 9 <= 1152, AID_E_SHAPE, "aid_encoder_forward: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    const AidEncoderNet& e = *enc;
+    const EncGeom g = enc_geom(e);
+    Workspace sws(saved, saved_bytes); EncSaved sv; enc_saved_layout(e, B, sws, sv); AID_WS_OK(sws);
+    Workspace ws(wsp, ws_bytes);
+    const float* masks[ENC_LAYERS] = {nullptr, train ? drop2d_1 : nullptr, train ? drop2d_2 : nullptr, nullptr};
+    L1D(aug_to_cnhw_kernel, (size_t)B * e.in_ch * e.H * e.W, s, x, train ? shift_h : nullptr, shift_w, pad, sv.x0, B, e.in_ch, e.H, e.W);
+    const float* cur = sv.x0;
+    for (int i = 0; i < ENC_LAYERS; ++i) {
+        const size_t N = (size_t)B * g.ho[i] * g.ho[i];
+        const size_t mark = ws.mark();
+        float* col = ws.f32((size_t)g.Kp[i] * N); AID_WS_OK(ws);
+        hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, s, e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], train,
+                           train, sv.w_eff[i], sv.sn[i]);
+        AID_LAUNCH_CHECK();
+        L1D(im2col3_kernel, (size_t)g.Kp[i] * N, s, cur, col, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], g.K[i], (size_t)g.Kp[i] * N);
+        GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], col, (int)N, sv.conv_out[i], (int)N, g.cout[i], (int)N, g.Kp[i]);
+        ga.b_kmajor = 1;
+        AID_TRY(gemm_f32(ga, s));
+        hipLaunchKernelGGL(gn_mish_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], sv.act[i],
+                           g.cout[i], B, g.ho[i] * g.ho[i], g.G[i]);
+        AID_LAUNCH_CHECK();
+        ws.release(mark);
+        cur = sv.act[i];
+    }
+    const int HW = g.HW, Hh = g.ho[3];
+    L1D(attn_pool_kernel, B * HW, s, cur, sv.pool, sv.amax, 256, B, HW);
+    L1D(attn_conv_kernel, B * HW, s, sv.pool, e.att_conv_w, e.att_conv_b, e.att_temperature, sv.apre, sv.att, B, Hh, Hh);
+    L1D(attn_apply_kernel, (size_t)256 * B * HW, s, cur, sv.att, sv.xf, 256, B, HW);
+    hipLaunchKernelGGL(bigln_kernel, dim3(B), dim3(1024), 0, s, sv.xf, e.ln_g, e.ln_b, sv.xln, sv.ln_stats, g.F);
+    AID_LAUNCH_CHECK();
+    {   // Linear(F -> 2L): deterministic split-K
+        const size_t mark = ws.mark();
+        const int S = conv_slabs(g.F);
+        GemmArgs ga = gemm_args(sv.xln, (int)g.F, e.out0.w, (int)g.F, sv.s0.lin, e.out0.out, B, e.out0.out, (int)g.F);
+        ga.bias = e.out0.b; ga.slab = ws.f32((size_t)S * B * e.out0.out); ga.nslab = S; AID_WS_OK(ws);
+        AID_TRY(gemm_f32(ga, s));
+        ws.release(mark);
+    }
+    AID_TRY(ln_act(sv.s0.lin, e.out0.out, e.out1.g, e.out1.b, ACT_MISH, train ? drop_out : nullptr, sv.s0.y, e.out0.out, sv.s0.stats, B, e.out0.out, s));
+    AID_TRY(linear_fwd(sv.s0.y, e.out0.out, e.out4.w, e.out4.b, sv.o4, e.out4.out, B, e.out4.out, e.out4.in, ACT_NONE, s));
+    AID_TRY(ln_act(sv.o4, e.out4.out, e.out5.g, e.out5.b, ACT_TANH, nullptr, sv.feat, e.out4.out, sv.st5, B, e.out4.out, s));
+    AID_TRY(copy_f32(sv.feat, features, (size_t)B * e.out4.out, s));
+    return AID_OK;
+}
+
+// backward: d_features [B, L] -> parameter gradients ACCUMULATED into `grads` (same table type; conv_u/conv_v/unused members ignored)
+int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                         const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* wsp,
+                         size_t ws_bytes, void* stream) {
+    AID_REQUIRE(enc && grads && d_features && saved, AID_E_NULL, "aid_encoder_backward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const AidEncoderNet& e = *enc; const AidEncoderNet& gr = *grads;
+    const EncGeom g = enc_geom(e);
+    Workspace sws((void*)saved, saved_bytes); EncSaved sv; enc_saved_layout(e, B, sws, sv); AID_WS_OK(sws);
+    Workspace ws(wsp, ws_bytes);
+    const int L = e.out4.out, L2 = e.out0.out, HW = g.HW, Hh = g.ho[3];
+    const float* masks[ENC_LAYERS] = {nullptr, train ? drop2d_1 : nullptr, train ? drop2d_2 : nullptr, nullptr};
+    float* d_o4 = ws.f32((size_t)B * L); float* dyeff = ws.f32((size_t)B * (L2 > L ? L2 : L)); float* dh1 = ws.f32((size_t)B * L2);
+    float* d_o0 = ws.f32((size_t)B * L2);
+    float* dxln = ws.f32((size_t)B * g.F); float* dxf = ws.f32((size_t)B * g.F);
+    AID_WS_OK(ws);
+    // ---- output head: tanh(LN(Linear)) <- Dropout(Mish(LN(Linear(F))))
+    AID_TRY(ln_bwd_rows(d_features, L, sv.o4, L, sv.st5, e.out5.g, e.out5.b, ACT_TANH, nullptr, d_o4, L, dyeff, B, L, s));
+    AID_TRY(ln_param_grad(dyeff, sv.o4, L, sv.st5, gr.out5.g, gr.out5.b, B, L, s, &ws));
+    AID_TRY(linear_bwd_weight(d_o4, L, sv.s0.y, L2, gr.out4.w, B, L, L2, s, 1));
+    AID_TRY(colsum(d_o4, L, gr.out4.b, B, L, 1, s, &ws));
+    AID_TRY(linear_bwd_data(d_o4, L, e.out4.w, L2, dh1, L2, B, L, s));
+    AID_TRY(ln_bwd_rows(dh1, L2, sv.s0.lin, L2, sv.s0.stats, e.out1.g, e.out1.b, ACT_MISH, train ? drop_out : nullptr, d_o0, L2, dyeff, B, L2, s));
+    AID_TRY(ln_param_grad(dyeff, sv.s0.lin, L2, sv.s0.stats, gr.out1.g, gr.out1.b, B, L2, s, &ws));
+    // ---- Linear(F -> 2L): dW [2L, F] += d_o0^T xln ; db ; dxln = d_o0 W
+    AID_TRY(linear_bwd_weight(d_o0, L2, sv.xln, (int)g.F, gr.out0.w, B, L2, (int)g.F, s, 1));
+    AID_TRY(colsum(d_o0, L2, gr.out0.b, B, L2, 1, s, &ws));
+    AID_TRY(linear_bwd_data(d_o0, L2, e.out0.w, (int)g.F, dxln, (int)g.F, B, L2, s));
+    // ---- LayerNorm(F)
+    hipLaunchKernelGGL(bigln_param_grad_kernel, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, s, dxln, sv.xf, sv.ln_stats, gr.ln_g, gr.ln_b, B, g.F);
+    hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.xf, e.ln_g, sv.ln_stats, dxf, g.F);
+    AID_LAUNCH_CHECK();
+    // ---- spatial attention
+    const size_t nact3 = (size_t)256 * B * HW;
+    float* dact = ws.f32(nact3); float* da = ws.f32((size_t)B * HW); float* tpart = ws.f32((size_t)B * HW);
+    AID_WS_OK(ws);
+    L1D(attn_bwd_a_kernel, B * HW, s, dxf, sv.act[3], sv.att, sv.apre, e.att_temperature, dact, da, tpart, 256, B, HW);
+    hipLaunchKernelGGL(attn_bwd_c_kernel, dim3(1), dim3(1024), 0, s, da, sv.pool, tpart, gr.att_conv_w, gr.att_conv_b, gr.att_temperature, B, Hh, Hh);
+    AID_LAUNCH_CHECK();
+    L1D(attn_bwd_b_kernel, B * HW, s, da, e.att_conv_w, sv.amax, dact, 256, B, Hh, Hh);
+    // ---- conv stack, reverse
+    float* dcur = dact;      // gradient wrt act[i] (CNHW)
+    for (int i = ENC_LAYERS - 1; i >= 0; --i) {
+        const int hw = g.ho[i] * g.ho[i];
+        const size_t N = (size_t)B * hw;
+        const size_t mark = ws.mark();
+        float* dconv = ws.f32((size_t)g.cout[i] * N); float* col = ws.f32((size_t)g.Kp[i] * N);
+        float* dweff = ws.f32((size_t)g.cout[i] * g.Kp[i]);
+        const int S = conv_slabs(N);
+        float* slab = ws.f32((size_t)S * g.cout[i] * g.Kp[i]);
+        AID_WS_OK(ws);
+        hipLaunchKernelGGL(gn_mish_bwd_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv,
+                           g.cout[i], B, hw, g.G[i]);
+        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(g.cout[i]), dim3(1024), 0, s, dcur, sv.conv_out[i], sv.gn_stats[i], gr.gn_g[i], gr.gn_b[i], g.cout[i], B, hw, g.G[i]);
+        AID_LAUNCH_CHECK();
+        const float* xin = i == 0 ? sv.x0 : sv.act[i - 1];
+        L1D(im2col3_kernel, (size_t)g.Kp[i] * N, s, xin, col, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], g.K[i], (size_t)g.Kp[i] * N);
+        {   // dW_eff[Cout][Kp] = dconv[Cout][N] x col[Kp][N]^T  (both k-contiguous along N; huge reduction -> slabs)
+            GemmArgs ga = gemm_args(dconv, (int)N, col, (int)N, dweff, g.Kp[i], g.cout[i], g.Kp[i], (int)N);
+            ga.slab = slab; ga.nslab = S;
+            AID_TRY(gemm_f32(ga, s));
+        }
+        hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, s, dweff, sv.w_eff[i], sv.sn[i], g.cout[i], g.K[i], g.Kp[i], gr.conv_w[i]);
+        AID_LAUNCH_CHECK();
+        if (i > 0) {   // dcol[Kp][N] = W_eff^T dconv ; col2im -> gradient wrt act[i-1]
+            GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], dconv, (int)N, col, (int)N, g.Kp[i], (int)N, g.cout[i]);
+            ga.a_kmajor = 1; ga.b_kmajor = 1;
+            AID_TRY(gemm_f32(ga, s));
+            const size_t nin = (size_t)g.cin[i] * B * g.hi[i] * g.hi[i];
+            float* dprev = dconv;   // reuse: dconv is dead after the two GEMMs; cin*hi*hi*B <= cout*ho*ho*B for layers 1..3
+            L1D(col2im3_kernel, nin, s, col, dprev, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], nin);
+            // keep dprev alive below the mark: copy into the persistent gradient buffer
+            AID_TRY(copy_f32(dprev, dact, nin, s));
+            dcur = dact;
+        }
+        ws.release(mark);
+    }
+    return AID_OK;
+}
+
+}  // extern "C"

@@ -152,9 +152,12 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[PA], rb[PB];
-    const int nk = (g.K + BK - 1) / BK;
-    load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
-    load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
+    const int nk_all = (g.K + BK - 1) / BK;
+    const int per = (nk_all + gridDim.y - 1) / gridDim.y;           // K tiles per slice (gridDim.y = 1 unless slab mode)
+    const int kt0 = blockIdx.y * per;
+    const int nk = max(0, min(per, nk_all - kt0));
+    load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, kt0 * BK, g.M, g.K, tid, ra);
+    load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, kt0 * BK, g.N, g.K, tid, rb);
     store_tile<BM, AKM, NT, PA>(As, tid, ra);
     store_tile<BN, BKM, NT, PB>(Bs, tid, rb);
     __syncthreads();
@@ -162,8 +165,8 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
-            load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, (kt + 1) * BK, g.M, g.K, tid, ra);
-            load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, (kt + 1) * BK, g.N, g.K, tid, rb);
+            load_tile<BM, AKM, VEC, NT, PA>(g.A, g.lda, m0, (kt0 + kt + 1) * BK, g.M, g.K, tid, ra);
+            load_tile<BN, BKM, VEC, NT, PB>(g.B, g.ldb, n0, (kt0 + kt + 1) * BK, g.N, g.K, tid, rb);
         }
         const float* a_s = As + cur * TA::FLOATS;
         const float* b_s = Bs + cur * TB::FLOATS;
@@ -189,15 +192,17 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
         __syncthreads();
     }
     // C/D map of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
+    // (full unroll is mandatory: a rolled loop would index acc[][] at run time and send the accumulators to scratch)
+#pragma clang loop unroll(full)
     for (int i = 0; i < TM; ++i)
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int j = 0; j < TN; ++j)
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = n0 + wn + 32 * j + li;
-                epilogue_store(g, row, col, acc[i][j][r]);
+                if (g.slab) { if (row < g.M && col < g.N) g.slab[((size_t)blockIdx.y * g.M + row) * g.N + col] = acc[i][j][r]; }
+                else epilogue_store(g, row, col, acc[i][j][r]);
             }
 }
 
@@ -478,7 +483,7 @@ __global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n)
         asm volatile("" ::: "memory");
         const float* a_s = As + cur * RA::FLOATS;
         const float* b_s = Bs + cur * RB::FLOATS;
-#pragma unroll 2
+#pragma unroll 1
         for (int g8 = 0; g8 < KSTAGE / 8; ++g8) {
             f32x4 av[TM], bv[TN];
 #pragma unroll
@@ -500,11 +505,11 @@ __global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n)
             ring_dma<BN, KSTAGE, BKM>(g.B, g.ldb, n0, g.N, (st + 2) * KSTAGE, Bs + cur * RB::FLOATS, wave, lane);
         }
     }
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < TM; ++i)
-#pragma unroll
+#pragma clang loop unroll(full)
         for (int j = 0; j < TN; ++j)
-#pragma unroll
+#pragma clang loop unroll(full)
             for (int r = 0; r < 16; ++r)
                 epilogue_store(g, m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + wn + 32 * j + li, acc[i][j][r]);
 }
@@ -552,8 +557,9 @@ static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
             done = true;
         }
     }
-    if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, true>), dim3(tm * tn), dim3(256), lds, s, g, tn);
-    else     hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, false>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    const int ny = g.slab ? g.nslab : 1;
+    if (vec) hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, true>), dim3(tm * tn, ny), dim3(256), lds, s, g, tn);
+    else     hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, false>), dim3(tm * tn, ny), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
 template <bool AKM, bool BKM>
@@ -605,6 +611,20 @@ static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0;
 
 void gemm_force_kernel(int k) { g_force_kernel = k; }
 
+__global__ void slab_fold_kernel(const float* __restrict__ slab, int nslab, GemmArgs g) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t mn = (size_t)g.M * g.N;
+    if (i >= mn) return;
+    float v = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) v += slab[(size_t)sl * mn + i];
+    const int row = i / g.N, col = i % g.N;
+    v *= g.alpha;
+    if (g.bias) v += g.bias[col];
+    const size_t o = (size_t)row * g.ldc + col;
+    if (g.accumulate) v += g.C[o];
+    g.C[o] = v;
+}
+
 int gemm_f32(const GemmArgs& g, hipStream_t s) {
     AID_REQUIRE(g.A && g.B && g.C, AID_E_NULL, "gemm_f32: null operand");
     AID_REQUIRE(g.M >= 0 && g.N >= 0 && g.K >= 0, AID_E_SHAPE, "gemm_f32: negative dim");
@@ -615,6 +635,20 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     // vector (16-B) global loads need every row start 16-B aligned along the contiguous dim
     bool vec = aligned16(g.A) && aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);
     vec = vec && (g.a_kmajor ? (g.M % 4 == 0) : (g.K % 4 == 0)) && (g.b_kmajor ? (g.N % 4 == 0) : (g.K % 4 == 0));
+    if (g.slab) {   // deterministic split-K: K-slices -> slab -> ordered fold
+        AID_REQUIRE(g.nslab >= 1 && g.act == ACT_NONE && !g.preact && !g.mask && !g.dact_pre && !g.residual, AID_E_SHAPE, "gemm_f32: slab mode needs a plain epilogue");
+        ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+        int r;
+        if (!g.a_kmajor && !g.b_kmajor) r = launch_tile<64, 64, false, false>(g, vec, s);
+        else if (!g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, false, true>(g, vec, s);
+        else if (g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, true, true>(g, vec, s);
+        else r = launch_tile<64, 64, true, false>(g, vec, s);
+        if (r != AID_OK) return r;
+        const size_t mn = (size_t)g.M * g.N;
+        hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, g.slab, g.nslab, g);
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
     ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
     int r;
     if (!g.a_kmajor && !g.b_kmajor) r = dispatch<false, false>(g, vec, s);

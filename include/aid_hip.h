@@ -278,6 +278,31 @@ int aid_reward_normalize(const float* rewards, int B, double* state, float* out,
 int aid_reward_normalize_global(const float* stats_src, int n_stats, const float* rewards, int B, double* state, float* out,
                                 void* stream);
 
+/* ---- A13: DrQ-v2 pixel encoder (aid/encoder/visual_encoders.py:13-225) + RandomShiftAugmentation (:471-492) ----------
+ * 4 x {conv3x3 (no bias, legacy spectral norm; stride 2,1,1,1; in_ch->32->64->128->256) -> GroupNorm -> Mish -> Dropout2d}
+ * -> SpatialAttention -> flatten (NCHW order) -> LayerNorm(256*42*42) -> Linear -> LN -> Mish -> Dropout(.1) -> Linear -> LN -> tanh.
+ * x: [B, in_ch, H, W] float32 (frame-stacked, in [0,1]).  shift_h / shift_w: per-sample crop offsets in [0, 2*pad] of the
+ * reflect-padded image (NULL = no augmentation).  drop2d_1 [B,64], drop2d_2 [B,128], drop_out [B, 2*feature_dim]: scaled keep masks
+ * (NULL in eval mode).  train=1 runs the power iteration and UPDATES conv_u / conv_v in place (as the reference's buffers).
+ * `saved` (aid_encoder_saved_bytes) carries the activations to aid_encoder_backward, which ACCUMULATES parameter gradients
+ * into `grads` (conv_w = d weight_orig; conv_u/conv_v ignored). */
+typedef struct AidEncoderNet {
+    int32_t feature_dim, in_ch, H, W;
+    float *conv_w[4], *conv_u[4], *conv_v[4];            /* convs.i.weight_orig / weight_u / weight_v */
+    float *gn_g[4], *gn_b[4];                            /* norms.i.weight / bias */
+    float *att_temperature, *att_conv_w, *att_conv_b;    /* attention.temperature / spatial_conv.{weight,bias} */
+    float *ln_g, *ln_b;                                  /* ln.weight / bias [256*42*42] */
+    AidLinear out0; AidLN out1; AidLinear out4; AidLN out5;   /* output_layers.{0,1,4,5} */
+} AidEncoderNet;
+size_t aid_encoder_saved_bytes(const AidEncoderNet* enc, int B);
+size_t aid_encoder_workspace(const AidEncoderNet* enc, int B);
+int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const int32_t* shift_h, const int32_t* shift_w, int pad,
+                        const float* drop2d_1, const float* drop2d_2, const float* drop_out, int train, float* features, void* saved,
+                        size_t saved_bytes, void* ws, size_t ws_bytes, void* stream);
+int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                         const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* ws,
+                         size_t ws_bytes, void* stream);
+
 /* ---- A0: ReplayBuffer.sample gather (aid/utils/buffers.py:83-111), device-resident ring arrays.
  * idx: [B] int64 row indices.  One coalesced pass over the 2*O + A + 2 floats of each transition. */
 int aid_replay_gather(const float* obs, const float* next_obs, const float* actions, const float* rewards, const float* dones,

@@ -8,11 +8,15 @@ from .configs.config import (ActiveInferenceConfig, BeliefDynamicsConfig, Diffus
 
 __version__ = "0.1.0"
 __all__ = ["ActiveInferenceConfig", "BeliefDynamicsConfig", "DiffusionConfig", "PixelObservationConfig", "TrainingConfig",
-           "DiffusionStateAgent", "StateBasedAgent", "DiffusionActiveInference", "LatentDiffusionProcess", "BeliefDynamics", "FreeEnergyComputation"]
+           "DiffusionStateAgent", "StateBasedAgent", "DiffusionPixelAgent", "PixelBasedAgent", "DrQV2Encoder",
+           "RandomShiftAugmentation", "DiffusionActiveInference", "LatentDiffusionProcess", "BeliefDynamics", "FreeEnergyComputation"]
 
 
 def __getattr__(name):  # lazy: importing the package must not require the GPU library (build() imports it on CPU)
-    if name in ("DiffusionStateAgent", "StateBasedAgent", "BaseActiveInferenceAgent"):
+    if name in ("DrQV2Encoder", "RandomShiftAugmentation", "SpatialAttention"):
+        from . import encoder
+        return getattr(encoder, name)
+    if name in ("DiffusionStateAgent", "StateBasedAgent", "DiffusionPixelAgent", "PixelBasedAgent", "BaseActiveInferenceAgent"):
         from . import agents
         return getattr(agents, name)
     if name in ("DiffusionActiveInference", "LatentDiffusionProcess", "BeliefDynamics", "FreeEnergyComputation", "EMAModel"):

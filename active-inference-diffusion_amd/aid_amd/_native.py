@@ -114,7 +114,11 @@ class AidDiffusionParams(C.Structure):
 
 
 class AidElboNoise(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2")]
+    _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2", "d_obs_out")]
+
+
+class AidFeatureDecoder(C.Structure):
+    _fields_ = [("l0", AidLinear), ("ln", AidLN), ("l4", AidLinear)]
 
 
 class AidEfeNoise(C.Structure):
@@ -372,7 +376,7 @@ ELBO_METRICS = ("reconstruction_loss", "kl_loss", "score_matching_loss", "elbo",
 def elbo_step(net: AidScoreNet, grads: AidScoreNet, dp: AidDiffusionParams, dgrads: AidDiffusionParams, dec: AidDecoderNet,
               rew: AidRewardNet, obs, rewards, latents, time_importance, first_call: bool, noise: dict = None, train=True,
               kl_weight=0.1, diffusion_weight=1.0, reward_weight=0.5, gp_weight=0.1, seed=0, offset=0, ws: Workspace = None,
-              defer_time_importance=False):
+              defer_time_importance=False, recon_preset=None):
     """compute_diffusion_elbo forward+backward; gradients accumulate into the `grads`/`dgrads` tables.
     -> (metrics [16] device tensor, t [B], per_sample_losses [B])"""
     B = obs.shape[0]
@@ -383,11 +387,14 @@ def elbo_step(net: AidScoreNet, grads: AidScoreNet, dp: AidDiffusionParams, dgra
     cfg = AidElboCfg(kl_weight, diffusion_weight, reward_weight, gp_weight, int(bool(train)), int(bool(first_call)), seed, offset,
                      int(bool(defer_time_importance)), 0)
     metrics = torch.zeros(16, device=obs.device, dtype=torch.float32)
+    if recon_preset is not None:
+        metrics[0:1].copy_(recon_preset.reshape(1))
     t_out = torch.empty(B, device=obs.device, dtype=torch.float32)
     per = torch.empty(B, device=obs.device, dtype=torch.float32)
     ws = ws or Workspace(obs.device)
-    buf = ws.get(lib().aid_elbo_step_workspace(C.byref(net), C.byref(dec), B))
-    check(lib().aid_elbo_step(C.byref(net), C.byref(grads), C.byref(dp), C.byref(dgrads), C.byref(dec), C.byref(rew), B, _ptr(obs),
+    decp = C.byref(dec) if dec is not None else None
+    buf = ws.get(lib().aid_elbo_step_workspace(C.byref(net), decp, B))
+    check(lib().aid_elbo_step(C.byref(net), C.byref(grads), C.byref(dp), C.byref(dgrads), decp, C.byref(rew), B, _ptr(obs),
                               _ptr(rewards), _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(time_importance), _ptr(t_out), _ptr(per),
                               _ptr(metrics), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_elbo_step")
     return metrics, t_out, per
@@ -422,9 +429,10 @@ def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizo
     efe = torch.empty(B, device=latents.device, dtype=torch.float32)
     info = torch.zeros(16, device=latents.device, dtype=torch.float32)
     ws = ws or Workspace(latents.device)
-    buf = ws.get(lib().aid_efe_step_workspace(C.byref(pol), C.byref(dec), B, C.byref(cfg)))
+    decp = C.byref(dec) if dec is not None else None
+    buf = ws.get(lib().aid_efe_step_workspace(C.byref(pol), decp, B, C.byref(cfg)))
     check(lib().aid_efe_step(C.byref(pol), C.byref(pgrads) if pgrads is not None else None, C.byref(dyn), C.byref(rew), C.byref(val),
-                             C.byref(dec), C.byref(epi), B, _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(running_mean), _ptr(efe), _ptr(info),
+                             decp, C.byref(epi) if epi is not None else None, B, _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(running_mean), _ptr(efe), _ptr(info),
                              C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_efe_step")
     return efe, info
 
@@ -629,3 +637,34 @@ def encoder_backward(enc: AidEncoderNet, grads: AidEncoderNet, d_features, saved
     check(lib().aid_encoder_backward(C.byref(enc), C.byref(grads), B, _ptr(d_features.contiguous()), _ptr(drop2d_1), _ptr(drop2d_2), _ptr(drop_out),
                                      int(bool(train)), C.c_void_p(saved.data_ptr()), C.c_size_t(saved.numel()), C.c_void_p(buf.data_ptr()),
                                      C.c_size_t(buf.numel()), _stream()), "aid_encoder_backward")
+
+
+def feature_decoder_step(fd: AidFeatureDecoder, fgrads: AidFeatureDecoder, latents, target, drop_mask, d_target, ws: Workspace = None):
+    """recon = mse(feature_decoder(latents), target): param grads -> fgrads, d(recon)/d(target) accumulated into d_target. -> recon (device [1])"""
+    B = latents.shape[0]
+    loss = torch.zeros(1, device=latents.device)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_small_net_workspace(B, fd.l0.out))
+    check(lib().aid_feature_decoder_step(C.byref(fd), C.byref(fgrads), B, _ptr(latents), _ptr(target), _ptr(drop_mask), _ptr(d_target), _ptr(loss),
+                                         C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_feature_decoder_step")
+    return loss
+
+
+def infonce_step(dyn: AidDynamicsNet, latents, actions, next_enc, weight, d_next_enc, ws: Workspace = None):
+    B = latents.shape[0]
+    loss = torch.zeros(1, device=latents.device)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_small_net_workspace(B, dyn.D) + 16 * B * B)
+    check(lib().aid_infonce_step(C.byref(dyn), B, _ptr(latents), _ptr(actions), _ptr(next_enc), C.c_float(weight), _ptr(d_next_enc), _ptr(loss),
+                                 C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_infonce_step")
+    return loss
+
+
+def grad_sumsq(g, scratch):
+    check(lib().aid_grad_sumsq(_ptr(g), C.c_size_t(g.numel()), _ptr(scratch), _stream()), "aid_grad_sumsq")
+
+
+def adamw_step_ext(p, g, m, v, ema, lr, weight_decay, step, clip_norm, scratch, ext_sumsq, beta1=0.9, beta2=0.999, eps=1e-8, ema_decay=0.9999):
+    check(lib().aid_adamw_step_ext(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay),
+                                   C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), C.c_float(ema_decay),
+                                   _ptr(scratch), _ptr(ext_sumsq), _stream()), "aid_adamw_step_ext")

@@ -1,0 +1,247 @@
+"""DiffusionPixelAgent (active_inference_diffusion/agents/pixel_agent.py:19-470): DrQ-v2 encoder -> features -> the same
+diffusion active-inference core with observation_dim = latent_dim.  Same constructor, `act`, `encode_observation`,
+`train_step`, `compute_representation_loss`, optimiser attributes and metric keys as the reference.
+
+Not built: the ConvDecoder and the pixel branch of the epistemic estimator.  The epistemic term is
+computed under no_grad in the reference, so skipping it changes no parameter update; it removes the `epistemic/*`
+diagnostics and the (weight 0.1) epistemic contribution to the logged `policy_loss`."""
+from __future__ import annotations
+
+from typing import Any, Dict, Tuple
+
+import numpy as np
+import torch
+
+from .. import _native as nat
+from .. import parallel
+from ..arena import ArenaOptimizer, ParamArena
+from ..configs.config import PixelObservationConfig
+from ..core.active_inference import DiffusionActiveInference
+from ..encoder.visual_encoders import DrQV2Encoder, RandomShiftAugmentation
+from ..utils.buffers import ReplayBuffer
+from .base_agent import BaseActiveInferenceAgent
+
+
+class _PixelScoreOptimizer:
+    """The reference's single AdamW over score net + diffusion + encoder + feature decoder (pixel_agent.py:441-449) with
+    its clip over the first three only (:325-331): three arenas, one shared squared-norm."""
+
+    def __init__(self, score: ParamArena, encoder: ParamArena, fdec: ParamArena, lr: float, clip: float):
+        self.score, self.encoder, self.fdec, self.clip = score, encoder, fdec, clip
+        self.param_groups = [{"lr": lr, "weight_decay": 1e-5, "betas": (0.9, 0.999), "eps": 1e-8}]
+        self._pending = None
+
+    def zero_grad(self, set_to_none: bool = False):
+        for a in (self.score, self.encoder, self.fdec):
+            a.zero_grad()
+
+    def allreduce_grads(self, async_op: bool = False):
+        self._pending = [parallel.allreduce_mean_(a.grad, async_op=async_op) for a in (self.score, self.encoder, self.fdec)]
+
+    def step(self):
+        if self._pending is not None:
+            for h in self._pending:
+                if h is not None:
+                    h.wait()
+            self._pending = None
+        else:
+            for a in (self.score, self.encoder, self.fdec):
+                parallel.allreduce_mean_(a.grad)
+        g = self.param_groups[0]
+        ss, se = self.score.grad_sumsq().clone(), self.encoder.grad_sumsq().clone()
+        self.score.step(g["lr"], g["weight_decay"], self.clip, 0.9999, ext_sumsq=se)
+        self.encoder.step(g["lr"], g["weight_decay"], self.clip, ext_sumsq=ss)
+        self.fdec.step(g["lr"], g["weight_decay"], 3.0e38)       # in the optimiser, outside the clipped set
+
+    def state_dict(self):
+        return {"score": self.score.state_dict(), "encoder": self.encoder.state_dict(), "feature_decoder": self.fdec.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.score.load_state_dict(sd["score"]); self.encoder.load_state_dict(sd["encoder"]); self.fdec.load_state_dict(sd["feature_decoder"])
+
+
+class DiffusionPixelAgent(BaseActiveInferenceAgent):
+    def __init__(self, env, config, training_config, pixel_config: PixelObservationConfig):
+        self.pixel_config = pixel_config
+        self.frame_stack = 1
+        super().__init__(env, config, training_config)
+
+    def _setup_dimensions(self):
+        self.obs_space, self.action_space = self.env.observation_space, self.env.action_space
+        shape = getattr(self.obs_space, "shape", None)
+        if shape is None:
+            raise ValueError(f"Unsupported observation space: {type(self.obs_space)}")
+        if len(shape) == 3:      # (C, H, W), or (H, W, C) when the last axis looks like channels
+            self.obs_shape = (shape[-1], shape[0], shape[1]) if shape[-1] in (1, 3) else tuple(shape)
+        elif len(shape) == 4:
+            self.frame_stack, self.obs_shape = shape[0], tuple(shape[1:])
+        else:
+            raise ValueError(f"Unexpected observation shape: {shape}")
+        if getattr(self.action_space, "shape", None) is None:
+            raise ValueError(f"Unsupported action space: {type(self.action_space)}")
+        self.action_dim = self.action_space.shape[0]
+        self.config.action_dim = self.action_dim
+        self.config.observation_dim = self.config.latent_dim
+
+    def _build_models(self):
+        pc = self.pixel_config
+        self.encoder = DrQV2Encoder(obs_shape=self.obs_shape, feature_dim=self.config.latent_dim, frame_stack=pc.frame_stack, num_layers=4, num_filters=32)
+        self.augmentation = RandomShiftAugmentation(pad=pc.random_shift_pad) if pc.augmentation else None
+        self.active_inference = DiffusionActiveInference(observation_dim=self.config.observation_dim, action_dim=self.action_dim,
+                                                         latent_dim=self.config.latent_dim, config=self.config, pixel_shape=self.obs_shape)
+        self.encoder.to(self.device)
+        self.encoder_arena = ParamArena([("encoder." + n, p) for n, p in self.encoder.trained_parameters()], self.device)
+        self.encoder.rng_seed = self.active_inference.noise.seed ^ 0x5EED
+
+    def _setup_optimizers(self):
+        a, lr, clip = self.active_inference.arenas, self.config.learning_rate, self.config.gradient_clip
+        self.score_optimizer = _PixelScoreOptimizer(a["score"], self.encoder_arena, a["feature_decoder"], lr, clip)
+        self.policy_optimizer = ArenaOptimizer(a["policy"], lr, 1e-5, clip)
+        self.value_optimizer = ArenaOptimizer(a["value"], lr, 1e-2, clip)
+        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip)
+
+    def _create_replay_buffer(self) -> ReplayBuffer:
+        shape = (self.frame_stack, *self.obs_shape) if self.frame_stack > 1 else self.obs_shape
+        return ReplayBuffer(capacity=self.training_config.buffer_size, obs_shape=shape, action_dim=self.action_dim, device=self.device, optimize_memory=True)
+
+    def enable_data_parallel(self):
+        for a in (*self.active_inference.arenas.values(), self.encoder_arena):
+            parallel.broadcast_arena_(a.flat)
+        for b in self.encoder.buffers():
+            parallel.broadcast_arena_(b)
+        self.active_inference.arenas["score"].reset_ema()
+        self.active_inference.noise.seed += 7919 * parallel.rank()
+        self.encoder.rng_seed += 7919 * parallel.rank()
+
+    # -------------------------------------------------------------------------------------------------- observation plumbing
+    def _process_observation(self, observation) -> torch.Tensor:
+        a = observation.detach().cpu().numpy() if torch.is_tensor(observation) else np.array(observation)
+        if a.ndim == 2:
+            a = a[None]
+        elif a.ndim == 3 and a.shape[-1] in (1, 3):
+            a = a.transpose(2, 0, 1)
+        elif a.ndim == 4 and a.shape[-1] in (1, 3):
+            a = a.transpose(0, 3, 1, 2)
+        elif a.ndim not in (3, 4):
+            raise ValueError(f"Unexpected observation shape: {a.shape}")
+        was_u8 = a.dtype == np.uint8
+        t = torch.as_tensor(a.astype(np.float32))
+        if t.dim() == 3 or (t.dim() == 4 and t.shape[0] == self.frame_stack):
+            t = t.unsqueeze(0)
+        if was_u8 or float(t.max()) > 1.0:
+            t = t / 255.0
+        return t
+
+    def _process_batch_observations(self, observations: torch.Tensor) -> torch.Tensor:
+        observations = observations.to(self.device)
+        if observations.dtype == torch.uint8:
+            observations = observations.float() / 255.0
+        if observations.dim() == 5:
+            b, fs, c, h, w = observations.shape
+            observations = observations.reshape(b, fs * c, h, w)
+        return observations
+
+    def _encoder_noise(self, B: int):
+        """Per-pass randomness: crop offsets of RandomShiftAugmentation (fused into the first conv's gather) + dropout masks."""
+        hook = getattr(self.active_inference.noise, "encoder", None)
+        n = hook(B, self.config.latent_dim, self.pixel_config.random_shift_pad) if hook is not None else None
+        if n is None:
+            n = {}
+            if self.augmentation is not None and self.training:
+                n["shift_h"], n["shift_w"] = self.augmentation.sample_shifts(B, self.device)
+        if self.augmentation is None or not self.training:
+            n.pop("shift_h", None); n.pop("shift_w", None)
+        n["pad"] = self.pixel_config.random_shift_pad
+        return n
+
+    def encode_observation(self, observation: torch.Tensor, keep_for_backward: bool = False, slot: str = "a"):
+        """pixels -> (augmentation, train mode only) -> DrQ-v2 features [B, latent_dim]   (pixel_agent.py:163-201)"""
+        if observation.dim() == 3:
+            observation = observation.unsqueeze(0)
+        elif observation.dim() not in (4, 5):
+            raise ValueError(f"Unexpected observation shape: {observation.shape}")
+        observation = self._process_batch_observations(observation)
+        return self.encoder(observation, self._encoder_noise(observation.shape[0]), keep_for_backward=keep_for_backward, slot=slot)
+
+    def act(self, observation: np.ndarray, deterministic: bool = False) -> Tuple[np.ndarray, Dict[str, Any]]:
+        enc = self.encode_observation(self._process_observation(observation).to(self.device))
+        action_t, info = self.active_inference.act(enc, deterministic=deterministic)
+        action = action_t.cpu().numpy().reshape(-1)
+        if not deterministic and self.training and self.exploration_noise > 0:
+            action = np.clip(action + np.random.normal(0, self.exploration_noise, size=action.shape), -1, 1)
+        info["encoded_obs_norm"] = float(enc.norm())
+        return action, info
+
+    def compute_representation_loss(self, obs, next_obs, actions, latents, next_latents, d_next_obs: torch.Tensor = None, weight: float = 1.0):
+        """InfoNCE between the dynamics model's predicted next latent and the encoded next observation (pixel_agent.py:413-437).
+        With d_next_obs, weight * d(loss)/d(next_obs) is accumulated into it; latent_dynamics gradients are not produced (the
+        reference zeroes them before they are ever used, :396)."""
+        ai = self.active_inference
+        if d_next_obs is None:
+            d_next_obs = torch.zeros_like(next_obs)
+        return nat.infonce_step(ai.latent_dynamics.table(), latents, actions.contiguous().float(), next_obs.contiguous(), weight, d_next_obs, ai._ws)[0]
+
+    # --------------------------------------------------------------------------------------------------
+    def train_step(self) -> Dict[str, float]:
+        """pixel_agent.py:274-411.  encode(obs), encode(next_obs) [two spectral-norm power iterations, as in the reference] ->
+        belief latents for both (one merged 2B-row reverse-diffusion loop) -> ELBO (+ feature-decoder reconstruction) and
+        InfoNCE, whose feature gradients drive the two encoder backward passes -> policy / value / dynamics phases."""
+        cfg, ai = self.config, self.active_inference
+        B = cfg.batch_size
+        if len(self.replay_buffer) < B:
+            return {}
+        batch = self.replay_buffer.sample(B)
+        actions, rewards, dones = batch["actions"], batch["rewards"], batch["dones"]
+        enc_obs, ctx_a = self.encode_observation(batch["observations"], keep_for_backward=True, slot="a")
+        enc_next, ctx_b = self.encode_observation(batch["next_observations"], keep_for_backward=True, slot="b")
+        dp = parallel.is_dp()
+        nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
+        both = ai.denoise_pair(enc_obs, enc_next)
+        latents, next_latents = both[:B], both[B:]
+        # score / diffusion / encoder / feature-decoder group
+        self.score_optimizer.zero_grad()
+        elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents)
+        d_next = torch.zeros_like(enc_next)
+        contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
+        self.encoder.backward(ai._last_d_obs, ctx_a)
+        self.encoder.backward(d_next, ctx_b)
+        if dp:
+            comm = self._comm_stream()
+            comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm):
+                self.score_optimizer.allreduce_grads(async_op=True)
+        else:
+            self.score_optimizer.step()
+        # policy
+        self.policy_optimizer.zero_grad()
+        efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
+        self.policy_optimizer.step()
+        if dp:
+            torch.cuda.current_stream().wait_stream(self._comm_stream())
+            self.score_optimizer.step()
+        # value (the pixel agent reuses next_latents, pixel_agent.py:364-371) and dynamics
+        self.value_optimizer.zero_grad()
+        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
+                                       cfg.discount_factor, 0.95, 5, ws=ai._ws)
+        self.value_optimizer.step()
+        self.dynamics_optimizer.zero_grad()
+        dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
+        self.dynamics_optimizer.step()
+        self.total_steps += 1
+        keys, vals = [], []
+        for k, v in {**elbo_info, "contrastive_loss": contrastive, "policy_loss": efe_info.pop("policy_loss"), **efe_info, "value_loss": value_loss,
+                     "dynamics_loss": dyn_loss}.items():
+            if torch.is_tensor(v):
+                keys.append(k); vals.append(v.reshape(1))
+        metrics = dict(zip(keys, torch.cat(vals).cpu().tolist()))
+        metrics.update({"num_trajectories": efe_info["num_trajectories"], "horizon": efe_info["horizon"]})
+        self._last = {"latents": latents, "next_latents": next_latents, "encoded_obs": enc_obs, "encoded_next_obs": enc_next}
+        return metrics
+
+    def _comm_stream(self):
+        if getattr(self, "_comm", None) is None:
+            self._comm = torch.cuda.Stream(device=self.device)
+        return self._comm
+
+
+PixelBasedAgent = DiffusionPixelAgent

@@ -73,10 +73,20 @@ class ParamArena:
             p.grad = self.grad[o:o + p.numel()].view(shp)
 
     # -- fused clip -> AdamW -> EMA -----------------------------------------------------------------
-    def step(self, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999):
+    def step(self, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999, ext_sumsq: torch.Tensor = None):
+        """ext_sumsq: device scalar = sum of squared gradients of the OTHER arenas clipped together with this one."""
         self.step_count += 1
-        nat.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.ema, lr, weight_decay, self.step_count, clip_norm,
-                       self._scratch, ema_decay=ema_decay)
+        if ext_sumsq is not None:
+            nat.adamw_step_ext(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.ema, lr, weight_decay, self.step_count, clip_norm,
+                               self._scratch, ext_sumsq, ema_decay=ema_decay)
+        else:
+            nat.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.ema, lr, weight_decay, self.step_count, clip_norm,
+                           self._scratch, ema_decay=ema_decay)
+
+    def grad_sumsq(self) -> torch.Tensor:
+        """Device scalar (view of scratch[2]): sum of squares of this arena's gradients."""
+        nat.grad_sumsq(self.grad, self._scratch)
+        return self._scratch[2:3]
 
     def grad_norm(self) -> torch.Tensor:
         """Device scalar: the global L2 norm measured by the last step()."""

@@ -111,7 +111,13 @@ class DiffusionActiveInference(nn.Module):
         self.value_network = ValueNetwork(state_dim=L, hidden_dim=D, time_embed_dim=128, num_layers=3)
         self.latent_dynamics = LatentDynamicsModel(state_dim=L, action_dim=self.action_dim, hidden_dim=D, num_layers=3)
         if self.is_pixel_observation:
-            raise NotImplementedError("pixel-mode DiffusionActiveInference (ConvDecoder, feature_decoder) lands with the DrQ-v2 encoder path")
+            # Pixel mode (active_inference.py:133-149): observations are the DrQ-v2 features, reconstructed by `feature_decoder`.
+            # The ConvDecoder / pixel branch of the epistemic estimator is SURVEY §8(f) rank 1 (not built): the gradient-free
+            # epistemic term is skipped, which leaves every parameter update unchanged (it only feeds logged diagnostics).
+            self.feature_decoder = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Dropout(self.epistemic_dropout_rate),
+                                                 nn.Linear(D, L), nn.Tanh())
+            self.reward_predictor = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Linear(D, D // 2), nn.ReLU(), nn.Linear(D // 2, 2))
+            return
         p = self.epistemic_dropout_rate
         stage = lambda i, o: nn.Sequential(nn.Linear(i, o), nn.LayerNorm(o), nn.SiLU(), nn.Dropout(p))
         self.observation_decoder = nn.ModuleList([stage(L, 2 * D), stage(2 * D, 2 * D), stage(2 * D, D), nn.Linear(D, self.observation_dim)])
@@ -133,15 +139,20 @@ class DiffusionActiveInference(nn.Module):
             "value": ParamArena([("value_network." + n, p) for n, p in self.value_network.named_parameters()], device),
             "dynamics": ParamArena([("latent_dynamics." + n, p) for n, p in self.latent_dynamics.named_parameters()], device),
         }
-        frozen = [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
-        frozen += [("reward_predictor." + n, p) for n, p in self.reward_predictor.named_parameters()]
-        frozen += [("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters() if not n.startswith("decoder.")]
-        self.arenas["frozen"] = ParamArena(frozen, device)   # never stepped (SURVEY D3/D11); an arena only for alignment + one-shot zeroing
-        self._dec_tab = TableCache(lambda: nat.decoder_table(params_dict(self.observation_decoder), ""))
+        frozen = [("reward_predictor." + n, p) for n, p in self.reward_predictor.named_parameters()]
         self._rew_tab = TableCache(lambda: nat.reward_table(params_dict(self.reward_predictor), ""))
-        self._epi_tab = TableCache(lambda: nat.epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
-                                                                 if not n.startswith("decoder.")}, ""))
-        self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
+        if self.is_pixel_observation:
+            self.arenas["feature_decoder"] = ParamArena([("feature_decoder." + n, p) for n, p in self.feature_decoder.named_parameters()], device)
+            self._fd_tab = TableCache(lambda: self._fd_table(False)); self._fd_gtab = TableCache(lambda: self._fd_table(True))
+            self._running_mean = torch.zeros(1, device=device)
+        else:
+            frozen += [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
+            frozen += [("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters() if not n.startswith("decoder.")]
+            self._dec_tab = TableCache(lambda: nat.decoder_table(params_dict(self.observation_decoder), ""))
+            self._epi_tab = TableCache(lambda: nat.epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
+                                                                     if not n.startswith("decoder.")}, ""))
+            self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
+        self.arenas["frozen"] = ParamArena(frozen, device)   # never stepped (SURVEY D3/D11); an arena only for alignment + one-shot zeroing
         self.device = torch.device(device)
 
     def to(self, device, *a, **k):
@@ -152,13 +163,20 @@ class DiffusionActiveInference(nn.Module):
             self._to_device_and_flatten(device)
         return self
 
+    def _fd_table(self, grads: bool):
+        d = params_dict(self.feature_decoder, grads)
+        t = nat.AidFeatureDecoder(); t.l0 = nat._lin(d, "0"); t.ln = nat._ln(d, "1"); t.l4 = nat._lin(d, "4")
+        return t
+
     def state_dict(self, *a, **k):
-        self.epistemic_estimator.running_mean = self._running_mean.reshape(()).clone()
+        if not self.is_pixel_observation:
+            self.epistemic_estimator.running_mean = self._running_mean.reshape(()).clone()
         return super().state_dict(*a, **k)
 
     def load_state_dict(self, sd, strict: bool = True):
         out = super().load_state_dict(sd, strict=strict)
-        self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
+        if not self.is_pixel_observation:
+            self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
         self.arenas["score"].reset_ema()
         self.latent_diffusion._coefs = None
         return out
@@ -198,6 +216,12 @@ class DiffusionActiveInference(nn.Module):
         train = self.latent_score_network.training
         if noise is None:
             noise = self.noise.belief(B, L, self.config.hidden_dim, N, train) or {}
+        if self.is_pixel_observation:   # diagnostics through the feature decoder are not computed on this path
+            latent = self.denoise_only(observation, noise)
+            self.current_latent, self.latent_trajectory = latent, [latent]
+            return {"latent": latent, "latent_mean": latent.mean(0), "latent_std": latent.std(0) if B > 1 else torch.zeros_like(latent[0]),
+                    "trajectory_length": N + 1, "reconstruction_error": torch.zeros((), device=self.device), "observation": observation,
+                    "raw_observation": raw_observation}
         latent, stats = nat.belief_update(self.latent_score_network.table(), self.decoder_table(), self.latent_diffusion.coefs(), observation, N,
                                           noise.get("z_init"), noise.get("step_noise"), noise.get("drop_masks"), noise.get("dec_masks"),
                                           train=train, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
@@ -240,12 +264,14 @@ class DiffusionActiveInference(nn.Module):
         c = self.config
         if noise is None:
             noise = self.noise.efe(latent.shape[0], self.latent_dim, self.action_dim, horizon, num_trajectories, num_ambiguity_samples)
+        pix = self.is_pixel_observation
         efe, info = nat.efe_step(self.policy_network.table(), self.policy_network.grad_table() if backward else None, self.latent_dynamics.table(),
-                                 self.reward_table(), self.value_network.table(), self.decoder_table(), self.epistemic_table(), latent,
+                                 self.reward_table(), self.value_network.table(), None if pix else self.decoder_table(),
+                                 None if pix else self.epistemic_table(), latent,
                                  self._running_mean, horizon, num_trajectories, num_ambiguity_samples, noise=noise,
-                                 train=self.epistemic_estimator.training, epistemic_weight=c.epistemic_weight, pragmatic_weight=c.pragmatic_weight,
+                                 train=self.training, skip_epistemic=pix, epistemic_weight=c.epistemic_weight, pragmatic_weight=c.pragmatic_weight,
                                  consistency_weight=c.consistency_weight, discount=c.discount_factor, temperature=float(c.preference_temperature),
-                                 mine_alpha=self.epistemic_estimator.alpha, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+                                 mine_alpha=0.01, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
         out = {k: info[i] for i, k in enumerate(nat.EFE_INFO) if k != "policy_loss"}
         out.update({"num_trajectories": num_trajectories, "horizon": horizon, "epistemic/running_mean": self._running_mean[0],
                     "policy_loss": info[0]})
@@ -284,9 +310,22 @@ class DiffusionActiveInference(nn.Module):
         c, B = self.config, observations.shape[0]
         if noise is None:
             noise = self.noise.elbo(B, self.latent_dim, c.hidden_dim, first, self.time_importance_weights)
+        d_obs = None
+        preset = None
+        if self.is_pixel_observation:   # reconstruction through the feature decoder (gradients to it and to the encoder features)
+            d_obs = torch.zeros_like(observations)
+            fd_mask = (noise or {}).get("fd_mask")
+            if fd_mask is None and self.feature_decoder.training:
+                fd_mask = torch.empty(B, c.hidden_dim, device=self.device)
+                nat.fill_dropout_mask(fd_mask, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(fd_mask.numel()))
+            preset = nat.feature_decoder_step(self._fd_tab.get(self.feature_decoder), self._fd_gtab.get(self.feature_decoder), latents, observations,
+                                              fd_mask if self.feature_decoder.training else None, d_obs, self._ws)
+            noise = dict(noise or {}); noise["d_obs_out"] = d_obs
+        self._last_d_obs = d_obs
         metrics, t, per = nat.elbo_step(self.latent_score_network.table(), self.latent_score_network.grad_table(), self.latent_diffusion.table(),
-                                        self.latent_diffusion.grad_table(), self.decoder_table(), self.reward_table(), observations, rewards, latents,
-                                        self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training,
+                                        self.latent_diffusion.grad_table(), None if self.is_pixel_observation else self.decoder_table(),
+                                        self.reward_table(), observations, rewards, latents,
+                                        self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training, recon_preset=preset,
                                         kl_weight=c.kl_weight, diffusion_weight=c.diffusion_weight, reward_weight=c.reward_weight, gp_weight=0.1,
                                         seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws,
                                         defer_time_importance=parallel.is_dp())

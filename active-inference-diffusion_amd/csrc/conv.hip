@@ -519,3 +519,124 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// pixel-mode training pieces: feature decoder reconstruction, InfoNCE, stand-alone random shift
+namespace aid {
+__global__ void random_shift_nchw_kernel(const float* __restrict__ x, const int32_t* __restrict__ sh, const int32_t* __restrict__ sw, int pad,
+                                         float* __restrict__ out, int B, int C, int H, int W) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * C * H * W) return;
+    const int w = i % W, h = (i / W) % H; const size_t bc = i / ((size_t)W * H); const int b = bc / C;
+    out[i] = x[(bc * H + reflect_idx(h + sh[b] - pad, H)) * W + reflect_idx(w + sw[b] - pad, W)];
+}
+// pred = tanh(lin); loss = mean (pred - t)^2 ; dlin = 2 (pred - t)/(n) * (1 - pred^2) ; d_target += -2 (pred - t)/n
+__global__ void fd_loss_kernel(const float* __restrict__ lin, const float* __restrict__ t, float* __restrict__ dlin, float* __restrict__ dt,
+                               float* __restrict__ loss, int n) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float p = tanhf(lin[i]), d = p - t[i];
+        acc += d * d;
+        const float g = 2.f * d / (float)n;
+        dlin[i] = g * (1.f - p * p);
+        if (dt) dt[i] -= g;
+    }
+    const float s = wg_sum256(acc, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)n;
+}
+// rows normalised: out = x / max(||x||, 1e-12) ; norms saved
+__global__ void row_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, float* __restrict__ nrm, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int l = 0; l < L; ++l) s += x[(size_t)b * L + l] * x[(size_t)b * L + l];
+    const float n = fmaxf(sqrtf(s), 1e-12f);
+    nrm[b] = n;
+    for (int l = 0; l < L; ++l) out[(size_t)b * L + l] = x[(size_t)b * L + l] / n;
+}
+// cross entropy over rows of logits [B,B] against the diagonal; dlogits = (softmax - onehot)/B
+__global__ void ce_diag_kernel(const float* __restrict__ logits, float* __restrict__ dlogits, float* __restrict__ loss, int B) {
+    __shared__ float sh[16];
+    float acc = 0.f;
+    for (int r = threadIdx.x; r < B; r += blockDim.x) {
+        const float* lr = logits + (size_t)r * B;
+        float mx = lr[0];
+        for (int c = 1; c < B; ++c) mx = fmaxf(mx, lr[c]);
+        float se = 0.f;
+        for (int c = 0; c < B; ++c) se += expf(lr[c] - mx);
+        const float lse = mx + logf(se);
+        acc += lse - lr[r];
+        for (int c = 0; c < B; ++c) dlogits[(size_t)r * B + c] = (expf(lr[c] - lse) - (c == r ? 1.f : 0.f)) / (float)B;
+    }
+    const float s = wg_sum256(acc, sh);
+    if (threadIdx.x == 0) loss[0] = s / (float)B;
+}
+// d(x) of y = x/||x||:  (dy - y (dy.y)) / ||x|| ; accumulate weight * that
+__global__ void normalize_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, const float* __restrict__ nrm, float weight,
+                                     float* __restrict__ dx, int B, int L) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float dot = 0.f;
+    for (int l = 0; l < L; ++l) dot += dy[(size_t)b * L + l] * y[(size_t)b * L + l];
+    for (int l = 0; l < L; ++l) dx[(size_t)b * L + l] += weight * (dy[(size_t)b * L + l] - y[(size_t)b * L + l] * dot) / nrm[b];
+}
+}  // namespace aid
+
+extern "C" {
+
+int aid_random_shift(const float* x, const int32_t* shift_h, const int32_t* shift_w, int pad, int B, int C, int H, int W, float* out, void* stream) {
+    AID_REQUIRE(x && shift_h && shift_w && out, AID_E_NULL, "aid_random_shift: null tensor");
+    hipStream_t s = (hipStream_t)stream;
+    L1D(random_shift_nchw_kernel, (size_t)B * C * H * W, s, x, shift_h, shift_w, pad, out, B, C, H, W);
+    return AID_OK;
+}
+
+int aid_feature_decoder_step(const AidFeatureDecoder* fd, const AidFeatureDecoder* fgrads, int B, const float* latents, const float* target,
+                             const float* drop_mask, float* d_target, float* loss_out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(fd && fgrads && latents && target && loss_out, AID_E_NULL, "aid_feature_decoder_step: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const int L = fd->l0.in, D = fd->l0.out, Lo = fd->l4.out;
+    LlaSave s0; lla_alloc(B, D, ws, s0);
+    float* lin = ws.f32((size_t)B * Lo); float* dlin = ws.f32((size_t)B * Lo); float* dh = ws.f32((size_t)B * D);
+    AID_WS_OK(ws);
+    AID_TRY(lla_fwd(fd->l0, fd->ln, ACT_RELU, drop_mask, latents, L, B, s0, s));
+    AID_TRY(linear_fwd(s0.y, D, fd->l4.w, fd->l4.b, lin, Lo, B, Lo, D, ACT_NONE, s));
+    hipLaunchKernelGGL(fd_loss_kernel, dim3(1), dim3(1024), 0, s, lin, target, dlin, d_target, loss_out, B * Lo);
+    AID_LAUNCH_CHECK();
+    AID_TRY(linear_bwd_weight(dlin, Lo, s0.y, D, fgrads->l4.w, B, Lo, D, s, 1));
+    AID_TRY(colsum(dlin, Lo, fgrads->l4.b, B, Lo, 1, s, &ws));
+    AID_TRY(linear_bwd_data(dlin, Lo, fd->l4.w, D, dh, D, B, Lo, s));
+    AID_TRY(lla_bwd(fd->l0, fd->ln, &fgrads->l0, &fgrads->ln, ACT_RELU, drop_mask, latents, L, B, s0, dh, nullptr, 0, ws, s));
+    return AID_OK;
+}
+
+int aid_infonce_step(const AidDynamicsNet* dyn, int B, const float* latents, const float* actions, const float* next_enc, float weight,
+                     float* d_next_enc, float* loss_out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dyn && latents && actions && next_enc && d_next_enc && loss_out, AID_E_NULL, "aid_infonce_step: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const int L = dyn->L;
+    float* pred = ws.f32((size_t)B * L); float* pn = ws.f32((size_t)B * L); float* tn = ws.f32((size_t)B * L); float* n1 = ws.f32(B); float* n2 = ws.f32(B);
+    float* logits = ws.f32((size_t)B * B); float* dlog = ws.f32((size_t)B * B); float* dtn = ws.f32((size_t)B * L);
+    DynSave sv;
+    AID_TRY(dynamics_fwd(*dyn, B, latents, L, actions, dyn->A, pred, sv, ws, s));
+    L1D(row_normalize_kernel, B, s, pred, pn, n1, B, L);
+    L1D(row_normalize_kernel, B, s, next_enc, tn, n2, B, L);
+    const float scale = (1.0f / 0.1f) * (1.0f / (1.0f + expf(0.5f * logf(0.1f))));     // 1/temperature * 1/(1 + mean std), std = sqrt(0.1)
+    {   // logits = pn tn^T * scale
+        GemmArgs g = gemm_args(pn, L, tn, L, logits, B, B, B, L); g.alpha = scale;
+        AID_TRY(gemm_f32(g, s));
+    }
+    hipLaunchKernelGGL(ce_diag_kernel, dim3(1), dim3(1024), 0, s, logits, dlog, loss_out, B);
+    AID_LAUNCH_CHECK();
+    {   // dtn[j,:] = scale * sum_i dlog[i,j] pn[i,:]   (A = dlog stored [K=i][M=j] -> k-major; B = pn stored [K=i][N=l] -> k-major)
+        GemmArgs g = gemm_args(dlog, B, pn, L, dtn, L, B, L, B); g.a_kmajor = 1; g.b_kmajor = 1; g.alpha = scale;
+        AID_TRY(gemm_f32(g, s));
+    }
+    L1D(normalize_bwd_kernel, B, s, dtn, tn, n2, weight, d_next_enc, B, L);
+    return AID_OK;
+}
+
+}  // extern "C"

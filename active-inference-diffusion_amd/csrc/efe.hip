@@ -235,9 +235,9 @@ using namespace aid;
 extern "C" {
 
 size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg) {
-    if (!pol || !dec || !cfg || B <= 0) return 0;
+    if (!pol || !cfg || B <= 0 || (!dec && !cfg->skip_epistemic)) return 0;
     const size_t M = (size_t)cfg->K * B, R = M * cfg->S, D = pol->D, H = cfg->H;
-    size_t n = mine_ws_bytes(*dec, cfg->K, cfg->S, B);
+    size_t n = dec ? mine_ws_bytes(*dec, cfg->K, cfg->S, B) : 0;
     n += sizeof(float) * H * M * (40 * D + 64);                       // per-step saved activations (policy, dynamics, reward, value)
     n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
     n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
@@ -249,8 +249,9 @@ int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidD
                  const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
                  const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, void* wsp,
                  size_t ws_bytes, void* stream) {
-    AID_REQUIRE(pol && dyn && rew && val && dec && epi && latents && noise && cfg && running_mean && efe_out && info, AID_E_NULL,
+    AID_REQUIRE(pol && dyn && rew && val && latents && noise && cfg && running_mean && efe_out && info, AID_E_NULL,
                 "aid_efe_step: null argument");
+    AID_REQUIRE(cfg->skip_epistemic || (dec && epi), AID_E_NULL, "aid_efe_step: decoder / estimator tables are required unless skip_epistemic");
     const int H = cfg->H, K = cfg->K, S = cfg->S, L = pol->L, A = pol->A;
     AID_REQUIRE(B > 0 && H > 0 && K > 0 && S > 0 && B <= 2048, AID_E_SHAPE, "aid_efe_step: B=%d H=%d K=%d S=%d", B, H, K, S);
     hipStream_t s = (hipStream_t)stream;

@@ -196,13 +196,14 @@ __global__ void sumsq_partial_kernel(const float* __restrict__ g, size_t n, floa
     const float s = blk_sum(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
-__global__ void finalize_norm_kernel(const float* __restrict__ partial, int nb, float clip, float* __restrict__ out) {
+__global__ void finalize_norm_kernel(const float* __restrict__ partial, int nb, float clip, float* __restrict__ out, const float* __restrict__ ext) {
     __shared__ float sh[16];
     float acc = 0.f;
     for (int i = threadIdx.x; i < nb; i += blockDim.x) acc += partial[i];
     const float s = blk_sum(acc, sh);
     if (threadIdx.x == 0) {
-        const float nrm = sqrtf(s);
+        out[2] = s;                                       // this arena's own sum of squares
+        const float nrm = sqrtf(s + (ext ? ext[0] : 0.f));   // + the other arenas of the same clip group (pixel mode: score + encoder)
         out[0] = nrm;
         out[1] = clip > 0.f ? fminf(clip / (nrm + 1e-6f), 1.0f) : 1.0f;   // torch clip_grad_norm_
     }
@@ -231,8 +232,25 @@ using namespace aid;
 
 extern "C" {
 
+int aid_grad_sumsq(const float* g, size_t n, float* scratch, void* stream) {
+    AID_REQUIRE(g && scratch, AID_E_NULL, "aid_grad_sumsq: null");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((n + 255) / 256 > OPT_BLOCKS ? OPT_BLOCKS : (n + 255) / 256);
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, scratch + 8);
+    hipLaunchKernelGGL(finalize_norm_kernel, dim3(1), dim3(1024), 0, s, scratch + 8, nb, 0.f, scratch, (const float*)nullptr);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
+                       float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq, void* stream);
+
 int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
                    float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, void* stream) {
+    return aid_adamw_step_ext(p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, step, clip_norm, ema_decay, scratch, nullptr, stream);
+}
+
+int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
+                       float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq, void* stream) {
     AID_REQUIRE(p && g && m && v && scratch, AID_E_NULL, "aid_adamw_step: null arena");
     AID_REQUIRE(step >= 1, AID_E_SHAPE, "aid_adamw_step: step must be 1-based");
     hipStream_t s = (hipStream_t)stream;
@@ -240,7 +258,7 @@ int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, siz
     ProfScope prof(PROF_OPTIM, s, 0.0, (double)n * 4.0 * (ema ? 10.0 : 8.0));
     const int nb = (int)((n + 255) / 256 > OPT_BLOCKS ? OPT_BLOCKS : (n + 255) / 256);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, scratch + 8);
-    hipLaunchKernelGGL(finalize_norm_kernel, dim3(1), dim3(1024), 0, s, scratch + 8, nb, clip_norm, scratch);
+    hipLaunchKernelGGL(finalize_norm_kernel, dim3(1), dim3(1024), 0, s, scratch + 8, nb, clip_norm, scratch, ext_sumsq);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const int ub = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(adamw_kernel, dim3(ub), dim3(256), 0, s, p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, (float)bc1,
@@ -303,11 +321,11 @@ int aid_belief_update(const AidScoreNet* net, const AidDecoderNet* dec, int B, i
 }
 
 size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B) {
-    if (!net || !dec || B <= 0) return 0;
+    if (!net || B <= 0) return 0;
     const size_t D = net->D, L = net->L;
     size_t n = 2 * score_acts_bytes(*net, B, true) + score_tan_bytes(*net, B) + score_reverse_ws_bytes(*net, B) +
-               score_cond_backward_ws_bytes(*net, B) + decoder_ws_bytes(*dec, B);
-    n += sizeof(float) * (size_t)B * ((size_t)(2 * net->n_blocks + 1) * 2 * D + 12 * L + 2 * D + dec->O + 2 * dec->s[0].out + dec->s[2].out + 3 * D + 64);
+               score_cond_backward_ws_bytes(*net, B) + (dec ? decoder_ws_bytes(*dec, B) : 0);
+    n += sizeof(float) * (size_t)B * ((size_t)(2 * net->n_blocks + 1) * 2 * D + 12 * L + 2 * D + (dec ? dec->O + 2 * dec->s[0].out + dec->s[2].out : net->O) + 8 * D + 64);
     return n + (1 << 16);
 }
 
@@ -316,12 +334,13 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
                   const AidElboNoise* noise, const AidElboCfg* cfg, float* time_importance, float* t_out, float* per_sample_out,
                   float* metrics, void* wsp, size_t ws_bytes, void* stream) {
     AID_TRY(score_validate(net)); AID_TRY(score_validate(grads));
-    AID_REQUIRE(dp && dgrads && dec && rew && obs && rewards && latents && noise && cfg && time_importance && metrics, AID_E_NULL,
+    AID_REQUIRE(dp && dgrads && rew && obs && rewards && latents && noise && cfg && time_importance && metrics, AID_E_NULL,
                 "aid_elbo_step: null argument");
+    float* d_obs = noise->d_obs_out;   // optional [B,O]: accumulates d(loss)/d(observations) (pixel mode)
     AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_elbo_step: B=%d", B);
     hipStream_t s = (hipStream_t)stream;
     const AidScoreNet& n = *net;
-    const int D = n.D, L = n.L, O = dec->O, NA = 2 * n.n_blocks + 1, ldmod = NA * 2 * D;
+    const int D = n.D, L = n.L, O = dec ? dec->O : n.O, NA = 2 * n.n_blocks + 1, ldmod = NA * 2 * D;
     const bool train = cfg->train != 0;
     Workspace ws(wsp, ws_bytes);
     uint64_t ctr = cfg->offset;
@@ -332,7 +351,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     };
     // ---- noise (draw order of the reference: decoder masks, t, eps, score mask, GP mask, prior eps)
     const float* dmask[3] = {nullptr, nullptr, nullptr};
-    if (train) {
+    if (train && dec) {
         AID_TRY(draw(noise->dec_mask0, (size_t)B * dec->s[0].out, 2, 0.2f, &dmask[0]));
         AID_TRY(draw(noise->dec_mask1, (size_t)B * dec->s[1].out, 2, 0.2f, &dmask[1]));
         AID_TRY(draw(noise->dec_mask2, (size_t)B * dec->s[2].out, 2, 0.2f, &dmask[2]));
@@ -356,8 +375,10 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     AID_WS_OK(ws);
 
     // ---- reconstruction term (value only; decoder never trained in state mode)
-    AID_TRY(decoder_fwd(*dec, B, latents, L, train ? dmask : nullptr, rec, O, ws, s));
-    AID_TRY(mse_scalar(rec, O, obs, O, B, O, metrics + 0, s));
+    if (dec) {   // dec == NULL: the caller already stored the reconstruction term in metrics[0] (pixel mode: feature decoder)
+        AID_TRY(decoder_fwd(*dec, B, latents, L, train ? dmask : nullptr, rec, O, ws, s));
+        AID_TRY(mse_scalar(rec, O, obs, O, B, O, metrics + 0, s));
+    }
 
     // ---- main score-matching pass
     hipLaunchKernelGGL(elbo_prepare_kernel, dim3((B * L + 255) / 256), dim3(256), 0, s, latents, t, eps, dp->log_snr_min, dp->log_snr_max, zt, B, L);
@@ -376,7 +397,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     hipLaunchKernelGGL(mean_scalar_kernel, dim3(1), dim3(1024), 0, s, wts, B, metrics + 7);
     AID_LAUNCH_CHECK();
     AID_TRY(score_reverse(n, grads, B, am, nullptr, zt, nullptr, d_score, t, AID_T_CONTINUOUS, 0.f, dz, dmod, ws, s));
-    AID_TRY(score_cond_backward(n, *grads, B, am, dmod, obs, smask, t, AID_T_CONTINUOUS, ws, s));
+    AID_TRY(score_cond_backward(n, *grads, B, am, dmod, obs, smask, t, AID_T_CONTINUOUS, ws, s, d_obs));
     hipLaunchKernelGGL(elbo_lambda_grad_kernel, dim3(1), dim3(1024), 0, s, dlamA, dz, latents, eps, t, dp->log_snr_min, dp->log_snr_max,
                        dgrads->log_snr_min, dgrads->log_snr_max, B, L);
     AID_LAUNCH_CHECK();
@@ -393,7 +414,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     AID_TRY(gp_weights(gvec, wvec, metrics + 5, B, L, s));
     AID_TRY(score_tangent_forward(n, B, wvec, ag, tan, s));
     AID_TRY(score_reverse(n, grads, B, ag, &tan, zt, wvec, nullptr, t, AID_T_CONTINUOUS, -cfg->gp_weight, nullptr, dmod, ws, s));
-    AID_TRY(score_cond_backward(n, *grads, B, ag, dmod, obs, gmask, t, AID_T_CONTINUOUS, ws, s));
+    AID_TRY(score_cond_backward(n, *grads, B, ag, dmod, obs, gmask, t, AID_T_CONTINUOUS, ws, s, d_obs));
 
     // ---- prior / KL term, reward NLL, metrics, time-importance EMA
     hipLaunchKernelGGL(kl_prior_kernel, dim3(1), dim3(1024), 0, s, latents, peps, dp->prior_mean, dp->prior_log_std, t, cfg->kl_weight,

@@ -24,6 +24,6 @@ int score_reverse(const AidScoreNet& n, const AidScoreNet* gr, int B, const Scor
                   Workspace& ws, hipStream_t s);
 size_t score_cond_backward_ws_bytes(const AidScoreNet& n, int B);
 int score_cond_backward(const AidScoreNet& n, const AidScoreNet& gr, int B, const ScoreActs& a, const float* dmod, const float* obs,
-                        const float* drop_mask, const float* tvals, int t_mode, Workspace& ws, hipStream_t s);
+                        const float* drop_mask, const float* tvals, int t_mode, Workspace& ws, hipStream_t s, float* d_obs = nullptr);
 
 }  // namespace aid

@@ -125,7 +125,7 @@ int score_reverse(const AidScoreNet& n, const AidScoreNet* gr, int B, const Scor
 
 // backward of everything that produces the modulations: adaLN Linear stack, SiLU(cond), obs encoder, time embeddings
 int score_cond_backward(const AidScoreNet& n, const AidScoreNet& gr, int B, const ScoreActs& a, const float* dmod, const float* obs,
-                        const float* drop_mask, const float* tvals, int t_mode, Workspace& ws, hipStream_t s) {
+                        const float* drop_mask, const float* tvals, int t_mode, Workspace& ws, hipStream_t s, float* d_obs) {
     const int D = n.D, TE = n.TE, NA = n_ada(n), ldmod = NA * 2 * D;
     const size_t mark = ws.mark();
     float* dcond = ws.f32((size_t)B * D); float* d1 = ws.f32((size_t)B * D); float* d2 = ws.f32((size_t)B * D);
@@ -158,6 +158,7 @@ int score_cond_backward(const AidScoreNet& n, const AidScoreNet& gr, int B, cons
     AID_TRY(ln_bwd_rows(d2, D, a.o0, D, a.st_o0, n.oe1_g, n.oe1_b, ACT_SILU, drop_mask, d1, D, dyeff, B, D, s));
     AID_TRY(ln_param_grad(dyeff, a.o0, D, a.st_o0, gr.oe1_g, gr.oe1_b, B, D, s));
     AID_TRY(lin_rev(n.oe0_w, gr.oe0_w, gr.oe0_b, D, n.O, B, obs, n.O, nullptr, d1, nullptr, nullptr, nullptr, true, s));
+    if (d_obs) AID_TRY(linear_bwd_data(d1, D, n.oe0_w, n.O, d_obs, n.O, B, D, s, 1));   // pixel mode: the observation is the encoder output
     // ---- time embeddings (score_networks.py:119-141), dtemb = dcond
     if (t_mode != AID_T_DISCRETE) {
         AID_TRY(dot_accum(dcond, a.c2, (size_t)B * D, 1.f, gr.time_scale, s));

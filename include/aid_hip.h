@@ -187,6 +187,9 @@ int aid_belief_update(const AidScoreNet* net, const AidDecoderNet* dec, int B, i
  * 6 mean_time, 7 loss_weight_mean, 8 loss(=-elbo). */
 typedef struct AidElboNoise {
     const float *t, *eps, *prior_eps, *score_mask, *gp_mask, *dec_mask0, *dec_mask1, *dec_mask2;
+    float* d_obs_out;   /* optional OUTPUT [B,O]: accumulates d(loss)/d(observations) from the score net's obs encoder (main + GP pass);
+                           pixel mode, where the observations are the DrQ-v2 encoder's features.  With dec == NULL the reconstruction
+                           term is taken from metrics[0] as pre-set by the caller (aid_feature_decoder_step). */
 } AidElboNoise;
 typedef struct AidElboCfg {
     float kl_weight, diffusion_weight, reward_weight, gp_weight;
@@ -239,6 +242,30 @@ int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidD
                  const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
                  const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info,
                  void* ws, size_t ws_bytes, void* stream);
+
+/* sum of squares of a gradient arena -> scratch[2] (and its sqrt in scratch[0]); aid_adamw_step_ext adds *ext_sumsq to its own
+ * sum before clipping, so that several arenas are clipped by ONE global norm (pixel mode: score+diffusion and encoder arenas,
+ * aid/agents/pixel_agent.py:326-331). */
+int aid_grad_sumsq(const float* g, size_t n, float* scratch, void* stream);
+int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
+                       float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq,
+                       void* stream);
+
+/* ---- pixel mode (aid/agents/pixel_agent.py:273-437, aid/core/active_inference.py:142-149) --------------------------------------
+ * feature decoder Linear(L,D) LN ReLU Dropout(.2) Linear(D,L) Tanh: recon = mse(fd(latents), target); loss contribution +recon.
+ * Accumulates parameter gradients into fgrads and d(recon)/d(target) into d_target [B,L]; recon -> *loss_out (device). */
+typedef struct AidFeatureDecoder { AidLinear l0; AidLN ln; AidLinear l4; } AidFeatureDecoder;
+int aid_feature_decoder_step(const AidFeatureDecoder* fd, const AidFeatureDecoder* fgrads, int B, const float* latents,
+                             const float* target, const float* drop_mask, float* d_target, float* loss_out, void* ws, size_t ws_bytes,
+                             void* stream);
+/* InfoNCE representation loss (pixel_agent.py:413-437): pred = predict_next_latent(latents, actions); logits =
+ * normalize(pred) normalize(next_enc)^T / 0.1 * 1/(1+mean std); CE against the diagonal.  loss -> *loss_out;
+ * weight * d(loss)/d(next_enc) is accumulated into d_next_enc [B,L].  (Dynamics gradients are discarded by the reference.) */
+int aid_infonce_step(const AidDynamicsNet* dyn, int B, const float* latents, const float* actions, const float* next_enc, float weight,
+                     float* d_next_enc, float* loss_out, void* ws, size_t ws_bytes, void* stream);
+/* RandomShiftAugmentation as a stand-alone op: out[b,c,h,w] = reflect-padded x cropped at (shift_h[b], shift_w[b]); NCHW in/out. */
+int aid_random_shift(const float* x, const int32_t* shift_h, const int32_t* shift_w, int pad, int B, int C, int H, int W, float* out,
+                     void* stream);
 
 /* ---- A11 + value/dynamics optimiser phases (state_agent.py:183-241) -----------------------------
  * lambda-returns (active_inference.py:638-707; minibatch order treated as time), Huber value loss with

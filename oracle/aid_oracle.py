@@ -356,14 +356,16 @@ def gradient_penalty(p: Params, z_t: Tensor, t: Tensor, obs: Tensor, noise, trai
 def diffusion_elbo(p: Params, obs: Tensor, rewards: Tensor, latents: Tensor, noise,
                    tiw: Optional[Tensor], train: bool = True,
                    kl_weight_cfg: float = 0.1, diffusion_weight: float = 1.0,
-                   reward_weight: float = 0.5):
+                   reward_weight: float = 0.5, pixel: bool = False):
     """compute_diffusion_elbo.  Returns (loss=-elbo, info, t, per_sample_losses).
+    pixel=True: the reconstruction goes through `feature_decoder` (one Dropout(.2) mask [B,D]) against the encoder
+    features `obs`, which then carry gradient (active_inference.py:559-562).
 
     Draw order: decoder masks x3; rand[B] (tiw is None) or multinomial[B]+rand[B]; randn[B,L] eps;
     score mask; GP score mask; randn[B,L] prior.
     """
     B = obs.shape[0]
-    rec = F.mse_loss(decode_observation(p, latents, noise, train), obs)
+    rec = F.mse_loss(feature_decoder(p, latents, noise, train) if pixel else decode_observation(p, latents, noise, train), obs)
     t = _t(noise.rand(B)) if tiw is None else importance_sample_time(tiw, B, noise)
     eps = _t(noise.randn(*latents.shape))
     ls = log_snr(p, t)
@@ -455,9 +457,10 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
                          num_trajectories: int = 10, num_ambiguity_samples: int = 10,
                          train: bool = True, epistemic_weight: float = 0.1,
                          pragmatic_weight: float = 1.0, consistency_weight: float = 0.1,
-                         discount: float = 0.99, temperature: float = 1.0):
+                         discount: float = 0.99, temperature: float = 1.0, skip_epistemic: bool = False):
     """Returns (total_efe[B], info, new_running_mean).  Draw order per (k,t): rsample eps [B,A],
-    reparam randn[B,L], then epistemic_value's draws."""
+    reparam randn[B,L], then epistemic_value's draws.  skip_epistemic: the (no_grad) epistemic term is 0 and draws
+    nothing - the pixel path of this repo, whose ConvDecoder estimator is not built."""
     B = latent.shape[0]
     A = p[POLICY + "mean_head.2.weight"].shape[0]
     total = torch.zeros(B)
@@ -474,8 +477,11 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
             prag = pragmatic_weight * (r_mean / temperature)
             prag = prag + value_forward(p, nxt, torch.full((B,), float(t))).squeeze(-1)
             cons = -ent
-            epi, mi, joint, tlog, running_mean = epistemic_value(
-                p, nm.detach(), nlv, running_mean, noise, num_ambiguity_samples, train)
+            if skip_epistemic:
+                epi, mi, joint, tlog = torch.zeros(()), 0.0, 0.0, 0.0
+            else:
+                epi, mi, joint, tlog, running_mean = epistemic_value(
+                    p, nm.detach(), nlv, running_mean, noise, num_ambiguity_samples, train)
             epi = epi.expand(B)
             step = epistemic_weight * epi + pragmatic_weight * prag + consistency_weight * cons
             traj = traj + (discount ** t) * step
@@ -815,3 +821,84 @@ def feature_decoder(p: Params, z: Tensor, noise=None, train: bool = False, pre: 
     """Pixel-mode feature decoder, active_inference.py:142-149: Linear, LN, ReLU, Dropout(.2), Linear, Tanh."""
     x = F.relu(_ln(p, pre + "1", _lin(p, pre + "0", z)))
     return torch.tanh(_lin(p, pre + "4", _drop(x, noise, 0.2, train)))
+
+
+# ---------------------------------------------------------------------------------------------
+# A13  DiffusionPixelAgent.train_step                     aid/agents/pixel_agent.py:274-411
+# ---------------------------------------------------------------------------------------------
+ENC = "encoder."
+
+
+class OraclePixelState(OracleAgentState):
+    """`params` = pixel-mode DiffusionActiveInference state_dict (feature_decoder.*, no observation_decoder / estimator)
+    merged with the DrQV2Encoder state_dict under the prefix "encoder."."""
+
+    def __init__(self, params: Params, n_steps: int, schedule: str = "cosine"):
+        super().__init__(params, n_steps, schedule)
+        names = self.score_names()
+        self.opt["score"] = {"step": 0, "m": {n: torch.zeros_like(self.p[n]) for n in names}, "v": {n: torch.zeros_like(self.p[n]) for n in names}}
+
+    def score_names(self):
+        """The pixel agent's score optimiser (pixel_agent.py:441-449): score net, diffusion, encoder, feature decoder.
+        `attention.channel_reduce.*` never gets a gradient, so AdamW never touches it."""
+        enc = [n for n in self.p if n.startswith(ENC) and not n.endswith(("weight_u", "weight_v")) and "channel_reduce" not in n]
+        return group_names(self.p, "score") + enc + [n for n in self.p if n.startswith("feature_decoder.")]
+
+
+def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, horizon: int = 5, lr: float = 5e-5, clip: float = 0.5,
+                     num_trajectories: int = 10, contrastive_weight: float = 0.5, pad: int = 4, train: bool = True, return_grads: bool = False):
+    """One DiffusionPixelAgent.train_step, with the epistemic term skipped (see expected_free_energy).  Draw order: [shift h, w;
+    Dropout2d masks x2; Dropout mask] for obs, the same for next_obs; belief draws (+1 feature-decoder mask) for each; ELBO
+    draws (feature-decoder mask first); per (k,t) policy eps and reparam eps."""
+    p = st.p
+    names = st.score_names()
+    for n in p:
+        p[n].requires_grad_(bool((is_param(n) or n in names) and p[n].dtype.is_floating_point and not n.endswith(("weight_u", "weight_v"))))
+    obs, nobs, act = _t(batch["observations"]), _t(batch["next_observations"]), _t(batch["actions"])
+    rew, dones = batch["rewards"], np.asarray(batch["dones"]).astype(bool)
+    B = obs.shape[0]
+    enc_obs = encoder_forward(p, random_shift(obs, pad, noise) if train else obs, noise, train, pre=ENC)
+    enc_next = encoder_forward(p, random_shift(nobs, pad, noise) if train else nobs, noise, train, pre=ENC)
+    st.rms.update(np.asarray(rew, dtype=np.float32))
+    nrew = _t(st.rms.normalize(np.asarray(rew, dtype=np.float32)).astype(np.float32))
+    with torch.no_grad():
+        latents = generate_latent_trajectory(p, st.tab, enc_obs, noise, train)
+        feature_decoder(p, latents, noise, train)                       # reconstruction diagnostic of update_belief (draws its mask)
+        next_latents = generate_latent_trajectory(p, st.tab, enc_next, noise, train)
+        feature_decoder(p, next_latents, noise, train)
+    loss, info, t, per = diffusion_elbo(p, enc_obs, nrew, latents, noise, st.tiw, train, pixel=True)
+    contrastive = representation_loss(p, enc_next, act, latents)
+    total = loss + contrastive_weight * contrastive
+    ps = [p[n] for n in names]
+    grads = torch.autograd.grad(total, ps, allow_unused=True)
+    live = [(n, g.clone()) for n, g in zip(names, grads) if g is not None]
+    clip_grad_norm([g for n, g in live if not n.startswith("feature_decoder.")], clip)     # pixel_agent.py:325-331
+    o = st.opt["score"]; o["step"] += 1
+    with torch.no_grad():
+        for n, g in live:
+            adamw_step(p[n], g, o["m"][n], o["v"][n], o["step"], lr, 1e-5)
+    st.tiw = update_time_importance(torch.ones(100) if st.tiw is None else st.tiw, t, per)
+    with torch.no_grad():
+        for n in st.ema:
+            st.ema[n] = 0.9999 * st.ema[n] + (1 - 0.9999) * p[n]
+    metrics = {k: float(v) for k, v in info.items()}
+    metrics["contrastive_loss"] = float(contrastive)
+    grads_out = {"score": dict(live)}
+    efe, einfo, _ = expected_free_energy(p, latents, noise, 0.0, horizon, num_trajectories, 1, train, skip_epistemic=True)
+    ploss = efe.mean()
+    grads_out["policy"], _ = _opt_step(st, "policy", ploss, lr, 1e-5, clip)
+    metrics["policy_loss"] = float(ploss)
+    metrics.update({k: float(v) for k, v in einfo.items() if not k.startswith("epistemic/")})
+    values = value_forward(p, latents, torch.zeros(B)).squeeze(-1)
+    with torch.no_grad():
+        nv = value_forward(p, next_latents, torch.ones(B)).squeeze(-1)
+        targets = _t(lambda_returns(nrew.numpy(), nv.numpy(), dones))
+    vloss = F.huber_loss(values, targets)
+    grads_out["value"], _ = _opt_step(st, "value", vloss, lr, 1e-2, clip)
+    metrics["value_loss"] = float(vloss)
+    pred, _ = predict_next_latent(p, latents, act)
+    dloss = F.mse_loss(pred, next_latents)
+    grads_out["dynamics"], _ = _opt_step(st, "dynamics", dloss, lr, 1e-2, clip)
+    metrics["dynamics_loss"] = float(dloss)
+    aux = {"latents": latents, "next_latents": next_latents, "encoded_obs": enc_obs.detach(), "encoded_next_obs": enc_next.detach()}
+    return (metrics, grads_out, aux) if return_grads else metrics

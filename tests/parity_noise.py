@@ -13,9 +13,18 @@ def dev(x):
 
 
 class ParityNoise(NoiseSource):
-    def __init__(self, key: int):
+    def __init__(self, key: int, pixel: bool = False):
         super().__init__(seed=0)
         self.ns = NoiseStream(key)
+        self.pixel = pixel        # pixel mode: feature-decoder mask instead of the 3 decoder masks, no estimator draws in the EFE
+
+    def encoder(self, B, L, pad):
+        """One DrQ-v2 pass in train mode: RandomShiftAugmentation offsets, Dropout2d masks of layers 1, 2, Dropout mask of the head."""
+        ns = self.ns
+        sh, sw = ns.randint(0, 2 * pad + 1, B), ns.randint(0, 2 * pad + 1, B)
+        i32 = lambda a: torch.as_tensor(np.asarray(a, dtype=np.int32)).cuda()
+        return {"shift_h": i32(sh), "shift_w": i32(sw), "drop2d_1": dev(ns.dropout_mask((B, 64), 0.025)), "drop2d_2": dev(ns.dropout_mask((B, 128), 0.05)),
+                "drop_out": dev(ns.dropout_mask((B, 2 * L), 0.1))}
 
     def rekey(self, key: int):
         self.ns = NoiseStream(key)
@@ -33,12 +42,20 @@ class ParityNoise(NoiseSource):
                 masks[t] = ns.dropout_mask((B, D), 0.1)
             if t > 0:
                 eps[t] = ns.randn(B, L)
-        dec = [dev(ns.dropout_mask((B, w), 0.2)) for w in (2 * D, 2 * D, D)] if train else None   # decode_observation masks
+        if self.pixel:
+            dec = None
+            if train:
+                ns.dropout_mask((B, D), 0.2)            # feature-decoder mask of the (skipped) reconstruction diagnostic
+        else:
+            dec = [dev(ns.dropout_mask((B, w), 0.2)) for w in (2 * D, 2 * D, D)] if train else None   # decode_observation masks
         return {"z_init": dev(z0), "step_noise": dev(eps), "drop_masks": dev(masks) if train else None, "dec_masks": dec}
 
     def elbo(self, B, L, D, first_call, time_importance):
         ns = self.ns
-        n = {"dec_mask0": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask1": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask2": ns.dropout_mask((B, D), 0.2)}
+        if self.pixel:
+            n = {"fd_mask": ns.dropout_mask((B, D), 0.2)}
+        else:
+            n = {"dec_mask0": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask1": ns.dropout_mask((B, 2 * D), 0.2), "dec_mask2": ns.dropout_mask((B, D), 0.2)}
         n["t"] = ns.rand(B) if first_call else orc.importance_sample_time(time_importance.detach().cpu(), B, ns).numpy()
         n["eps"] = ns.randn(B, L); n["score_mask"] = ns.dropout_mask((B, D), 0.1); n["gp_mask"] = ns.dropout_mask((B, D), 0.1)
         n["prior_eps"] = ns.randn(B, L)
@@ -46,6 +63,13 @@ class ParityNoise(NoiseSource):
 
     def efe(self, B, L, A, H, K, S):
         ns = self.ns
+        if self.pixel:
+            n = {"policy_eps": np.zeros((H, K * B, A), np.float32), "reparam_eps": np.zeros((H, K * B, L), np.float32)}
+            for k in range(K):
+                for t in range(H):
+                    n["policy_eps"][t, k * B:(k + 1) * B] = ns.randn(B, A)
+                    n["reparam_eps"][t, k * B:(k + 1) * B] = ns.randn(B, L)
+            return {k: dev(v) for k, v in n.items()}
         M, R = K * B, K * S * B
         n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),
              "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((H, 4, R, L), np.float32),

@@ -100,3 +100,133 @@ def test_encoder_batch16_vs_oracle(nat):
         scale = float(r.abs().max()) + 1e-12
         err = float((gd[k].cpu() - r).abs().max()) / scale
         assert err < 3e-3, (k, err, scale)
+
+
+# ------------------------------------------------------------------------------------------------- pixel-mode training pieces
+from oracle.weights import draw_params, param_specs
+from parity_noise import ParityNoise
+
+
+def test_infonce_golden_and_oracle(nat, golden_dir):
+    """compute_representation_loss against the reference's own loss / d(loss)/d(next features) (tests/golden/pixel.npz)."""
+    g = np.load(os.path.join(golden_dir, "pixel.npz"))
+    L, A, D = 17, 6, 64
+    p = draw_params(param_specs(L, A, L, D, 4), 3, orc.schedule_tables(4))
+    dyn = nat.dynamics_table({k: v.cuda().contiguous() for k, v in p.items()}, A)
+    lat, act, nxt = dev(g["nce_lat"]), dev(g["nce_act"]), dev(g["nce_next"])
+    tn = torch.from_numpy(g["nce_next"]).requires_grad_(True)
+    ref = orc.representation_loss(p, tn, torch.from_numpy(g["nce_act"]), torch.from_numpy(g["nce_lat"]))
+    (gref,) = torch.autograd.grad(ref, tn)
+    d_next = torch.zeros_like(nxt)
+    loss = nat.infonce_step(dyn, lat, act, nxt, 0.5, d_next)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=2e-4)
+    np.testing.assert_allclose(d_next.cpu().numpy(), 0.5 * gref.numpy(), rtol=2e-3, atol=1e-6)
+
+
+def _pixel_agent(L, A, D, N, H, B, cap=32):
+    import aid_amd
+    from test_hip_agent import Box
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=L, hidden_dim=D, pixel_observation=True)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+
+    class Env:
+        observation_space, action_space = Box((3, 3, 84, 84)), Box((A,))
+    return aid_amd.DiffusionPixelAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=cap), aid_amd.PixelObservationConfig())
+
+
+def _load_pixel_params(agent, L, A, D, N, key):
+    """Oracle-drawn weights (non-zero adaLN / heads) for everything the oracle knows; the feature decoder keeps its own init."""
+    ai = agent.active_inference
+    p = draw_params(param_specs(L, A, L, D, N), key, orc.schedule_tables(N))
+    sd = ai.state_dict()
+    full = {k: (p[k] if k in p else v.cpu().clone()) for k, v in sd.items()}
+    ai.load_state_dict(full, strict=True)
+    pe = draw_encoder_params(encoder_specs(L), key + 1)
+    agent.encoder.load_state_dict(pe, strict=True)
+    merged = {k: v.clone() for k, v in full.items()}
+    merged.update({"encoder." + k: v.clone() for k, v in pe.items()})
+    return merged
+
+
+def test_pixel_elbo_feature_gradient_vs_oracle(nat):
+    """ELBO with the feature-decoder reconstruction: loss, feature-decoder gradients and d(loss)/d(encoder features) - the
+    cotangent the encoder backward consumes (recon target + score-net conditioning incl. the gradient penalty's double backward)."""
+    L, A, D, N, B = 32, 6, 64, 4, 8
+    agent = _pixel_agent(L, A, D, N, 2, B)
+    ai = agent.active_inference
+    p = _load_pixel_params(agent, L, A, D, N, 41)
+    ns = NoiseStream(12)
+    feats, lat, rew = np.tanh(ns.randn(B, L)).astype(np.float32), ns.randn(B, L), ns.randn(B)
+    pn = ParityNoise(77, pixel=True); ai.noise = pn
+    for a in ai.arenas.values():
+        a.zero_grad()
+    loss, info = ai.compute_diffusion_elbo(dev(feats), dev(rew), dev(lat))
+    for n in p:
+        p[n].requires_grad_(orc.is_param(n) and p[n].dtype.is_floating_point and not n.startswith("encoder."))
+    ft = torch.from_numpy(feats).requires_grad_(True)
+    lref, iref, _, _ = orc.diffusion_elbo(p, ft, torch.from_numpy(rew), torch.from_numpy(lat), NoiseStream(77), None, True, pixel=True)
+    names = [n for n in p if n.startswith(("feature_decoder.", "latent_score_network.obs_encoder.0"))]
+    gref = torch.autograd.grad(lref, [ft] + [p[n] for n in names])
+    np.testing.assert_allclose(float(loss), float(lref), rtol=2e-3)
+    np.testing.assert_allclose(float(info["reconstruction_loss"]), float(iref["reconstruction_loss"]), rtol=1e-4)
+    sc = float(gref[0].abs().max())
+    assert float((ai._last_d_obs.cpu() - gref[0]).abs().max()) / sc < 3e-3
+    gv = {**ai.arenas["feature_decoder"].grad_views(), **ai.arenas["score"].grad_views()}
+    for n, r in zip(names, gref[1:]):
+        assert float((gv[n].cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12) < 3e-3, n
+
+
+def test_pixel_agent_train_step_vs_oracle():
+    """One whole DiffusionPixelAgent.train_step (encoder x2, merged belief loop, ELBO + InfoNCE, two encoder backward passes,
+    shared-norm clip over score + diffusion + encoder, policy / value / dynamics phases) against the oracle's restatement."""
+    L, A, D, N, H, B = 32, 6, 64, 3, 2, 8
+    agent = _pixel_agent(L, A, D, N, H, B)
+    ai = agent.active_inference
+    p = _load_pixel_params(agent, L, A, D, N, 17)
+    bs = NoiseStream(4); cap = 16
+    store = {"observations": bs.rand(cap, 9 * 84 * 84), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32), "rewards": bs.randn(cap),
+             "next_observations": bs.rand(cap, 9 * 84 * 84), "dones": bs.rand(cap) < 0.1}
+    agent.replay_buffer.add_batch(store["observations"], store["actions"], store["rewards"], store["next_observations"], store["dones"])
+    pn = ParityNoise(321, pixel=True); ai.noise = pn; agent.replay_buffer.index_source = pn
+    m = agent.train_step()
+    st = orc.OraclePixelState(p, N)
+    ns = NoiseStream(321)
+    batch = orc.replay_sample(store, cap, B, ns)
+    batch["observations"] = batch["observations"].reshape(B, 9, 84, 84); batch["next_observations"] = batch["next_observations"].reshape(B, 9, 84, 84)
+    torch.set_num_threads(8)
+    m_ref, g_ref, aux = orc.pixel_train_step(st, batch, ns, horizon=H, return_grads=True)
+    np.testing.assert_allclose(agent._last["encoded_obs"].cpu().numpy(), aux["encoded_obs"].numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(agent._last["next_latents"].cpu().numpy(), aux["next_latents"].numpy(), rtol=2e-3, atol=1e-4)
+    for k, v in m_ref.items():
+        if isinstance(v, float) and k in m:
+            np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=k)
+    assert "contrastive_loss" in m
+    sd = {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}
+    for n in st.p:
+        ref = st.p[n].detach().numpy()
+        np.testing.assert_allclose(sd[n].cpu().numpy(), ref, rtol=1e-3, atol=3e-6, err_msg=n)
+    # the update really moved the encoder and the feature decoder; channel_reduce stays put
+    assert not np.allclose(sd["encoder.convs.0.weight_orig"].cpu().numpy(), p["encoder.convs.0.weight_orig"].detach().numpy(), atol=1e-7)
+    assert not np.allclose(sd["feature_decoder.0.weight"].cpu().numpy(), p["feature_decoder.0.weight"].detach().numpy(), atol=1e-7)
+
+
+def test_pixel_agent_philox_run():
+    """Production mode (device Philox, augmentation on): metric keys, finite values, act() from raw uint8 frames."""
+    L, A = 32, 4
+    agent = _pixel_agent(L, A, 64, 3, 2, 8)
+    rng = np.random.default_rng(0)
+    assert agent.train_step() == {}
+    for _ in range(16):
+        agent.replay_buffer.add(rng.random((3, 3, 84, 84), dtype=np.float32), rng.uniform(-1, 1, A), float(rng.standard_normal()),
+                                rng.random((3, 3, 84, 84), dtype=np.float32), False)
+    w0 = agent.encoder.convs[1].weight_orig.detach().clone()
+    for _ in range(2):
+        m = agent.train_step()
+    want = {"reconstruction_loss", "kl_loss", "score_matching_loss", "elbo", "reward_loss", "grad_penalty", "contrastive_loss", "policy_loss",
+            "pragmatic_mean", "consistency_mean", "value_loss", "dynamics_loss"}
+    assert want <= set(m) and all(np.isfinite(v) for v in m.values()), m
+    assert not torch.equal(w0, agent.encoder.convs[1].weight_orig)
+    action, info = agent.act((rng.random((3, 84, 84, 3)) * 255).astype(np.uint8))
+    assert action.shape == (A,) and np.all(np.isfinite(action)) and np.all(np.abs(action) <= 1)
+    import aid_amd.agents as ag
+    assert ag.PixelBasedAgent is ag.DiffusionPixelAgent

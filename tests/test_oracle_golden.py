@@ -146,3 +146,14 @@ def test_misc_goldens(golden_dir):
     mu, ob, sc = m["fp_mu"], m["fp_obs"], m["fp_score"]
     np.testing.assert_allclose(-(mu - ob) / 0.01 ** 2 - mu + sc, m["fp_grad"], rtol=1e-12)
     np.testing.assert_allclose(orc.gaussian_entropy_diag(m["fp_entropy_var"]), m["fp_entropy"], rtol=1e-12)
+
+
+def test_pixel_infonce_golden(golden_dir):
+    """compute_representation_loss (pixel_agent.py:413-437): loss and d(loss)/d(next features) as the reference produced them."""
+    from oracle.weights import draw_params, param_specs
+    g = np.load(os.path.join(golden_dir, "pixel.npz"))
+    p = draw_params(param_specs(17, 6, 17, 64, 4), 1234 + 17, orc.schedule_tables(4))
+    tn = torch.from_numpy(g["nce_next"]).requires_grad_(True)
+    loss = orc.representation_loss(p, tn, torch.from_numpy(g["nce_act"]), torch.from_numpy(g["nce_lat"]))
+    np.testing.assert_allclose(loss.item(), float(g["nce_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(torch.autograd.grad(loss, tn)[0].numpy(), g["nce_grad"], rtol=1e-4, atol=1e-8)

@@ -1,5 +1,5 @@
 import sys, os, time, json
-R=os.path.dirname(os.path.abspath(__file__)); sys.path.insert(0, R+"/active-inference-diffusion_amd"); sys.path.insert(0, R)
+R=os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R+"/active-inference-diffusion_amd"); sys.path.insert(0, R)
 import numpy as np, torch
 from aid_amd import _native as nat
 from oracle import aid_oracle as orc

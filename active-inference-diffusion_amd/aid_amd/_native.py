@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libaid_hip.so")
 AID_MAX_BLOCKS = 8
 T_DISCRETE, T_CONTINUOUS = 0, 1
 ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3}
-PROF_GEMM, PROF_ROWWISE, PROF_OPTIM = 0, 1, 2
+PROF_GEMM, PROF_ROWWISE, PROF_OPTIM, PROF_GEMM_TILE = 0, 1, 2, 3
 
 _fp = C.POINTER(C.c_float)
 
@@ -341,6 +341,10 @@ def prof_read(kernel_id: int):
     out = (C.c_double * 4)()
     check(lib().aid_prof_read(kernel_id, out), "aid_prof_read")
     return {"launches": int(out[0]), "ms": out[1], "flops": out[2], "bytes": out[3]}
+
+
+def prof_dump(path: str):
+    check(lib().aid_prof_dump(path.encode()), "aid_prof_dump")
 
 
 def decode_observation(dec: AidDecoderNet, z, masks=None, ws: Workspace = None):

@@ -41,6 +41,13 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     def _process_batch_observations(self, observations: torch.Tensor) -> torch.Tensor:
         return observations.to(self.device)
 
+    overlap_streams = True    # False: every phase on the current stream, in order (used when timing individual kernels)
+
+    def _side_workspace(self):
+        if getattr(self, "_ws_side", None) is None:
+            self._ws_side = nat.Workspace(self.device)
+        return self._ws_side
+
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self.device)
@@ -72,26 +79,34 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         # 1. latents via reverse diffusion (no gradients): obs and next_obs share one 2B-row loop
         both = ai.denoise_pair(obs, next_obs)
         latents = both[:B]
-        # 2. score / diffusion group
+        # 2. score / diffusion group: ELBO forward + backward on the main stream
         self.score_optimizer.zero_grad()
         elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents)
-        if dp:   # 109 MB gradient mean over xGMI, hidden under the EFE phase (which does not read score parameters)
-            comm = self._comm_stream()
-            comm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm):
-                self.score_optimizer.allreduce_grads(async_op=True)
+        main = torch.cuda.current_stream()
+        if self.overlap_streams:
+            # The policy phase reads no score-network parameter, and the value phase needs a fresh belief over next_obs from
+            # the UPDATED score network (state_agent.py:194-205).  So: [gradient all-reduce ->] score step -> third reverse
+            # loop run on a side stream underneath the EFE/MINE phase.  The loop's batch-256 kernels are latency-bound and
+            # leave most CUs idle; the 25 600-row MINE GEMMs fill them.  Same arithmetic, same draw order (EFE, then belief).
+            elbo_done = torch.cuda.Event(); elbo_done.record(main)
         else:
             self.score_optimizer.step()
         # 3. policy
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
-        if dp:
-            torch.cuda.current_stream().wait_stream(self._comm_stream())
-            self.score_optimizer.step()
-        # 4. value (targets from a re-sampled next-latent belief, state_agent.py:194-205)
+        # 4. value (targets from a re-sampled next-latent belief)
+        if self.overlap_streams:
+            side = self._comm_stream()
+            side.wait_event(elbo_done)
+            with torch.cuda.stream(side):
+                self.score_optimizer.step()            # data parallel: the 109 MB RCCL all-reduce runs here, off the critical path
+                next_latents = ai.denoise_only(next_obs, ws=self._side_workspace())
+            next_latents.record_stream(main)
+            main.wait_stream(side)
+        else:
+            next_latents = ai.denoise_only(next_obs)
         self.value_optimizer.zero_grad()
-        next_latents = ai.denoise_only(next_obs)
         value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
                                        cfg.discount_factor, 0.95, 5, ws=ai._ws)
         self.value_optimizer.step()

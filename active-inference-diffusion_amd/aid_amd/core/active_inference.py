@@ -229,15 +229,16 @@ class DiffusionActiveInference(nn.Module):
         return {"latent": latent, "latent_mean": stats[:L], "latent_std": stats[L:2 * L], "trajectory_length": N + 1,
                 "reconstruction_error": stats[2 * L], "observation": observation, "raw_observation": raw_observation}
 
-    def denoise_only(self, observation: torch.Tensor, noise: Optional[dict] = None) -> torch.Tensor:
-        """The reverse loop without the diagnostic decode/statistics: what train_step needs (it discards the rest)."""
+    def denoise_only(self, observation: torch.Tensor, noise: Optional[dict] = None, ws=None) -> torch.Tensor:
+        """The reverse loop without the diagnostic decode/statistics: what train_step needs (it discards the rest).
+        `ws`: a private workspace when the loop runs on a side stream next to other native calls."""
         observation = observation.to(self.device).float().contiguous()
         N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
         if noise is None:
             noise = self.noise.belief(observation.shape[0], self.latent_dim, self.config.hidden_dim, N, train) or {}
         return nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), observation, N, noise.get("z_init"),
                                 noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
-                                offset=self.noise.next_offset(), ws=self._ws)
+                                offset=self.noise.next_offset(), ws=ws or self._ws)
 
     def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
         """Two independent belief updates (state_agent.py:135-140) as ONE reverse loop over 2B rows: the batch-256 layers are

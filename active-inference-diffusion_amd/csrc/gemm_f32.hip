@@ -207,6 +207,178 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// Large-problem variant of the tile kernel with the K depth of a stage (BKT) and the workgroup->tile map as
+// parameters.  Shallower stages (BKT = 16) shrink the LDS image so that 128-row tiles still run 3-4 workgroups
+// per CU, and a 128-wide tile halves the bytes each CU must ingest per MFMA (the per-CU L2/MALL ingest rate, not
+// HBM, is what starves fp32 MFMA at 64x64).  map = 1: each XCD works through all N-tiles of a group of 8 for one
+// M-tile before moving to the next M-tile, so an activation tile is fetched from the Infinity Cache once per XCD
+// and re-used from that XCD's L2, while the 8 weight panels of the group (<= 2 MB at K = 1024) stay L2-resident.
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, bool KMAJOR, int BKT>
+struct TileK {
+    static constexpr int LD = KMAJOR ? (ROWS + 4) : (BKT + 4);
+    static constexpr int NROW = KMAJOR ? BKT : ROWS;
+    static constexpr int FLOATS = LD * NROW;
+    static constexpr int F4 = ROWS * BKT / 4;
+};
+
+template <int ROWS, bool KMAJOR, int BKT, int NT, int P>
+__device__ __forceinline__ void load_tile_k(const float* __restrict__ G, int ld, int r0, int k0, int R, int K, int tid, f32x4 (&regs)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int f = tid + NT * i;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (f < TileK<ROWS, KMAJOR, BKT>::F4) {
+            if (!KMAJOR) {
+                const int row = f / (BKT / 4), kq = f % (BKT / 4);
+                const int gr = r0 + row, gk = k0 + 4 * kq;
+                if (gr < R && gk < K) v = *reinterpret_cast<const f32x4*>(G + (size_t)gr * ld + gk);
+            } else {
+                const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+                const int gk = k0 + k, gr = r0 + 4 * rq;
+                if (gk < K && gr < R) v = *reinterpret_cast<const f32x4*>(G + (size_t)gk * ld + gr);
+            }
+        }
+        regs[i] = v;
+    }
+}
+template <int ROWS, bool KMAJOR, int BKT, int NT, int P>
+__device__ __forceinline__ void store_tile_k(float* __restrict__ S, int tid, const f32x4 (&regs)[P]) {
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int f = tid + NT * i;
+        if (f < TileK<ROWS, KMAJOR, BKT>::F4) {
+            int off;
+            if (!KMAJOR) { const int row = f / (BKT / 4), kq = f % (BKT / 4); off = row * TileK<ROWS, KMAJOR, BKT>::LD + 4 * kq; }
+            else { const int k = f / (ROWS / 4), rq = f % (ROWS / 4); off = k * TileK<ROWS, KMAJOR, BKT>::LD + 4 * rq; }
+            *reinterpret_cast<f32x4*>(S + off) = regs[i];
+        }
+    }
+}
+template <int ROWS, bool KMAJOR, int BKT>
+__device__ __forceinline__ f32x4 read_frag_k(const float* __restrict__ S, int r, int g8, int h) {
+    if (!KMAJOR) return *reinterpret_cast<const f32x4*>(S + r * TileK<ROWS, KMAJOR, BKT>::LD + 8 * g8 + 4 * h);
+    f32x4 v;
+    const float* p = S + (8 * g8 + 4 * h) * TileK<ROWS, KMAJOR, BKT>::LD + r;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = p[j * TileK<ROWS, KMAJOR, BKT>::LD];
+    return v;
+}
+
+__device__ __forceinline__ void tile_coords_big(int b, int tiles_m, int tiles_n, int map, int& tm, int& tn) {
+    if (map == 1) {
+        const int G = tiles_n < 8 ? tiles_n : 8;
+        if (tiles_n % G == 0 && (tiles_m & 7) == 0) {
+            const int x = b & 7, q = b >> 3;
+            const int T = x + 8 * (q / G);                       // task = (M-tile, N-group), dealt round-robin to the XCDs
+            tm = T % tiles_m; tn = (T / tiles_m) * G + q % G;
+            return;
+        }
+    }
+    tile_coords(b, tiles_m, tiles_n, tm, tn);
+}
+
+template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD>
+__global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, int map) {
+    constexpr int NT = 256;
+    constexpr int TM = BM / 64, TN = BN / 64;
+    using TA = TileK<BM, AKM, BKT>; using TB = TileK<BN, BKM, BKT>;
+    constexpr int PA = (TA::F4 + NT - 1) / NT, PB = (TB::F4 + NT - 1) / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;
+    float* Bs = smem + 2 * TA::FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    int tm_, tn_; tile_coords_big(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, map, tm_, tn_);
+    const int m0 = tm_ * BM, n0 = tn_ * BN;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = (g.K + BKT - 1) / BKT;
+    auto contract = [&](int cur) {
+        const float* a_s = As + cur * TA::FLOATS;
+        const float* b_s = Bs + cur * TB::FLOATS;
+#pragma unroll
+        for (int g8 = 0; g8 < BKT / 8; ++g8) {
+            f32x4 av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = read_frag_k<BM, AKM, BKT>(a_s, wm + 32 * i + li, g8, h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = read_frag_k<BN, BKM, BKT>(b_s, wn + 32 * j + li, g8, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+    };
+    if constexpr (PD == 1) {
+        f32x4 ra[PA], rb[PB];
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) {
+                load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 1) * BKT, g.M, g.K, tid, ra);
+                load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 1) * BKT, g.N, g.K, tid, rb);
+            }
+            contract(cur);
+            if (kt + 1 < nk) {
+                store_tile_k<BM, AKM, BKT, NT, PA>(As + (cur ^ 1) * TA::FLOATS, tid, ra);
+                store_tile_k<BN, BKM, BKT, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, tid, rb);
+            }
+            __syncthreads();
+        }
+    } else {
+        // prefetch distance 2: tile kt+2's global loads are issued before tile kt is contracted and land in the register set
+        // that tile kt+1 does not use, so a load has two contraction periods to arrive (Infinity-Cache / HBM latency is longer
+        // than one 32-deep stage of fp32 MFMAs).  The loop is unrolled by two so both register sets are named statically.
+        f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra0);
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb0);
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, BKT, g.M, g.K, tid, ra1);     // rows beyond K come back as zeros
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, BKT, g.N, g.K, tid, rb1);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra0);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            // even step: LDS[0] holds tile kt, set 1 holds tile kt+1 (in flight), set 0 is free
+            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 2) * BKT, g.M, g.K, tid, ra0);
+            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 2) * BKT, g.N, g.K, tid, rb0);
+            contract(0);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As + TA::FLOATS, tid, ra1);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs + TB::FLOATS, tid, rb1);
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            // odd step: LDS[1] holds tile kt+1, set 0 holds tile kt+2 (in flight), set 1 is free
+            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 3) * BKT, g.M, g.K, tid, ra1);
+            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 3) * BKT, g.N, g.K, tid, rb1);
+            contract(1);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra0);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb0);
+            __syncthreads();
+        }
+    }
+#pragma clang loop unroll(full)
+    for (int i = 0; i < TM; ++i)
+#pragma clang loop unroll(full)
+        for (int j = 0; j < TN; ++j)
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 16; ++r)
+                epilogue_store(g, m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + wn + 32 * j + li, acc[i][j][r]);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Small-M kernel: 32x32 output tile per workgroup, the 4 waves split every 32-deep K tile four
 // ways (8 k each = 4 MFMAs) and reduce through LDS.  4x more workgroups than the 64x64 tiling and
 // a 4x shorter dependent MFMA chain per wave: this is the batch-256 configuration.
@@ -562,6 +734,19 @@ static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
     else     hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, false>), dim3(tm * tn, ny), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
+static int g_big_map = 0;
+template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD = 1>
+static int launch_big(const GemmArgs& g, hipStream_t s) {
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * (TileK<BM, AKM, BKT>::FLOATS + TileK<BN, BKM, BKT>::FLOATS);
+    static bool attr_done = false;
+    if (lds > 65536 && !attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn), dim3(256), lds, s, g, tn, g_big_map);
+    return AID_OK;
+}
 template <bool AKM, bool BKM>
 static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
@@ -586,6 +771,13 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
             case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
             case 5: return launch_tile<128, 128, AKM, BKM>(g, vec, s);
             case 6: return launch_splitk<AKM, BKM>(g, vec, s);
+            case 7: if (vec) return launch_big<64, 64, 16, AKM, BKM, 2>(g, s); break;
+            case 8: if (vec) return launch_big<128, 64, 16, AKM, BKM>(g, s); break;
+            case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
+            case 10: if (vec) return launch_big<64, 64, 16, AKM, BKM>(g, s); break;
+            case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM>(g, s); break;
+            case 12: if (vec) return launch_big<128, 64, 16, AKM, BKM, 2>(g, s); break;
+            case 13: if (vec) return launch_big<64, 128, 16, AKM, BKM>(g, s); break;
             default: break;
         }
     }
@@ -594,6 +786,10 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     // tiles; below that the grid cannot fill the chip and the 32x32 LDS-DMA panel kernel (whole K in flight at once,
     // 4-way in-workgroup split-K) has the shortest critical path.
     const long t64a = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
+    // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): same 64x64x32 tile with prefetch distance 2 and the
+    // XCD-grouped tile map (+3..20 % on these shapes, profiles/gemm_big_r01.txt); below that the plain kernel is as fast.
+    if (g_force_kernel == 0 && vec && t64a >= 2048 && g.K >= 64) { const int keep = g_big_map; g_big_map = 1;
+        const int r = launch_big<64, 64, 32, AKM, BKM, 2>(g, s); g_big_map = keep; return r; }
     if (g_force_kernel == 0 && t64a >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
     {
     const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
@@ -608,8 +804,12 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// true when the automatic dispatcher sends this problem to gemm_tile_kernel (profiling label only)
+static inline bool routes_to_tile(const GemmArgs& g) {
+    return g_force_kernel == 0 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 160;
+}
 
-void gemm_force_kernel(int k) { g_force_kernel = k; }
+void gemm_force_kernel(int k) { g_force_kernel = k & 0xff; g_big_map = (k >> 8) & 0xff; }
 
 __global__ void slab_fold_kernel(const float* __restrict__ slab, int nslab, GemmArgs g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -637,7 +837,8 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     vec = vec && (g.a_kmajor ? (g.M % 4 == 0) : (g.K % 4 == 0)) && (g.b_kmajor ? (g.N % 4 == 0) : (g.K % 4 == 0));
     if (g.slab) {   // deterministic split-K: K-slices -> slab -> ordered fold
         AID_REQUIRE(g.nslab >= 1 && g.act == ACT_NONE && !g.preact && !g.mask && !g.dact_pre && !g.residual, AID_E_SHAPE, "gemm_f32: slab mode needs a plain epilogue");
-        ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+        ProfScope prof(PROF_GEMM_TILE, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+        prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor + 4;
         int r;
         if (!g.a_kmajor && !g.b_kmajor) r = launch_tile<64, 64, false, false>(g, vec, s);
         else if (!g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, false, true>(g, vec, s);
@@ -649,7 +850,9 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         AID_LAUNCH_CHECK();
         return AID_OK;
     }
-    ProfScope prof(PROF_GEMM, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    ProfScope prof(routes_to_tile(g) ? PROF_GEMM_TILE : PROF_GEMM, s, 2.0 * g.M * g.N * g.K,
+                   4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
+    prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor;
     int r;
     if (!g.a_kmajor && !g.b_kmajor) r = dispatch<false, false>(g, vec, s);
     else if (!g.a_kmajor && g.b_kmajor) r = dispatch<false, true>(g, vec, s);

@@ -11,7 +11,7 @@ void set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int id, m, n, k, layout; };
 struct ProfState {
     bool on = false;
     std::mutex mu;
@@ -28,7 +28,7 @@ ProfScope::~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.recs[id].push_back({e0, e1, flops, bytes});
+    g_prof.recs[id].push_back({e0, e1, flops, bytes, id, m, n, k, layout});
 }
 
 }  // namespace aid
@@ -45,6 +45,21 @@ int aid_prof_reset(void) {
         for (auto& r : g_prof.recs[k]) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
         g_prof.recs[k].clear();
     }
+    return AID_OK;
+}
+int aid_prof_dump(const char* path) {
+    AID_REQUIRE(path, AID_E_NULL, "aid_prof_dump: null path");
+    FILE* f = fopen(path, "w");
+    AID_REQUIRE(f, AID_E_SHAPE, "aid_prof_dump: cannot open %s", path);
+    std::lock_guard<std::mutex> lk(g_prof.mu);
+    fprintf(f, "kernel_id,M,N,K,layout,ms\n");
+    for (int k = 0; k < PROF_COUNT; ++k)
+        for (auto& r : g_prof.recs[k]) {
+            float t = 0.f;
+            if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1.f;
+            fprintf(f, "%d,%d,%d,%d,%d,%.6f\n", r.id, r.m, r.n, r.k, r.layout, t);
+        }
+    fclose(f);
     return AID_OK;
 }
 int aid_prof_read(int kernel_id, double out[4]) {

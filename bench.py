@@ -10,8 +10,9 @@ rollout + policy BPTT, value and dynamics updates, four fused clip/AdamW/EMA ste
 parallel: every rank owns a replay shard and a 256-row minibatch, gradients are averaged with one RCCL all-reduce per
 optimiser group.  `value` = batch-256 train steps per second summed over ranks.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the fp32-MFMA GEMM family, measured live with HIP events
-through aid_prof_*), `cpu_baseline` (the oracle's train_step timed on the host cores, rank 0, N=1 only).
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the dominant kernel, aid::gemm_tile_kernel, measured live with HIP
+events through aid_prof_*; `roofline_gemm_family` = every GEMM launch, `roofline_hbm` = the optimiser kernel), `cpu_baseline`
+(the oracle's train_step timed on the host cores, rank 0, N=1 only).
 """
 import argparse
 import json
@@ -109,6 +110,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="keep every phase on one stream (rocprofv3 --pmc passes: counter collection "
+                    "serialises dispatches anyway and crashes on this pool when two streams dispatch concurrently)")
+    ap.add_argument("--dump-launches", default="", help="write the per-launch GEMM timings of the profiled step to this CSV")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +130,8 @@ def main():
     agent = make_agent(device, seed=rank)
     if world > 1:
         agent.enable_data_parallel()
+    if args.no_overlap:
+        agent.overlap_streams = False
 
     def sync():
         if world > 1:
@@ -153,14 +159,27 @@ def main():
     for _ in range(reps):
         ai.denoise_only(obs)
     torch.cuda.synchronize(); dn = (time.perf_counter() - t1) / reps
+    # event-bracketed launches need one stream: the side-stream overlap of train_step is switched off for this one step
+    agent.overlap_streams = False
+    agent.train_step(); torch.cuda.synchronize()
     nat.prof_enable(True); nat.prof_reset()
     agent.train_step(); torch.cuda.synchronize()
-    g = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
+    gt = nat.prof_read(nat.PROF_GEMM_TILE); gs = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
+    if args.dump_launches:
+        nat.prof_dump(args.dump_launches)
     nat.prof_enable(False); nat.prof_reset()
+    agent.overlap_streams = not args.no_overlap
     if rank != 0:
         return
     steps_per_s = args.steps / elapsed
-    achieved = g["flops"] / (g["ms"] * 1e-3) if g["ms"] > 0 else 0.0
+    g = {k: gt[k] + gs[k] for k in gt}
+    achieved = gt["flops"] / (gt["ms"] * 1e-3) if gt["ms"] > 0 else 0.0
+    family = g["flops"] / (g["ms"] * 1e-3) if g["ms"] > 0 else 0.0
+    traffic = None
+    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/README.md says how they were taken)
+        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["gemm_tile_kernel"]["bytes_per_launch"]
+    except Exception:
+        pass
     out = {
         "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -172,10 +191,17 @@ def main():
         "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
         "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * steps_per_s / 1e12,
         "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
-        "roofline": {"bound": "mfma", "kernel": "aid::gemm_{panel,tile}_kernel (fp32 MFMA GEMM family, all launches of one train_step)",
+        # dominant kernel = aid::gemm_tile_kernel (largest share of GPU time in profiles/); achieved = sum(2MNK) of its launches in one
+        # train_step / sum of their HIP-event durations (events on the launch stream)
+        "roofline": {"bound": "mfma", "kernel": "aid::gemm_tile_kernel<64,64> (fp32 MFMA; MINE / rollout / backward GEMMs with >= 160 tiles)",
                      "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA,
-                     "traffic": None, "launches_per_step": g["launches"], "gemm_ms_per_step": g["ms"], "flop_per_step": g["flops"],
-                     "optimizer_GBps": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None},
+                     "traffic": traffic, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"], "flop_per_step": gt["flops"],
+                     "flop_per_launch": gt["flops"] / max(gt["launches"], 1), "us_per_launch": 1e3 * gt["ms"] / max(gt["launches"], 1)},
+        "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step (tile + panel + split-K kernels)", "achieved": family / 1e12,
+                                 "frac": family / PEAK_F32_MFMA, "launches_per_step": g["launches"], "ms_per_step": g["ms"], "flop_per_step": g["flops"]},
+        "roofline_hbm": {"bound": "hbm", "kernel": "aid::adamw_kernel (clip + AdamW + EMA over the score arena)",
+                         "achieved": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (o["bytes"] / (o["ms"] * 1e-3) / 8e12) if o["ms"] > 0 else None},
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

@@ -45,7 +45,10 @@ const char* aid_last_error(void);
 int aid_prof_enable(int on);
 int aid_prof_reset(void);
 int aid_prof_read(int kernel_id, double out[4]);
-#define AID_PROF_GEMM 0
+/* One CSV line per recorded launch (kernel_id,M,N,K,layout,milliseconds): the in-situ per-shape timing the GEMM dispatcher is tuned from. */
+int aid_prof_dump(const char* path);
+#define AID_PROF_GEMM 0        /* fp32-MFMA GEMM launches routed to the small-problem kernels (panel / split-K / ring) */
+#define AID_PROF_GEMM_TILE 3   /* fp32-MFMA GEMM launches routed to gemm_tile_kernel (the dominant kernel of a train_step) */
 #define AID_PROF_ROWWISE 1
 #define AID_PROF_OPTIM 2
 
@@ -61,7 +64,8 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream);
-/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk */
+/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk,
+ * 7-13 gemm_big_kernel variants (tools/perf/big_gemm.py); bits 8+ select the XCD-grouped tile map of gemm_big_kernel */
 int aid_gemm_force_kernel(int k);
 
 /* ---- Philox fills (production RNG; parity tests pass explicit tensors instead) ---------------- */

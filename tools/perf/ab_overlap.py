@@ -1,0 +1,14 @@
+import sys, os, time
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R + "/active-inference-diffusion_amd"); sys.path.insert(0, R)
+import torch, bench
+agent = bench.make_agent(torch.device("cuda"))
+for _ in range(3): agent.train_step()
+def run(n=10):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): agent.train_step()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+for rep in range(3):
+    for ov in (False, True):
+        agent.overlap_streams = ov
+        run(2)
+        print(f"overlap={ov}: {run():.2f} ms/step", flush=True)

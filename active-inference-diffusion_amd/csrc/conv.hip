@@ -265,26 +265,48 @@ __global__ void attn_bwd_b_kernel(const float* __restrict__ da, const float* __r
     const float avg = d0 / (float)C; const int am = amax[i];
     for (int c = 0; c < C; ++c) dx[(size_t)c * B * H * W + i] += avg + (c == am ? d1 : 0.f);
 }
-// backward C (one workgroup): dW[2][7][7], dbias, dtemperature
-__global__ void attn_bwd_c_kernel(const float* __restrict__ da, const float* __restrict__ pool, const float* __restrict__ tpart, float* __restrict__ dw,
-                                  float* __restrict__ dbias, float* __restrict__ dtemp, int B, int H, int W) {
+// backward C: dW[2][7][7], dbias, dtemperature.  Stage 1: every workgroup reduces its slice of the B*H*W positions to 100 partial sums
+// (98 taps + dbias + dtemp); stage 2: one workgroup folds the partials in a fixed order (deterministic).
+constexpr int ATTN_C_PARTS = 512;
+__global__ void __launch_bounds__(256) attn_bwd_c_part_kernel(const float* __restrict__ da, const float* __restrict__ pool, const float* __restrict__ tpart,
+                                                              float* __restrict__ part /*[parts][100]*/, int B, int H, int W) {
     __shared__ float sh[16];
     const int n = B * H * W;
-    for (int t = 0; t < 98; ++t) {
-        const int ch = t / 49, ky = (t % 49) / 7, kx = t % 7;
-        float s = 0.f;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const int x0 = i % W, y0 = (i / W) % H, b = i / (W * H);
-            const int yy = y0 + ky - 3, xx = x0 + kx - 3;
-            if (yy >= 0 && yy < H && xx >= 0 && xx < W) s += da[i] * pool[(((size_t)b * 2 + ch) * H + yy) * W + xx];
-        }
-        const float tot = wg_sum256(s, sh);
-        if (threadIdx.x == 0) dw[t] += tot;
-    }
+    const int per = (n + gridDim.x - 1) / gridDim.x;
+    const int i0 = blockIdx.x * per, i1 = min(n, i0 + per);
+    float acc[98];
+#pragma unroll
+    for (int t = 0; t < 98; ++t) acc[t] = 0.f;
     float s0 = 0.f, s1 = 0.f;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) { s0 += da[i]; s1 += tpart[i]; }
+    for (int i = i0 + (int)threadIdx.x; i < i1; i += blockDim.x) {
+        const int x0 = i % W, y0 = (i / W) % H, b = i / (W * H);
+        const float g = da[i];
+        s0 += g; s1 += tpart[i];
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const float* pb = pool + ((size_t)b * 2 + ch) * H * W;
+#pragma unroll
+            for (int ky = 0; ky < 7; ++ky) {
+                const int yy = y0 + ky - 3;
+#pragma unroll
+                for (int kx = 0; kx < 7; ++kx) {
+                    const int xx = x0 + kx - 3;
+                    if (yy >= 0 && yy < H && xx >= 0 && xx < W) acc[(ch * 7 + ky) * 7 + kx] += g * pb[yy * W + xx];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 98; ++t) { const float tot = wg_sum256(acc[t], sh); if (threadIdx.x == 0) part[(size_t)blockIdx.x * 100 + t] = tot; }
     const float a0 = wg_sum256(s0, sh), a1 = wg_sum256(s1, sh);
-    if (threadIdx.x == 0) { dbias[0] += a0; dtemp[0] += a1; }
+    if (threadIdx.x == 0) { part[(size_t)blockIdx.x * 100 + 98] = a0; part[(size_t)blockIdx.x * 100 + 99] = a1; }
+}
+__global__ void attn_bwd_c_fold_kernel(const float* __restrict__ part, int parts, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dtemp) {
+    const int t = threadIdx.x;
+    if (t >= 100) return;
+    float s = 0.f;
+    for (int p = 0; p < parts; ++p) s += part[(size_t)p * 100 + t];
+    if (t < 98) dw[t] += s; else if (t == 98) dbias[0] += s; else dtemp[0] += s;
 }
 
 // ---- LayerNorm over F = 451 584 features, one workgroup per row -----------------------------------------------------------------------
@@ -475,7 +497,9 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
     float* dact = ws.f32(nact3); float* da = ws.f32((size_t)B * HW); float* tpart = ws.f32((size_t)B * HW);
     AID_WS_OK(ws);
     L1D(attn_bwd_a_kernel, B * HW, s, dxf, sv.act[3], sv.att, sv.apre, e.att_temperature, dact, da, tpart, 256, B, HW);
-    hipLaunchKernelGGL(attn_bwd_c_kernel, dim3(1), dim3(1024), 0, s, da, sv.pool, tpart, gr.att_conv_w, gr.att_conv_b, gr.att_temperature, B, Hh, Hh);
+    float* cpart = ws.f32((size_t)ATTN_C_PARTS * 100); AID_WS_OK(ws);
+    hipLaunchKernelGGL(attn_bwd_c_part_kernel, dim3(ATTN_C_PARTS), dim3(256), 0, s, da, sv.pool, tpart, cpart, B, Hh, Hh);
+    hipLaunchKernelGGL(attn_bwd_c_fold_kernel, dim3(1), dim3(128), 0, s, cpart, ATTN_C_PARTS, gr.att_conv_w, gr.att_conv_b, gr.att_temperature);
     AID_LAUNCH_CHECK();
     L1D(attn_bwd_b_kernel, B * HW, s, da, e.att_conv_w, sv.amax, dact, 256, B, Hh, Hh);
     // ---- conv stack, reverse

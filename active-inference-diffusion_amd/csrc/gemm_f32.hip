@@ -207,6 +207,52 @@ __global__ void __launch_bounds__(256) gemm_tile_kernel(GemmArgs g, int tiles_n)
 }
 
 // ------------------------------------------------------------------------------------------------
+// K <= 32 (the first layer of every network on the path: K = latent_dim / observation_dim = 17 at HalfCheetah sizes).
+// An MFMA tile kernel pads such a K to a 32-deep stage and pays its whole staging pipeline for a handful of FMAs; here
+// a 64x64 output tile per workgroup keeps both operand tiles (64 x K each) in LDS and every thread owns 4x4 outputs on
+// the f32 VALU.  The kernel is output-write bound (M*N*4 bytes), which is the right bound for this shape.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemm_smallk_kernel(GemmArgs g, int tiles_n) {
+    __shared__ float xs[64][33];
+    __shared__ float wsm[64][33];
+    const int tid = threadIdx.x;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 64, n0 = tn * 64, K = g.K;
+    for (int i = tid; i < 64 * K; i += 256) {
+        const int r = i / K, k = i % K;
+        xs[r][k] = (m0 + r < g.M) ? g.A[(size_t)(m0 + r) * g.lda + k] : 0.f;
+        wsm[r][k] = (n0 + r < g.N) ? g.B[(size_t)(n0 + r) * g.ldb + k] : 0.f;
+    }
+    __syncthreads();
+    const int tc = tid & 15, tr = tid >> 4;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k = 0; k < K; ++k) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = xs[tr + 16 * i][k];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) b[j] = wsm[tc + 16 * j][k];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) epilogue_store(g, m0 + tr + 16 * i, n0 + tc + 16 * j, acc[i][j]);
+}
+static int launch_smallk(const GemmArgs& g, hipStream_t s) {
+    const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
+    hipLaunchKernelGGL(gemm_smallk_kernel, dim3(tm * tn), dim3(256), 0, s, g, tn);
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Large-problem variant of the tile kernel with the K depth of a stage (BKT) and the workgroup->tile map as
 // parameters.  Shallower stages (BKT = 16) shrink the LDS image so that 128-row tiles still run 3-4 workgroups
 // per CU, and a 128-wide tile halves the bytes each CU must ingest per MFMA (the per-CU L2/MALL ingest rate, not

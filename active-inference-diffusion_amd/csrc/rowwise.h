@@ -37,6 +37,8 @@ int score_head(const float* raw, const float* mult, const float* t, int mode, fl
 
 // fused head + p_sample (diffusion.py:208-255) for one reverse step; coef = coefs + 5*step (device)
 //   s = clamp(raw)*mult*tw ; z0 = (z + c0*s)*c1 ; mean = c2*z0 + c3*z ; z' = mean + (step>0 ? c4*eps : 0)
+int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const float* mult, float t_value, int continuous, const float* coef,
+                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s);
 int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
                   const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
 

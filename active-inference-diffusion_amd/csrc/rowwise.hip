@@ -238,6 +238,47 @@ __global__ void head_p_sample_kernel(const float* __restrict__ raw, const float*
     zo[i] = v;
     if (traj) traj[i] = v;
 }
+// Fused last head layer + reverse step: raw = p0 . W2^T (no bias, K = D/2, N = L), then the head transform and p_sample above.
+// One wave per row: lanes split K, one butterfly reduction per output column (L is 17..128 on this path).
+__global__ void __launch_bounds__(256) head2_p_sample_kernel(const float* __restrict__ p0, int ldp, const float* __restrict__ W2, int Kp,
+                                                             const float* __restrict__ mult, float tv, int cont, const float* __restrict__ coef,
+                                                             int step, const float* __restrict__ z, const float* __restrict__ eps,
+                                                             float* __restrict__ zo, float* __restrict__ traj, float* __restrict__ raw_out,
+                                                             int M, int L) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* pr = p0 + (size_t)row * ldp;
+    for (int l0 = 0; l0 < L; l0 += 64) {
+        float mine = 0.f;
+        const int lend = (L - l0) < 64 ? (L - l0) : 64;
+        for (int l = 0; l < lend; ++l) {
+            const float* w = W2 + (size_t)(l0 + l) * Kp;
+            float acc = 0.f;
+            for (int k = lane; k < Kp; k += 64) acc = fmaf(pr[k], w[k], acc);
+            acc = wave_sum(acc);
+            if (lane == l) mine = acc;
+        }
+        if (lane < lend) {
+            const size_t i = (size_t)row * L + l0 + lane;
+            if (raw_out) raw_out[i] = mine;
+            float sc = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
+            if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
+            const float zt = z[i];
+            const float z0 = (zt + coef[0] * sc) * coef[1];
+            float v = coef[2] * z0 + coef[3] * zt;
+            if (step > 0) v += coef[4] * eps[i];
+            zo[i] = v;
+            if (traj) traj[i] = v;
+        }
+    }
+}
+int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const float* mult, float t_value, int continuous, const float* coef,
+                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s) {
+    hipLaunchKernelGGL(head2_p_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, s, p0, ldp, W2, Kp, mult, t_value, continuous, coef, step, z, eps,
+                       z_out, traj_out, raw_out, M, L);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
 int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
                   const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s) {
     const int n = M * L;

@@ -51,6 +51,6 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
 struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; };
 int score_fuse_attention(const AidScoreNet& n, Workspace& ws, ScoreFused& f, hipStream_t s);
 // latent_proj, DiT blocks, final adaLN, output_proj -> a.raw [B,L]
-int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused = nullptr);
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused = nullptr, bool skip_last = false);
 
 }  // namespace aid

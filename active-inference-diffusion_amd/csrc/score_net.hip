@@ -133,7 +133,7 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
     return score_cond_mod(n, B, temb, ld_temb, a, s);
 }
 
-int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused) {
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused, bool skip_last) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
     AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     for (int i = 0; i < n.n_blocks; ++i) {
@@ -153,7 +153,7 @@ int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool 
     }
     AID_TRY(adaln(a.h_last, D, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.nxf, D, a.st_f, B, D, s));
     AID_TRY(linear_fwd(a.nxf, D, n.op0_w, n.op0_b, a.p0, D / 2, B, D / 2, D, ACT_SILU, s, a.p0_pre));
-    AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
+    if (!skip_last) AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));   // else: fused into head2_p_sample
     return AID_OK;
 }
 
@@ -223,7 +223,7 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     if (!net || B <= 0 || n_steps <= 0) return 0;
     const size_t D = net->D, L = net->L, C = denoise_chunk_steps(*net, B, n_steps), NA = 2 * net->n_blocks + 1;
     size_t n = score_acts_bytes(*net, B > n_steps ? B : n_steps, false);
-    n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D));
+    n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D) + (size_t)n_steps * B * L);
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
     return n + (1 << 16);
@@ -282,7 +282,7 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* temb_table = ws.f32((size_t)N * D);
     float* zA = ws.f32((size_t)B * L);
     float* zB = ws.f32((size_t)B * L);
-    float* eps_buf = ws.f32((size_t)B * L);
+    float* eps_own = step_noise ? nullptr : ws.f32((size_t)N * B * L);   // device-Philox mode: every step's noise in ONE fill
     float* re_buf = ws.f32((size_t)B * L);
     int* nan_flag = (int*)ws.raw(256);
     float* o2_shared = ws.f32((size_t)B * D);
@@ -312,6 +312,8 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
         AID_TRY(linear_fwd(a.x2, D, n.oe7_w, n.oe7_b, o2_shared, D, B, D, D, ACT_NONE, s));
     }
     uint64_t ctr = offset;
+    const float* eps_all = step_noise;
+    if (!eps_all) { AID_TRY(philox_fill(eps_own, (size_t)N * B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)N * B * L + 3) / 4; eps_all = eps_own; }
     if (z_init) AID_TRY(copy_f32(z_init, zA, (size_t)B * L, s));
     else { AID_TRY(philox_fill(zA, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; }
     if (traj) AID_TRY(copy_f32(zA, traj, (size_t)B * L, s));
@@ -345,16 +347,12 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
         // ---- the z-dependent part, step by step
         for (int t = t_hi; t >= t_lo; --t) {
             a.mod = mod_all + (size_t)(t - t_lo) * B * ldmod;
-            AID_TRY(score_trunk(n, B, z, a, false, s, &fused));
-            const float* eps = nullptr;
-            if (t > 0) {
-                eps = step_noise ? step_noise + (size_t)t * B * L : nullptr;
-                if (!eps) { AID_TRY(philox_fill(eps_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; eps = eps_buf; }
-            }
+            AID_TRY(score_trunk(n, B, z, a, false, s, &fused, true));
+            const float* eps = (t > 0) ? eps_all + (size_t)t * B * L : nullptr;
             float* dst = (t == 0) ? z_out : zn;
             const float tval = collector ? (float)t / (float)collector_max_index : (float)t;
-            AID_TRY(head_p_sample(a.raw, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
-                                  traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
+            AID_TRY(head2_p_sample(a.p0, D / 2, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
+                                   traj ? traj + (size_t)(N - t) * B * L : nullptr, nullptr, B, L, s));
             if (collector) {   // whole-batch NaN/Inf re-initialisation, decided on device (a host sync in the reference)
                 const float* rn = reinit_noise ? reinit_noise + (size_t)t * B * L : nullptr;
                 if (!rn) { AID_TRY(philox_fill(re_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; rn = re_buf; }

@@ -10,8 +10,9 @@ rollout + policy BPTT, value and dynamics updates, four fused clip/AdamW/EMA ste
 parallel: every rank owns a replay shard and a 256-row minibatch, gradients are averaged with one RCCL all-reduce per
 optimiser group.  `value` = batch-256 train steps per second summed over ranks.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the dominant kernel, aid::gemm_tile_kernel, measured live with HIP
-events through aid_prof_*; `roofline_gemm_family` = every GEMM launch, `roofline_hbm` = the optimiser kernel), `cpu_baseline`
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the kernel family with the largest share of GPU time, measured live with
+HIP events through aid_prof_*; `roofline_second_kernel`, `roofline_gemm_family` = every GEMM launch, `roofline_hbm` = the optimiser
+kernel), `cpu_baseline`
 (the oracle's train_step timed on the host cores, rank 0, N=1 only).
 """
 import argparse
@@ -173,13 +174,28 @@ def main():
         return
     steps_per_s = args.steps / elapsed
     g = {k: gt[k] + gs[k] for k in gt}
-    achieved = gt["flops"] / (gt["ms"] * 1e-3) if gt["ms"] > 0 else 0.0
-    family = g["flops"] / (g["ms"] * 1e-3) if g["ms"] > 0 else 0.0
-    traffic = None
-    try:   # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/README.md says how they were taken)
-        traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["gemm_tile_kernel"]["bytes_per_launch"]
+    tf = lambda d: (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0
+    pmc = {}
+    try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md: how they were taken and corrected)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
     except Exception:
         pass
+    def traffic(prefix):
+        for k, v in pmc.items():
+            if k.startswith(prefix) and "fetch_bytes_per_launch_corrected" in v:
+                return v["fetch_bytes_per_launch_corrected"] + v.get("write_bytes_per_launch", 0.0)
+        return None
+    # The kernel with the largest share of GPU time (profiles/r01_train_step_kernel_stats.csv) is the small-problem GEMM kernel of the
+    # reverse-diffusion loops (gemm_panel_kernel + its split-K / ring siblings: every GEMM launch with < 160 64x64 tiles).
+    small = {"bound": "mfma", "kernel": "aid::gemm_panel_kernel family (fp32 MFMA, batch-256/512 layers of the reverse loops, ELBO and BPTT)",
+             "achieved": tf(gs), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tf(gs) * 1e12 / PEAK_F32_MFMA,
+             "traffic": traffic("gemm_panel_kernel<false, false>"), "launches_per_step": gs["launches"], "ms_per_step": gs["ms"],
+             "flop_per_launch": gs["flops"] / max(gs["launches"], 1), "us_per_launch": 1e3 * gs["ms"] / max(gs["launches"], 1),
+             "note": "per-CU ingest/latency-bound at M<=512 (DESIGN.md section 4); achieved = sum(2MNK)/sum(HIP-event durations) of these launches"}
+    big = {"bound": "mfma", "kernel": "aid::gemm_big_kernel / gemm_tile_kernel (fp32 MFMA, >= 160 tiles: MINE, hoisted conditioning, rollout)",
+           "achieved": tf(gt), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tf(gt) * 1e12 / PEAK_F32_MFMA,
+           "traffic": traffic("gemm_big_kernel"), "launches_per_step": gt["launches"], "ms_per_step": gt["ms"],
+           "flop_per_launch": gt["flops"] / max(gt["launches"], 1), "us_per_launch": 1e3 * gt["ms"] / max(gt["launches"], 1)}
     out = {
         "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -191,14 +207,10 @@ def main():
         "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
         "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * steps_per_s / 1e12,
         "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
-        # dominant kernel = aid::gemm_tile_kernel (largest share of GPU time in profiles/); achieved = sum(2MNK) of its launches in one
-        # train_step / sum of their HIP-event durations (events on the launch stream)
-        "roofline": {"bound": "mfma", "kernel": "aid::gemm_tile_kernel<64,64> (fp32 MFMA; MINE / rollout / backward GEMMs with >= 160 tiles)",
-                     "achieved": achieved / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": achieved / PEAK_F32_MFMA,
-                     "traffic": traffic, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"], "flop_per_step": gt["flops"],
-                     "flop_per_launch": gt["flops"] / max(gt["launches"], 1), "us_per_launch": 1e3 * gt["ms"] / max(gt["launches"], 1)},
-        "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step (tile + panel + split-K kernels)", "achieved": family / 1e12,
-                                 "frac": family / PEAK_F32_MFMA, "launches_per_step": g["launches"], "ms_per_step": g["ms"], "flop_per_step": g["flops"]},
+        "roofline": small if gs["ms"] >= gt["ms"] else big,
+        "roofline_second_kernel": big if gs["ms"] >= gt["ms"] else small,
+        "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step", "achieved": tf(g), "frac": tf(g) * 1e12 / PEAK_F32_MFMA,
+                                 "launches_per_step": g["launches"], "ms_per_step": g["ms"], "flop_per_step": g["flops"]},
         "roofline_hbm": {"bound": "hbm", "kernel": "aid::adamw_kernel (clip + AdamW + EMA over the score arena)",
                          "achieved": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": (o["bytes"] / (o["ms"] * 1e-3) / 8e12) if o["ms"] > 0 else None},

@@ -183,3 +183,15 @@ def test_collector_sampling_golden(nat, golden_dir, tag):
     ref = orc.collector_sampling(p, orc.schedule_tables(N), torch.from_numpy(g["obs"]),
                                  type("R", (), {"randn": staticmethod(lambda *s, _it=iter([z_bad, eps[2], rn[2], eps[1]]): next(_it))})(), steps, N, False)
     np.testing.assert_allclose(out2.cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 512, 17), (256, 512, 11), (100, 70, 3), (2560, 128, 17), (64, 64, 32), (1, 1, 1)])
+def test_gemm_small_k_route(nat, M, N, K):
+    """K <= 32 problems go to the VALU small-K kernel: same result as the fp64 product, with the fused epilogue."""
+    ns = NoiseStream(77)
+    A, W, b, res = ns.randn(M, K), ns.randn(N, K), ns.randn(N), ns.randn(M, N)
+    C = torch.empty(M, N, device="cuda")
+    nat.gemm(dev(A), dev(W), C, M, N, K, K, K, N, bias=dev(b), act="silu", residual=dev(res), ldr=N)
+    pre = A.astype(np.float64) @ W.astype(np.float64).T + b
+    ref = pre / (1 + np.exp(-pre)) + res
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)

@@ -36,7 +36,7 @@ def hopper():
 
 
 def pixel():
-    L, A, B = 50, 6, 256
+    L, A, B = 128, 6, 256
     cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=5, latent_dim=L, hidden_dim=512, pixel_observation=True)
     cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=50)
 
@@ -59,7 +59,7 @@ def pixel():
     for _ in range(5):
         enc.backward(d, ctx)
     torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / 5
-    print(json.dumps({"config": "cfg4 pixel 84x84x9 B=256 H=5 N=50 L=50", "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "encoder_fwd_ms": tf * 1e3,
+    print(json.dumps({"config": "cfg4 pixel 84x84x9 B=256 H=5 N=50 L=128", "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "encoder_fwd_ms": tf * 1e3,
                       "encoder_bwd_ms": tb * 1e3, "finite": bool(all(np.isfinite(v) for v in m.values())), "mem_GB": torch.cuda.max_memory_allocated() / 1e9}))
 
 

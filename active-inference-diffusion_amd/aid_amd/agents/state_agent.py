@@ -59,35 +59,46 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             parallel.broadcast_arena_(a.flat)
         self.active_inference.arenas["score"].reset_ema()
         self.active_inference.noise.seed += 7919 * parallel.rank()   # independent device-RNG streams per rank
+        self.active_inference.param_version += 1
 
     # ------------------------------------------------------------------------------------------------
     def train_step(self) -> Dict[str, float]:
         """One update of all four groups (state_agent.py:110-243).  Phases: minibatch gather -> reward normalisation ->
-        belief latents for obs and next_obs (ONE merged 2B-row reverse-diffusion loop) -> ELBO step (score group) ->
-        EFE step (policy) -> third belief update + lambda-returns + Huber (value) -> MSE (dynamics).
-        The epistemic-estimator training branch (`total_steps % 5 == 0`) cannot run in the reference and is
-        skipped.  Metrics are read back from the device once, at the end."""
+        belief latents for obs and next_obs -> ELBO step (score group) -> EFE step (policy) -> third belief update +
+        lambda-returns + Huber (value) -> MSE (dynamics).  The epistemic-estimator training branch (`total_steps % 5 == 0`)
+        cannot run in the reference and is skipped.  Metrics are read back from the device once, at the end.
+
+        Scheduling (results unchanged): the reference's training loop runs hundreds of train_steps back to back on a fixed
+        replay buffer (examples/train_mujoco.py:332-336).  The third belief update of step i and the two belief updates that open
+        step i+1 use the SAME score parameters (the ones just updated), so step i draws step i+1's minibatch right after its own
+        third-belief draws - the reference's draw order - and runs all three belief updates as ONE 3B-row reverse loop on a side
+        stream underneath its EFE/MINE phase.  Step i+1 consumes the prefetched latents iff nothing they depend on has changed
+        (replay-buffer version, score-parameter version, batch size, train mode); otherwise it recomputes them.  After a miss the
+        prefetch backs off exponentially, so a train-once-per-env-step loop pays (almost) nothing for it."""
         cfg, ai = self.config, self.active_inference
         B = cfg.batch_size
         if len(self.replay_buffer) < B:
             return {}
-        batch = self.replay_buffer.sample(B)
+        dp = parallel.is_dp()
+        main = torch.cuda.current_stream()
+        pre = self._take_prefetch(B)
+        if pre is not None:
+            batch, both = pre
+        else:
+            batch = self.replay_buffer.sample(B)
+            both = ai.denoise_pair(batch["observations"], batch["next_observations"])
         obs, actions, rewards = batch["observations"], batch["actions"], batch["rewards"]
         next_obs, dones = batch["next_observations"], batch["dones"]
-        dp = parallel.is_dp()
         nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
-        # 1. latents via reverse diffusion (no gradients): obs and next_obs share one 2B-row loop
-        both = ai.denoise_pair(obs, next_obs)
         latents = both[:B]
         # 2. score / diffusion group: ELBO forward + backward on the main stream
         self.score_optimizer.zero_grad()
         elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents)
-        main = torch.cuda.current_stream()
         if self.overlap_streams:
             # The policy phase reads no score-network parameter, and the value phase needs a fresh belief over next_obs from
-            # the UPDATED score network (state_agent.py:194-205).  So: [gradient all-reduce ->] score step -> third reverse
-            # loop run on a side stream underneath the EFE/MINE phase.  The loop's batch-256 kernels are latency-bound and
-            # leave most CUs idle; the 25 600-row MINE GEMMs fill them.  Same arithmetic, same draw order (EFE, then belief).
+            # the UPDATED score network (state_agent.py:194-205).  So: [gradient all-reduce ->] score step -> reverse loop run on a
+            # side stream underneath the EFE/MINE phase.  The loop's batch-256 kernels are latency-bound and leave most CUs idle;
+            # the 25 600-row MINE GEMMs fill them.  Same arithmetic, same draw order (EFE, then belief).
             elbo_done = torch.cuda.Event(); elbo_done.record(main)
         else:
             self.score_optimizer.step()
@@ -95,17 +106,32 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
-        # 4. value (targets from a re-sampled next-latent belief)
+        # 4. value (targets from a re-sampled next-latent belief) [+ the two belief updates of the next step]
+        side = self._comm_stream() if self.overlap_streams else main
         if self.overlap_streams:
-            side = self._comm_stream()
             side.wait_event(elbo_done)
-            with torch.cuda.stream(side):
+        with torch.cuda.stream(side):
+            if self.overlap_streams:
                 self.score_optimizer.step()            # data parallel: the 109 MB RCCL all-reduce runs here, off the critical path
-                next_latents = ai.denoise_only(next_obs, ws=self._side_workspace())
+            ws = self._side_workspace() if self.overlap_streams else None
+            if self._want_prefetch():
+                N, train = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
+                hook = lambda: ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
+                n3 = hook()                                        # draws of the third belief update ...
+                nxt = self.replay_buffer.sample(B)                 # ... then the next step's index draw and its two belief updates
+                tri = ai.denoise_many([next_obs, nxt["observations"], nxt["next_observations"]], [n3, hook(), hook()], ws=ws)
+                next_latents = tri[:B]
+                self._prefetch = {"batch": nxt, "latents": tri[B:], "buffer": (id(self.replay_buffer), self.replay_buffer.version),
+                                  "params": (self.score_optimizer.arena.step_count, ai.param_version), "B": B, "train": train}
+            else:
+                next_latents = ai.denoise_only(next_obs, ws=ws)
+        if self.overlap_streams:
             next_latents.record_stream(main)
+            if self._prefetch is not None:
+                self._prefetch["latents"].record_stream(main)
+                for v in self._prefetch["batch"].values():
+                    v.record_stream(main)
             main.wait_stream(side)
-        else:
-            next_latents = ai.denoise_only(next_obs)
         self.value_optimizer.zero_grad()
         value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
                                        cfg.discount_factor, 0.95, 5, ws=ai._ws)
@@ -125,3 +151,37 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         metrics.update({"num_trajectories": efe_info["num_trajectories"], "horizon": efe_info["horizon"]})
         self._last = {"latents": latents, "next_latents": next_latents}
         return metrics
+
+    # -- cross-step prefetch of the next minibatch's belief latents ------------------------------------------------------------
+    prefetch_next_batch = True     # False: never look ahead (every train_step samples and denoises its own minibatch)
+    _prefetch = None
+    _prefetch_backoff = 0          # train_steps to wait before trying again after an unused prefetch
+    _prefetch_wait = 0
+
+    def _want_prefetch(self) -> bool:
+        self._prefetch = None
+        if not self.prefetch_next_batch:
+            return False
+        if self._prefetch_wait > 0:
+            self._prefetch_wait -= 1
+            return False
+        return True
+
+    def _take_prefetch(self, B: int):
+        """The prefetched (minibatch, latents) if they are exactly what this step would compute, else None."""
+        pre, self._prefetch = self._prefetch, None
+        if pre is None:
+            return None
+        ai = self.active_inference
+        ok = (pre["buffer"] == (id(self.replay_buffer), self.replay_buffer.version) and pre["B"] == B and
+              pre["params"] == (self.score_optimizer.arena.step_count, ai.param_version) and pre["train"] == ai.latent_score_network.training)
+        if ok:
+            self._prefetch_backoff = 0
+            return pre["batch"], pre["latents"]
+        self._prefetch_backoff = min(64, max(1, 2 * self._prefetch_backoff))
+        self._prefetch_wait = self._prefetch_backoff
+        return None
+
+    def invalidate_prefetch(self):
+        """Call after changing score-network parameters by hand (load_state_dict and the optimisers do it themselves)."""
+        self._prefetch = None

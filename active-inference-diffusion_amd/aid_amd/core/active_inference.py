@@ -94,6 +94,7 @@ class DiffusionActiveInference(nn.Module):
         self._to_device_and_flatten(self.device)
         self.current_latent, self.latent_trajectory = None, []
         self._ws = nat.Workspace(self.device)
+        self.param_version = 0          # bumped whenever parameters change outside an optimiser step (load_state_dict, broadcast)
 
     # ------------------------------------------------------------------------------------------ construction
     def _build_models(self):
@@ -179,6 +180,7 @@ class DiffusionActiveInference(nn.Module):
             self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
         self.arenas["score"].reset_ema()
         self.latent_diffusion._coefs = None
+        self.param_version += 1
         return out
 
     # ------------------------------------------------------------------------------------------ tables
@@ -240,22 +242,26 @@ class DiffusionActiveInference(nn.Module):
                                 noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
                                 offset=self.noise.next_offset(), ws=ws or self._ws)
 
-    def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
-        """Two independent belief updates (state_agent.py:135-140) as ONE reverse loop over 2B rows: the batch-256 layers are
-        latency-bound, so doubling the rows per launch is nearly free.  Returns [2B, L] (rows of obs_a first)."""
-        B, N, train = obs_a.shape[0], self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
-        if noise_a is None:
-            noise_a = self.noise.belief(B, self.latent_dim, self.config.hidden_dim, N, train)
-            noise_b = self.noise.belief(B, self.latent_dim, self.config.hidden_dim, N, train)
+    def denoise_many(self, obs_list, noises=None, ws=None) -> torch.Tensor:
+        """Several independent belief updates as ONE reverse loop over the concatenated rows (the batch-256 layers are latency-bound:
+        512 rows cost 1.4x the time of 256, 768 rows 2x).  `noises`: one hook result per entry (parity tests), or None => the
+        NoiseSource is asked once per entry, in order.  Returns [sum(rows), L], rows of obs_list[0] first."""
+        N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
+        if noises is None:
+            noises = [self.noise.belief(o.shape[0], self.latent_dim, self.config.hidden_dim, N, train) for o in obs_list]
         noise = {}
-        if noise_a is not None:
+        if noises[0] is not None:
             for k, dim in (("z_init", 0), ("step_noise", 1), ("drop_masks", 1)):
-                if noise_a.get(k) is not None:
-                    noise[k] = torch.cat([noise_a[k], noise_b[k]], dim=dim).contiguous()
-        obs = torch.cat([obs_a.to(self.device).float(), obs_b.to(self.device).float()], dim=0).contiguous()
+                if noises[0].get(k) is not None:
+                    noise[k] = torch.cat([n[k] for n in noises], dim=dim).contiguous()
+        obs = torch.cat([o.to(self.device).float() for o in obs_list], dim=0).contiguous()
         return nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), obs, N, noise.get("z_init"),
                                 noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
-                                offset=self.noise.next_offset(), ws=self._ws)
+                                offset=self.noise.next_offset(), ws=ws or self._ws)
+
+    def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
+        """Two independent belief updates (state_agent.py:135-140) as one 2B-row loop.  Returns [2B, L] (rows of obs_a first)."""
+        return self.denoise_many([obs_a, obs_b], None if noise_a is None else [noise_a, noise_b])
 
     # ------------------------------------------------------------------------------------------ A8 / A10
     def compute_expected_free_energy_diffusion(self, latent: torch.Tensor, horizon: int = 5, num_trajectories: int = 10,

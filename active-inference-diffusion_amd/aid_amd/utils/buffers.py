@@ -20,6 +20,7 @@ class ReplayBuffer:
     def __init__(self, capacity: int, obs_shape: Tuple[int, ...], action_dim: int, device, optimize_memory: bool = False):
         self.capacity, self.device, self.obs_shape = int(capacity), torch.device(device), tuple(obs_shape)
         self.pos = self.size = 0
+        self.version = 0            # bumped by every insertion (train_step's cross-step prefetch checks it)
         self.compress, self.dtype = False, np.float32
         obs_dim = int(np.prod(obs_shape))
         self._obs_dim, self.action_dim = obs_dim, action_dim
@@ -37,6 +38,7 @@ class ReplayBuffer:
         self.dones[i] = float(bool(done))
         self.pos = (self.pos + 1) % self.capacity
         self.size = min(self.size + 1, self.capacity)
+        self.version += 1
 
     def add_batch(self, obs, actions, rewards, next_obs, dones):
         """Bulk insert (synthetic-replay benches, vectorised collectors): one H->D copy per field."""
@@ -48,6 +50,7 @@ class ReplayBuffer:
         self.rewards[idx] = f(rewards).reshape(n); self.dones[idx] = f(dones).reshape(n)
         self.pos = (self.pos + n) % self.capacity
         self.size = min(self.size + n, self.capacity)
+        self.version += 1
 
     def sample(self, batch_size: int) -> Dict[str, torch.Tensor]:
         idx = self.index_source.replay_indices(self.size, batch_size) if self.index_source is not None else None

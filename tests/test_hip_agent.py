@@ -53,6 +53,7 @@ def test_state_dict_layout_and_golden_train_steps(golden_dir, tag):
         agent.replay_buffer.add(store["observations"][i], store["actions"][i], float(store["rewards"][i]), store["next_observations"][i], bool(store["dones"][i]))
     pn = ParityNoise(0)
     ai.noise = pn; agent.replay_buffer.index_source = pn
+    agent.prefetch_next_batch = False      # the goldens re-key the noise stream per train_step; the prefetch draws across step boundaries
     for step in (1, 2):
         pn.rekey(int(g[f"ts{step}_key"]))
         m = agent.train_step()
@@ -129,3 +130,43 @@ def test_act_and_philox_train_step_run():
     assert np.isfinite(info["expected_free_energy"]) and info["latent"].shape == (1, O)
     import aid_amd.agents as ag
     assert ag.StateBasedAgent is ag.DiffusionStateAgent
+
+
+def test_cross_step_prefetch_equals_reference_order():
+    """Three back-to-back train_steps with the next-minibatch prefetch ON (step i runs its third belief update together with step
+    i+1's two, on the side stream) against the oracle stepping in the reference's order on ONE continuous noise stream; then the
+    guards: an insertion into the replay buffer or a load_state_dict makes the next step discard the prefetched latents."""
+    O, A, D, N, H, B = 17, 6, 64, 4, 2, 8
+    agent = _agent(O, A, D, N, H, B)
+    ai = agent.active_inference
+    specs = param_specs(O, A, O, D, N)
+    p = draw_params(specs, 77, orc.schedule_tables(N))
+    sd0 = ai.state_dict()
+    ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+    bs = NoiseStream(9); cap = 64
+    store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32), "rewards": bs.randn(cap),
+             "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+    agent.replay_buffer.add_batch(store["observations"], store["actions"], store["rewards"], store["next_observations"], store["dones"])
+    pn = ParityNoise(4242); ai.noise = pn; agent.replay_buffer.index_source = pn
+    assert agent.prefetch_next_batch
+    st = orc.OracleAgentState(p, N); ns = NoiseStream(4242)
+    for step in range(3):
+        m = agent.train_step()
+        assert (agent._prefetch is not None) and (step == 0 or agent._prefetch_backoff == 0)
+        m_ref = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
+        for k, v in m_ref.items():
+            if k in m and isinstance(v, float):
+                np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=f"step {step} {k}")
+    sd = ai.state_dict()
+    for n, _ in specs:
+        if n == "epistemic_estimator.running_mean":
+            continue
+        np.testing.assert_allclose(sd[n].cpu().numpy(), st.p[n].detach().numpy(), rtol=2e-3, atol=3e-6, err_msg=n)
+    # guards
+    agent.replay_buffer.add(store["observations"][0], store["actions"][0], 0.0, store["next_observations"][0], False)
+    assert agent._take_prefetch(B) is None and agent._prefetch_wait == 1
+    agent.train_step()                                   # backoff: this step does not prefetch
+    assert agent._prefetch is None
+    agent.train_step(); assert agent._prefetch is not None
+    ai.load_state_dict(ai.state_dict())
+    assert agent._take_prefetch(B) is None

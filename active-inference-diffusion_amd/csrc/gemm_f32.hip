@@ -268,37 +268,41 @@ struct TileK {
     static constexpr int F4 = ROWS * BKT / 4;
 };
 
+// Branch-free: every lane always loads from an in-range (clamped) address; out-of-range values are zeroed when the tile is written
+// to LDS (store_tile_k), i.e. only once the data is needed.  A branch around a load - or a select on the loaded value next to the
+// load - makes hipcc wait for the whole vector-memory queue (`s_waitcnt vmcnt(0)`) far too early, which would serialise the
+// two-tile-deep prefetch below (cdna_hip_programming.md, "Projection GEMM at M = 256", trap 4c).
 template <int ROWS, bool KMAJOR, int BKT, int NT, int P>
 __device__ __forceinline__ void load_tile_k(const float* __restrict__ G, int ld, int r0, int k0, int R, int K, int tid, f32x4 (&regs)[P]) {
+    static_assert(TileK<ROWS, KMAJOR, BKT>::F4 % NT == 0, "tile must be a whole number of float4 per thread");
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int f = tid + NT * i;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (f < TileK<ROWS, KMAJOR, BKT>::F4) {
-            if (!KMAJOR) {
-                const int row = f / (BKT / 4), kq = f % (BKT / 4);
-                const int gr = r0 + row, gk = k0 + 4 * kq;
-                if (gr < R && gk < K) v = *reinterpret_cast<const f32x4*>(G + (size_t)gr * ld + gk);
-            } else {
-                const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
-                const int gk = k0 + k, gr = r0 + 4 * rq;
-                if (gk < K && gr < R) v = *reinterpret_cast<const f32x4*>(G + (size_t)gk * ld + gr);
-            }
+        const float* p;
+        if (!KMAJOR) {
+            const int row = f / (BKT / 4), kq = f % (BKT / 4);
+            const int gr = r0 + row, gk = k0 + 4 * kq;
+            p = G + (size_t)(gr < R ? gr : R - 1) * ld + (gk < K ? gk : 0);
+        } else {
+            const int k = f / (ROWS / 4), rq = f % (ROWS / 4);
+            const int gk = k0 + k, gr = r0 + 4 * rq;
+            p = G + (size_t)(gk < K ? gk : K - 1) * ld + (gr < R ? gr : 0);
         }
-        regs[i] = v;
+        regs[i] = *reinterpret_cast<const f32x4*>(p);
     }
 }
 template <int ROWS, bool KMAJOR, int BKT, int NT, int P>
-__device__ __forceinline__ void store_tile_k(float* __restrict__ S, int tid, const f32x4 (&regs)[P]) {
+__device__ __forceinline__ void store_tile_k(float* __restrict__ S, int r0, int k0, int R, int K, int tid, const f32x4 (&regs)[P]) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const int f = tid + NT * i;
-        if (f < TileK<ROWS, KMAJOR, BKT>::F4) {
-            int off;
-            if (!KMAJOR) { const int row = f / (BKT / 4), kq = f % (BKT / 4); off = row * TileK<ROWS, KMAJOR, BKT>::LD + 4 * kq; }
-            else { const int k = f / (ROWS / 4), rq = f % (ROWS / 4); off = k * TileK<ROWS, KMAJOR, BKT>::LD + 4 * rq; }
-            *reinterpret_cast<f32x4*>(S + off) = regs[i];
-        }
+        int off; bool ok;
+        if (!KMAJOR) { const int row = f / (BKT / 4), kq = f % (BKT / 4); off = row * TileK<ROWS, KMAJOR, BKT>::LD + 4 * kq;
+                       ok = (r0 + row < R) && (k0 + 4 * kq < K); }
+        else { const int k = f / (ROWS / 4), rq = f % (ROWS / 4); off = k * TileK<ROWS, KMAJOR, BKT>::LD + 4 * rq;
+               ok = (k0 + k < K) && (r0 + 4 * rq < R); }
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(S + off) = ok ? regs[i] : z;
     }
 }
 template <int ROWS, bool KMAJOR, int BKT>
@@ -369,8 +373,8 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
         f32x4 ra[PA], rb[PB];
         load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
         load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
-        store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra);
-        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, 0, g.M, g.K, tid, ra);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, 0, g.N, g.K, tid, rb);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
@@ -380,8 +384,8 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
             }
             contract(cur);
             if (kt + 1 < nk) {
-                store_tile_k<BM, AKM, BKT, NT, PA>(As + (cur ^ 1) * TA::FLOATS, tid, ra);
-                store_tile_k<BN, BKM, BKT, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, tid, rb);
+                store_tile_k<BM, AKM, BKT, NT, PA>(As + (cur ^ 1) * TA::FLOATS, m0, (kt + 1) * BKT, g.M, g.K, tid, ra);
+                store_tile_k<BN, BKM, BKT, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, n0, (kt + 1) * BKT, g.N, g.K, tid, rb);
             }
             __syncthreads();
         }
@@ -394,24 +398,28 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
         load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb0);
         load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, BKT, g.M, g.K, tid, ra1);     // rows beyond K come back as zeros
         load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, BKT, g.N, g.K, tid, rb1);
-        store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra0);
-        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb0);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, 0, g.M, g.K, tid, ra0);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, 0, g.N, g.K, tid, rb0);
         __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
+        // An odd tile count runs one extra all-zero tile (loads beyond K come back as zeros) instead of leaving the loop half way:
+        // an exit between the two halves makes the compiler shuttle the accumulators between two register banks every iteration.
+        const int nk2 = (nk + 1) & ~1;
+        for (int kt = 0; kt < nk2; kt += 2) {
             // even step: LDS[0] holds tile kt, set 1 holds tile kt+1 (in flight), set 0 is free
             load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 2) * BKT, g.M, g.K, tid, ra0);
             load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 2) * BKT, g.N, g.K, tid, rb0);
+            __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the store)
             contract(0);
-            store_tile_k<BM, AKM, BKT, NT, PA>(As + TA::FLOATS, tid, ra1);
-            store_tile_k<BN, BKM, BKT, NT, PB>(Bs + TB::FLOATS, tid, rb1);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As + TA::FLOATS, m0, (kt + 1) * BKT, g.M, g.K, tid, ra1);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs + TB::FLOATS, n0, (kt + 1) * BKT, g.N, g.K, tid, rb1);
             __syncthreads();
-            if (kt + 1 >= nk) break;
             // odd step: LDS[1] holds tile kt+1, set 0 holds tile kt+2 (in flight), set 1 is free
             load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 3) * BKT, g.M, g.K, tid, ra1);
             load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 3) * BKT, g.N, g.K, tid, rb1);
+            __builtin_amdgcn_sched_barrier(0);
             contract(1);
-            store_tile_k<BM, AKM, BKT, NT, PA>(As, tid, ra0);
-            store_tile_k<BN, BKM, BKT, NT, PB>(Bs, tid, rb0);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, (kt + 2) * BKT, g.M, g.K, tid, ra0);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, (kt + 2) * BKT, g.N, g.K, tid, rb0);
             __syncthreads();
         }
     }
@@ -835,6 +843,10 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): same 64x64x32 tile with prefetch distance 2 and the
     // XCD-grouped tile map (+3..20 % on these shapes, profiles/gemm_big_r01.txt); below that the plain kernel is as fast.
     if (g_force_kernel == 0 && vec && t64a >= 2048 && g.K >= 64) { const int keep = g_big_map; g_big_map = 1;
+        const int r = launch_big<64, 64, 32, AKM, BKM, 2>(g, s); g_big_map = keep; return r; }
+    // 160..2047 tiles: the same branch-free, two-tile-deep kernel with the plain tile map (gemm_tile_kernel stays for unaligned
+    // operands, K < 64 and the deterministic slab split-K mode)
+    if (g_force_kernel == 0 && t64a >= 160 && vec && g.K >= 64) { const int keep = g_big_map; g_big_map = 0;
         const int r = launch_big<64, 64, 32, AKM, BKM, 2>(g, s); g_big_map = keep; return r; }
     if (g_force_kernel == 0 && t64a >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
     {

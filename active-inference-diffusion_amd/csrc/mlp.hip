@@ -35,9 +35,10 @@ int lla_alloc(int M, int out, Workspace& ws, LlaSave& sv) {
     sv.lin = ws.f32((size_t)M * out); sv.stats = ws.f32((size_t)M * 2); sv.y = ws.f32((size_t)M * out);
     return AID_OK;
 }
-int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, const float* x, int ldx, int M, LlaSave& sv, hipStream_t s) {
+int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, const float* x, int ldx, int M, LlaSave& sv, hipStream_t s,
+            const float* add) {
     AID_TRY(linear_fwd(x, ldx, l.w, l.b, sv.lin, l.out, M, l.out, l.in, ACT_NONE, s));
-    AID_TRY(ln_act(sv.lin, l.out, ln.g, ln.b, act, mask, sv.y, l.out, sv.stats, M, l.out, s));
+    AID_TRY(ln_act(sv.lin, l.out, ln.g, ln.b, act, mask, sv.y, l.out, sv.stats, M, l.out, s, add));
     return AID_OK;
 }
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
@@ -89,8 +90,7 @@ int decoder_fwd(const AidDecoderNet& d, int M, const float* z, int ldz, const fl
     lla_alloc(M, d.s[0].out, ws, s0); lla_alloc(M, d.s[1].out, ws, s1); lla_alloc(M, d.s[2].out, ws, s2);
     AID_WS_OK(ws);
     AID_TRY(lla_fwd(d.s[0], d.ln[0], ACT_SILU, masks ? masks[0] : nullptr, z, ldz, M, s0, s));
-    AID_TRY(lla_fwd(d.s[1], d.ln[1], ACT_SILU, masks ? masks[1] : nullptr, s0.y, d.s[0].out, M, s1, s));
-    AID_TRY(add_inplace(s1.y, s0.y, (size_t)M * d.s[1].out, s));   // h2 = h2 + h1 (skip, :240)
+    AID_TRY(lla_fwd(d.s[1], d.ln[1], ACT_SILU, masks ? masks[1] : nullptr, s0.y, d.s[0].out, M, s1, s, s0.y));   // h2 = stage(h1) + h1 (skip, :240)
     AID_TRY(lla_fwd(d.s[2], d.ln[2], ACT_SILU, masks ? masks[2] : nullptr, s1.y, d.s[1].out, M, s2, s));
     AID_TRY(linear_fwd(s2.y, d.s[2].out, d.out.w, d.out.b, out, ldo, M, d.out.out, d.out.in, ACT_NONE, s));
     ws.release(mark);

@@ -12,8 +12,9 @@ namespace aid {
 int sinusoid_embed(const float* t, const float* freq_scale, float tmul, int mode, float* out, int M, int dim, hipStream_t s);
 
 // y = act(LN(x)*gamma+beta) * mask.  gamma/beta may be null (non-affine). stats (optional): [M,2] = mean, rstd.
+// y = act(LN(x)) * mask (+ add: same [M, D] layout as y; the decoder's skip connection)
 int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
-           float* stats, int M, int D, hipStream_t s);
+           float* stats, int M, int D, hipStream_t s, const float* add = nullptr);
 
 // cond = LN(x)*gamma+beta + temb[row*ld_temb + c] ; sc = silu(cond).   (score_networks.py:145-153 + adaLN's SiLU)
 // x_mod > 0: row r reads x row (r % x_mod) (obs embedding shared by every step); temb_div > 0: row r adds temb row (r / temb_div)

@@ -37,7 +37,7 @@ int sinusoid_embed(const float* t, const float* fs, float tmul, int mode, float*
 
 __global__ void ln_act_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma,
                               const float* __restrict__ beta, int act, const float* __restrict__ mask,
-                              float* __restrict__ y, int ldy, float* __restrict__ stats, int M, int D) {
+                              float* __restrict__ y, int ldy, float* __restrict__ stats, int M, int D, const float* __restrict__ add) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= M) return;
     const float* xr = x + (size_t)row * ldx;
@@ -48,12 +48,14 @@ __global__ void ln_act_kernel(const float* __restrict__ x, int ldx, const float*
         if (gamma) v = v * gamma[c] + beta[c];
         v = act_apply(v, act);
         if (mask) v *= mask[(size_t)row * D + c];
+        if (add) v += add[(size_t)row * D + c];
         y[(size_t)row * ldy + c] = v;
     }
 }
 template <int NV>
 __global__ void ln_act_vec_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                  int act, const float* __restrict__ mask, float* __restrict__ y, int ldy, float* __restrict__ stats, int M) {
+                                  int act, const float* __restrict__ mask, float* __restrict__ y, int ldy, float* __restrict__ stats, int M,
+                                  const float* __restrict__ add) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63, row = blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
@@ -75,30 +77,32 @@ __global__ void ln_act_vec_kernel(const float* __restrict__ x, int ldx, const fl
     if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
     const f4* g4 = reinterpret_cast<const f4*>(gamma); const f4* b4 = reinterpret_cast<const f4*>(beta);
     const f4* m4 = mask ? reinterpret_cast<const f4*>(mask + (size_t)row * D) : nullptr;
+    const f4* a4 = add ? reinterpret_cast<const f4*>(add + (size_t)row * D) : nullptr;
     f4* yr = reinterpret_cast<f4*>(y + (size_t)row * ldy);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        f4 o, gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f}, mm = {1.f, 1.f, 1.f, 1.f};
+        f4 o, gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f}, mm = {1.f, 1.f, 1.f, 1.f}, aa = {0.f, 0.f, 0.f, 0.f};
         if (gamma) { gg = g4[lane + 64 * i]; bb = b4[lane + 64 * i]; }
         if (m4) mm = m4[lane + 64 * i];
+        if (a4) aa = a4[lane + 64 * i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * gg[j] + bb[j], act) * mm[j];
+        for (int j = 0; j < 4; ++j) o[j] = act_apply((v[i][j] - mean) * rstd * gg[j] + bb[j], act) * mm[j] + aa[j];
         yr[lane + 64 * i] = o;
     }
 }
 int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
-           float* stats, int M, int D, hipStream_t s) {
-    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mask) & 15) == 0 && ldx % 4 == 0 && ldy % 4 == 0;
+           float* stats, int M, int D, hipStream_t s, const float* add) {
+    const bool al = (((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mask | (uintptr_t)add) & 15) == 0 && ldx % 4 == 0 && ldy % 4 == 0;
     if (al && (D == 256 || D == 512 || D == 1024 || D == 2048)) {
         const dim3 grid((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
-        if (D == 256) hipLaunchKernelGGL(ln_act_vec_kernel<1>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
-        else if (D == 512) hipLaunchKernelGGL(ln_act_vec_kernel<2>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
-        else if (D == 1024) hipLaunchKernelGGL(ln_act_vec_kernel<4>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
-        else hipLaunchKernelGGL(ln_act_vec_kernel<8>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M);
+        if (D == 256) hipLaunchKernelGGL(ln_act_vec_kernel<1>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M, add);
+        else if (D == 512) hipLaunchKernelGGL(ln_act_vec_kernel<2>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M, add);
+        else if (D == 1024) hipLaunchKernelGGL(ln_act_vec_kernel<4>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M, add);
+        else hipLaunchKernelGGL(ln_act_vec_kernel<8>, grid, dim3(256), 0, s, x, ldx, gamma, beta, act, mask, y, ldy, stats, M, add);
         AID_LAUNCH_CHECK(); return AID_OK;
     }
     hipLaunchKernelGGL(ln_act_kernel, dim3((M + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK), dim3(256), 0, s, x, ldx, gamma, beta,
-                       act, mask, y, ldy, stats, M, D);
+                       act, mask, y, ldy, stats, M, D, add);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -239,43 +243,70 @@ __global__ void head_p_sample_kernel(const float* __restrict__ raw, const float*
     if (traj) traj[i] = v;
 }
 // Fused last head layer + reverse step: raw = p0 . W2^T (no bias, K = D/2, N = L), then the head transform and p_sample above.
-// One wave per row: lanes split K, one butterfly reduction per output column (L is 17..128 on this path).
+// A workgroup stages W2 ([L][K], K <= 256 per pass) and 16 rows of p0 in LDS; thread (row r = tid/16, slot j = tid%16) owns the
+// outputs l = j, j+16, ... of its row.  W2 rows are padded to K+1 floats so the 16 slots of a row read 16 different banks while
+// the p0 operand is a broadcast.
+constexpr int H2_ROWS = 16, H2_KC = 256;
 __global__ void __launch_bounds__(256) head2_p_sample_kernel(const float* __restrict__ p0, int ldp, const float* __restrict__ W2, int Kp,
                                                              const float* __restrict__ mult, float tv, int cont, const float* __restrict__ coef,
                                                              int step, const float* __restrict__ z, const float* __restrict__ eps,
                                                              float* __restrict__ zo, float* __restrict__ traj, float* __restrict__ raw_out,
                                                              int M, int L) {
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    extern __shared__ float h2s[];
+    float* ws = h2s;                                  // [L][H2_KC + 1]
+    float* ps = h2s + (size_t)L * (H2_KC + 1);        // [H2_ROWS][H2_KC + 1]
+    const int tid = threadIdx.x, r = tid >> 4, j = tid & 15;
+    const int row0 = blockIdx.x * H2_ROWS, row = row0 + r;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = 0.f;
+    for (int k0 = 0; k0 < Kp; k0 += H2_KC) {
+        const int kc = min(H2_KC, Kp - k0);
+        __syncthreads();
+        for (int i = tid; i < L * kc; i += 256) { const int l = i / kc, k = i % kc; ws[l * (H2_KC + 1) + k] = W2[(size_t)l * Kp + k0 + k]; }
+        for (int i = tid; i < H2_ROWS * kc; i += 256) { const int rr = i / kc, k = i % kc;
+            ps[rr * (H2_KC + 1) + k] = (row0 + rr < M) ? p0[(size_t)(row0 + rr) * ldp + k0 + k] : 0.f; }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int l = j + 16 * q;
+            if (l < L) {
+                const float* w = ws + l * (H2_KC + 1); const float* pr = ps + r * (H2_KC + 1);
+                float a = acc[q];
+                for (int k = 0; k < kc; ++k) a = fmaf(pr[k], w[k], a);
+                acc[q] = a;
+            }
+        }
+    }
     if (row >= M) return;
-    const float* pr = p0 + (size_t)row * ldp;
-    for (int l0 = 0; l0 < L; l0 += 64) {
-        float mine = 0.f;
-        const int lend = (L - l0) < 64 ? (L - l0) : 64;
-        for (int l = 0; l < lend; ++l) {
-            const float* w = W2 + (size_t)(l0 + l) * Kp;
-            float acc = 0.f;
-            for (int k = lane; k < Kp; k += 64) acc = fmaf(pr[k], w[k], acc);
-            acc = wave_sum(acc);
-            if (lane == l) mine = acc;
-        }
-        if (lane < lend) {
-            const size_t i = (size_t)row * L + l0 + lane;
-            if (raw_out) raw_out[i] = mine;
-            float sc = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
-            if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
-            const float zt = z[i];
-            const float z0 = (zt + coef[0] * sc) * coef[1];
-            float v = coef[2] * z0 + coef[3] * zt;
-            if (step > 0) v += coef[4] * eps[i];
-            zo[i] = v;
-            if (traj) traj[i] = v;
-        }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int l = j + 16 * q;
+        if (l >= L) continue;
+        const size_t i = (size_t)row * L + l;
+        const float mine = acc[q];
+        if (raw_out) raw_out[i] = mine;
+        float sc = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
+        if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
+        const float zt = z[i];
+        const float z0 = (zt + coef[0] * sc) * coef[1];
+        float v = coef[2] * z0 + coef[3] * zt;
+        if (step > 0) v += coef[4] * eps[i];
+        zo[i] = v;
+        if (traj) traj[i] = v;
     }
 }
 int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const float* mult, float t_value, int continuous, const float* coef,
                    int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s) {
-    hipLaunchKernelGGL(head2_p_sample_kernel, dim3((M + 3) / 4), dim3(256), 0, s, p0, ldp, W2, Kp, mult, t_value, continuous, coef, step, z, eps,
-                       z_out, traj_out, raw_out, M, L);
+    AID_REQUIRE(L >= 1 && L <= 128, AID_E_SHAPE, "head2_p_sample: latent_dim %d outside [1, 128]", L);
+    const size_t lds = sizeof(float) * ((size_t)L * (H2_KC + 1) + (size_t)H2_ROWS * (H2_KC + 1));
+    static bool attr_done = false;
+    if (lds > 65536 && !attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)head2_p_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(head2_p_sample_kernel, dim3((M + H2_ROWS - 1) / H2_ROWS), dim3(256), lds, s, p0, ldp, W2, Kp, mult, t_value, continuous,
+                       coef, step, z, eps, z_out, traj_out, raw_out, M, L);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 

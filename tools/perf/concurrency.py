@@ -32,8 +32,8 @@ def both_rev(force=0):
     efe()
     main.wait_stream(side)
 print(f"efe alone {t(efe):.2f} ms   denoise alone {t(dn):.2f} ms   denoise(tile64) alone {t(lambda: dn(4)):.2f} ms")
-print(f"both (efe first)      {t(both):.2f} ms   with side tile64 {t(lambda: both(4)):.2f} ms")
-print(f"both (denoise first)  {t(both_rev):.2f} ms   with side tile64 {t(lambda: both_rev(4)):.2f} ms")
+print(f"both (efe first)      {t(both):.2f} ms   with side tile64 {t(lambda: both(4)):.2f} ms   with side splitk {t(lambda: both(6)):.2f} ms")
+print(f"denoise(splitk) alone {t(lambda: dn(6)):.2f} ms")
 # host-side enqueue cost
 t0 = time.perf_counter(); efe(); te = time.perf_counter() - t0; torch.cuda.synchronize()
 t0 = time.perf_counter(); dn(); td = time.perf_counter() - t0; torch.cuda.synchronize()

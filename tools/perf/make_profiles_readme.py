@@ -1,0 +1,58 @@
+"""Regenerates profiles/README.md from the committed rocprofv3 / bench artifacts (run from the repo root, no GPU needed)."""
+import csv, json, os
+P = "profiles"
+bench = json.loads(open(os.path.join(P, "r01_bench.json")).read().strip().splitlines()[-1])
+rows = list(csv.DictReader(open(os.path.join(P, "r01_train_step_kernel_stats.csv"))))
+pmc = json.load(open(os.path.join(P, "r01_pmc_summary.json")))
+other = {}
+if os.path.exists(os.path.join(P, "r01_other_configs.jsonl")):
+    for line in open(os.path.join(P, "r01_other_configs.jsonl")):
+        line = line.strip()
+        if line.startswith("{"):
+            d = json.loads(line); other[d["config"]] = d
+tot = sum(float(r["TotalDurationNs"]) for r in rows)
+out = []
+w = out.append
+w("# profiles/ — rocprofv3 evidence, round 1\n")
+w("Regenerate this file with `python tools/perf/make_profiles_readme.py`; collect the inputs on the GPU box with `bash tools/perf/pmc_bench.sh`\n"
+  "(kernel stats + one PMC counter group per pass) and `python bench.py > profiles/r01_bench.json`.\n")
+w("| file | what |\n|---|---|\n"
+  "| `r01_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags) |\n"
+  "| `r01_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` |\n"
+  "| `r01_pmc_summary.json` | per-kernel averages of the PMC passes over ONE train_step (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) |\n"
+  "| `gemm_big_r01.txt`, `gemm_shapes_r01.txt` | microbenchmarks of the GEMM kernel variants per shape (`tools/perf/big_gemm.py`, `scratch_micro.py`); the dispatcher in `csrc/gemm_f32.hip` is set from them and from the in-situ chain `tools/perf/cold_chain.py` |\n"
+  "| `r01_other_configs.jsonl` | cfg 3 (Hopper, B=1024) and cfg 4 (pixels, B=256) train_step timings (`tools/perf/other_configs.py`) |\n")
+w("## Bench line (cfg 2: B=256, H=5, K=10, S=10, N=50, D=512, fp32)\n")
+w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/step; whole-step algorithmic rate {bench['train_step_algorithmic_tflops']:.1f} TFLOP/s "
+  f"= {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
+for key in ("roofline", "roofline_second_kernel"):
+    r = bench[key]
+    w(f"* `{key}`: {r['kernel']} — {r['achieved']:.1f} TFLOP/s = **{100*r['frac']:.1f} %** of peak over {r['launches_per_step']} launches "
+      f"({r['ms_per_step']:.1f} ms of the profiled step, {r['us_per_launch']:.1f} µs and {r['flop_per_launch']/1e9:.2f} GFLOP per launch"
+      + (f", PMC traffic {r['traffic']/1e6:.1f} MB per launch" if r.get("traffic") else "") + ").")
+f = bench["roofline_gemm_family"]; h = bench["roofline_hbm"]
+w(f"* every GEMM launch: {f['achieved']:.1f} TFLOP/s = {100*f['frac']:.1f} % ({f['launches_per_step']} launches, {f['flop_per_step']/1e12:.2f} TFLOP per step).")
+w(f"* HBM-bound kernel (`adamw_kernel`, 1.09 GB of algorithmic traffic per launch over the 27.15 M-parameter score arena): {h['achieved']:.0f} GB/s = {100*h['frac']:.0f} % of the 8 TB/s peak "
+  f"(≈{100*h['achieved']/6300:.0f} % of the 6.3 TB/s the guide measures as achievable).")
+if "cpu_baseline" in bench:
+    c = bench["cpu_baseline"]
+    w(f"* CPU baseline (oracle port, {c['cores']} host cores): {c['value']:.3f} steps/s ({c['sample']}) → GPU/CPU = {bench['speedup_vs_cpu_baseline']:.0f}×.")
+w("")
+w(f"## Kernel time under rocprofv3 (sum of kernel durations {tot/1e6:.0f} ms over the whole bench process; two streams overlap, so the sum exceeds wall time)\n")
+w("| kernel | calls | avg µs | total ms | % |\n|---|---|---|---|---|")
+for r in rows[:16]:
+    w(f"| `{r['Name'][:88]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.1f} | {float(r['TotalDurationNs'])/1e6:.1f} | {float(r['Percentage']):.1f} |")
+w("")
+w("## PMC passes (one train_step; FETCH_SIZE x 1 KiB x 2 = corrected read bytes, WRITE_SIZE x 1 KiB; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs ÷ GRBM_GUI_ACTIVE / 8 XCDs)\n")
+w("| kernel | launches | avg µs | read MB/launch | write MB/launch | MFMA pipe busy | eff. clock GHz |\n|---|---|---|---|---|---|---|")
+for k, v in pmc.items():
+    w(f"| `{k[:60]}` | {v.get('launches_mfma','')} | {v.get('avg_us_mfma',0):.1f} | {v.get('fetch_bytes_per_launch_corrected',0)/1e6:.1f} | {v.get('write_bytes_per_launch',0)/1e6:.1f} | "
+      f"{100*v.get('mfma_util',0):.1f} % | {v.get('eff_clock_GHz',0):.2f} |")
+w("\nThe effective-clock column reads high on dispatches shorter than ≈0.3 ms (guide, DVFS note); it is meaningful for `gemm_big_kernel` only.\n")
+if other:
+    w("## Other BASELINE configs (same build, 1x MI355X)\n")
+    for k, d in other.items():
+        extra = "".join(f", {a} {d[a]:.1f}" for a in ("encoder_fwd_ms", "encoder_bwd_ms") if a in d)
+        w(f"* {k}: {d['ms_per_step']:.1f} ms/step = {d['steps_per_s']:.2f} steps/s{extra}")
+open(os.path.join(P, "README.md"), "w").write("\n".join(out) + "\n")
+print("\n".join(out)[:3000])

@@ -740,6 +740,85 @@ __global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n)
                 epilogue_store(g, m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + wn + 32 * j + li, acc[i][j][r]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Panel kernel with 128-deep stages: the same 32x32 tile / 4-way in-workgroup split-K / LDS-DMA structure at HALF the LDS
+// (67 KB), so TWO workgroups share a CU.  Used when a small-M layer has more 32x32 tiles than the chip has CUs (the 768-row
+// reverse loop: 384 tiles): with the 133 KB variant the second half of the grid waits for the first to retire.
+// ------------------------------------------------------------------------------------------------
+template <bool AKM, bool BKM>
+__global__ void __launch_bounds__(256) gemm_panel128_kernel(GemmArgs g, int tiles_n) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int KST = 128;
+    using RA = Ring<32, KST, AKM>; using RB = Ring<32, KST, BKM>;
+    static_assert((RA::INSTR + RB::INSTR) / 4 == 8, "vmcnt(8) below assumes 8 DMA instructions per wave per stage");
+    float* As = smem; float* Bs = smem + 2 * RA::FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    int tm_, tn_; tile_coords(blockIdx.x, (g.M + 31) / 32, tiles_n, tm_, tn_);
+    const int m0 = tm_ * 32, n0 = tn_ * 32;
+    const int ns = g.K / KST;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ring_dma<32, KST, AKM>(g.A, g.lda, m0, g.M, 0, As, wave, lane);
+    ring_dma<32, KST, BKM>(g.B, g.ldb, n0, g.N, 0, Bs, wave, lane);
+    if (ns > 1) {
+        ring_dma<32, KST, AKM>(g.A, g.lda, m0, g.M, KST, As + RA::FLOATS, wave, lane);
+        ring_dma<32, KST, BKM>(g.B, g.ldb, n0, g.N, KST, Bs + RB::FLOATS, wave, lane);
+    }
+    for (int st = 0; st < ns; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const float* a_s = As + cur * RA::FLOATS;
+        const float* b_s = Bs + cur * RB::FLOATS;
+        const int kw = wave * (KST / 4);
+#pragma unroll
+        for (int g8 = 0; g8 < KST / 32; ++g8) {
+            const f32x4 av = ring_frag<32, KST, AKM>(a_s, li, kw + 8 * g8, h);
+            const f32x4 bv = ring_frag<32, KST, BKM>(b_s, li, kw + 8 * g8, h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+        if (st + 2 < ns) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ring_dma<32, KST, AKM>(g.A, g.lda, m0, g.M, (st + 2) * KST, As + cur * RA::FLOATS, wave, lane);
+            ring_dma<32, KST, BKM>(g.B, g.ldb, n0, g.N, (st + 2) * KST, Bs + cur * RB::FLOATS, wave, lane);
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    float* red = smem;
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = acc[r] + red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane];
+            epilogue_store(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v);
+        }
+    }
+}
+template <bool AKM, bool BKM>
+static int launch_panel128(const GemmArgs& g, hipStream_t s) {
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    const size_t lds = sizeof(float) * 2 * (Ring<32, 128, AKM>::FLOATS + Ring<32, 128, BKM>::FLOATS);
+    static bool done = false;
+    if (!done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_panel128_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        done = true;
+    }
+    hipLaunchKernelGGL((gemm_panel128_kernel<AKM, BKM>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    return AID_OK;
+}
+
 template <int BM, int BN, int KSTAGE, bool AKM, bool BKM>
 static int launch_ring(const GemmArgs& g, hipStream_t s) {
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -832,6 +911,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
             case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM>(g, s); break;
             case 12: if (vec) return launch_big<128, 64, 16, AKM, BKM, 2>(g, s); break;
             case 13: if (vec) return launch_big<64, 128, 16, AKM, BKM>(g, s); break;
+            case 14: if (p32_ok && (!AKM || g.M % 32 == 0)) return launch_panel128<AKM, BKM>(g, s); break;
             default: break;
         }
     }
@@ -852,6 +932,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     {
     const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
                           (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0) && t32 <= 1536;
+    if (panel_ok && t32 > 272 && g.ksplit <= 1) return launch_panel128<AKM, BKM>(g, s);   // more tiles than CUs: two 67 KB workgroups per CU
     if (panel_ok) return launch_panel<AKM, BKM>(g, s);
     }
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);

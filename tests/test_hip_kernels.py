@@ -195,3 +195,25 @@ def test_gemm_small_k_route(nat, M, N, K):
     pre = A.astype(np.float64) @ W.astype(np.float64).T + b
     ref = pre / (1 + np.exp(-pre)) + res
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("code", [1, 2, 4, 6, 7, 8, 9 + 256, 10, 11 + 256, 12, 13, 14])
+@pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
+def test_gemm_every_kernel_variant(nat, code, layout):
+    """Each kernel of the family (forced through aid_gemm_force_kernel) on a shape all of them accept, incl. a ragged row count for the
+    k-contiguous-A layouts; same fp64 reference as the automatic dispatcher's tests."""
+    M, N, K = (768, 512, 1024) if layout == "tn" else (700, 512, 1024)
+    rng = np.random.default_rng(code)
+    A = rng.standard_normal((M, K)).astype(np.float32); Bm = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    akm = 1 if layout == "tn" else 0; bkm = 0 if layout == "nt" else 1
+    Ad = dev(A.T if akm else A); Bd = dev(Bm.T if bkm else Bm)
+    out = torch.zeros(M, N, device="cuda")
+    nat.gemm_force_kernel(code)
+    try:
+        nat.gemm(Ad, Bd, out, M, N, K, Ad.shape[1], Bd.shape[1], N, akm, bkm, bias=dev(bias))
+    finally:
+        nat.gemm_force_kernel(0)
+    ref = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
+    scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64).T + 1.0
+    assert np.max(np.abs(out.cpu().numpy() - ref) / scale) < 2e-6

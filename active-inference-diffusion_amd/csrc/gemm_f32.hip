@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) gemm_smallk_kernel(GemmArgs g, int tiles_
         wsm[r][k] = (n0 + r < g.N) ? g.B[(size_t)(n0 + r) * g.ldb + k] : 0.f;
     }
     __syncthreads();
-    const int tc = tid & 15, tr = tid >> 4;
+    const int tc = tid & 15, tr = tid >> 4;      // rows tr + 16 i, columns 4 tc + j (contiguous: 16-B stores on the plain epilogue)
     float acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -235,16 +235,36 @@ __global__ void __launch_bounds__(256) gemm_smallk_kernel(GemmArgs g, int tiles_
 #pragma unroll
         for (int i = 0; i < 4; ++i) a[i] = xs[tr + 16 * i][k];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) b[j] = wsm[tc + 16 * j][k];
+        for (int j = 0; j < 4; ++j) b[j] = wsm[4 * tc + j][k];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
     }
+    const int c0 = n0 + 4 * tc;
+    const bool plain = !g.preact && !g.dact_pre && !g.mask && !g.residual && !g.accumulate && (g.ldc & 3) == 0 && c0 + 3 < g.N &&
+                       ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0);
+    if (plain) {
+        float bb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = g.bias[c0 + j];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = m0 + tr + 16 * i;
+            if (row >= g.M) continue;
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = act_apply(acc[i][j] * g.alpha + bb[j], g.act);
+            *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + c0) = o;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) epilogue_store(g, m0 + tr + 16 * i, n0 + tc + 16 * j, acc[i][j]);
+        for (int j = 0; j < 4; ++j) epilogue_store(g, m0 + tr + 16 * i, c0 + j, acc[i][j]);
 }
 static int launch_smallk(const GemmArgs& g, hipStream_t s) {
     const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
@@ -932,7 +952,9 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     {
     const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
                           (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0) && t32 <= 1536;
-    if (panel_ok && t32 > 272 && g.ksplit <= 1) return launch_panel128<AKM, BKM>(g, s);   // more tiles than CUs: two 67 KB workgroups per CU
+    // more tiles than CUs and >= 16 row tiles (the 768-row reverse loop, 1024-row batches): two 67 KB workgroups per CU beat two
+    // rounds of the 133 KB kernel by 12-18 us per launch in situ; a 256-row x 2048-column layer is the exception (cold_chain.py)
+    if (panel_ok && t32 > 272 && g.M >= 512 && g.ksplit <= 1) return launch_panel128<AKM, BKM>(g, s);
     if (panel_ok) return launch_panel<AKM, BKM>(g, s);
     }
     const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);

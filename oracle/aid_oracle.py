@@ -450,6 +450,27 @@ def epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_m
         return torch.clamp(mi, min=0.0), mi, joint, t_log, float(np.float32(new_rm))
 
 
+def burn_pixel_epistemic_draws(noise, B: int, L: int, S: int, train: bool, ntk: int = 4, heads: int = 8, queries: int = 16, tokens: int = 441):
+    """The draws of FunctionSpaceEpistemicEstimator.forward in pixel mode (active_inference.py:995-1063, 940-993; the
+    ConvDecoder runs in eval mode, the SpatialAttentionAggregator's attention dropout (util.py:25-30) is live in train mode):
+    S x randn[B,L]; ntk x (randn[S*B,L], attention-dropout mask [S*B*heads, queries, tokens]); projector mask [S*B,512]; MINE masks
+    2 x [S*B,512]; S x randperm(B); MINE masks 2 x [S*B,512].  The pixel estimator itself is not built: its value is
+    gradient-free, so parameter updates do not depend on it; this only keeps later draws aligned with the reference."""
+    for _ in range(S):
+        noise.randn(B, L)
+    for _ in range(ntk):
+        noise.randn(S * B, L)
+        if train:
+            noise.dropout_mask((S * B * heads, queries, tokens), 0.1)
+    if train:
+        noise.dropout_mask((S * B, 512), 0.1)
+        noise.dropout_mask((S * B, 512), 0.1); noise.dropout_mask((S * B, 512), 0.1)
+    for _ in range(S):
+        noise.randperm(B)
+    if train:
+        noise.dropout_mask((S * B, 512), 0.1); noise.dropout_mask((S * B, 512), 0.1)
+
+
 # ---------------------------------------------------------------------------------------------
 # A8  Expected Free Energy rollout                     aid/core/active_inference.py:314-396
 # ---------------------------------------------------------------------------------------------
@@ -457,7 +478,8 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
                          num_trajectories: int = 10, num_ambiguity_samples: int = 10,
                          train: bool = True, epistemic_weight: float = 0.1,
                          pragmatic_weight: float = 1.0, consistency_weight: float = 0.1,
-                         discount: float = 0.99, temperature: float = 1.0, skip_epistemic: bool = False):
+                         discount: float = 0.99, temperature: float = 1.0, skip_epistemic: bool = False,
+                         burn_pixel_epistemic: bool = False):
     """Returns (total_efe[B], info, new_running_mean).  Draw order per (k,t): rsample eps [B,A],
     reparam randn[B,L], then epistemic_value's draws.  skip_epistemic: the (no_grad) epistemic term is 0 and draws
     nothing - the pixel path of this repo, whose ConvDecoder estimator is not built."""
@@ -479,6 +501,8 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
             cons = -ent
             if skip_epistemic:
                 epi, mi, joint, tlog = torch.zeros(()), 0.0, 0.0, 0.0
+                if burn_pixel_epistemic:   # consume exactly what the reference's pixel estimator draws here (stream alignment only)
+                    burn_pixel_epistemic_draws(noise, B, nm.shape[1], num_ambiguity_samples, train)
             else:
                 epi, mi, joint, tlog, running_mean = epistemic_value(
                     p, nm.detach(), nlv, running_mean, noise, num_ambiguity_samples, train)
@@ -846,7 +870,8 @@ class OraclePixelState(OracleAgentState):
 
 
 def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, horizon: int = 5, lr: float = 5e-5, clip: float = 0.5,
-                     num_trajectories: int = 10, contrastive_weight: float = 0.5, pad: int = 4, train: bool = True, return_grads: bool = False):
+                     num_trajectories: int = 10, contrastive_weight: float = 0.5, pad: int = 4, train: bool = True, return_grads: bool = False,
+                     burn_epistemic_samples: int = 0):
     """One DiffusionPixelAgent.train_step, with the epistemic term skipped (see expected_free_energy).  Draw order: [shift h, w;
     Dropout2d masks x2; Dropout mask] for obs, the same for next_obs; belief draws (+1 feature-decoder mask) for each; ELBO
     draws (feature-decoder mask first); per (k,t) policy eps and reparam eps."""
@@ -884,7 +909,8 @@ def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, 
     metrics = {k: float(v) for k, v in info.items()}
     metrics["contrastive_loss"] = float(contrastive)
     grads_out = {"score": dict(live)}
-    efe, einfo, _ = expected_free_energy(p, latents, noise, 0.0, horizon, num_trajectories, 1, train, skip_epistemic=True)
+    efe, einfo, _ = expected_free_energy(p, latents, noise, 0.0, horizon, num_trajectories, max(burn_epistemic_samples, 1), train,
+                                         skip_epistemic=True, burn_pixel_epistemic=burn_epistemic_samples > 0)
     ploss = efe.mean()
     grads_out["policy"], _ = _opt_step(st, "policy", ploss, lr, 1e-5, clip)
     metrics["policy_loss"] = float(ploss)

@@ -156,3 +156,12 @@ def draw_params(specs, key: int, schedule_tables=None, head_scale: float = 1.0) 
             v = 0.1 * x
         out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).reshape(shape)
     return out
+
+
+def draw_feature_decoder(L: int, D: int, key: int) -> Dict[str, torch.Tensor]:
+    """Pixel-mode `feature_decoder` (active_inference.py:142-149): Linear(L,D), LayerNorm(D), ReLU, Dropout, Linear(D,L), Tanh."""
+    ns = NoiseStream(key)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return {"feature_decoder.0.weight": t(ns.randn(D, L) / np.sqrt(L)), "feature_decoder.0.bias": t(0.05 * ns.randn(D)),
+            "feature_decoder.1.weight": t(1.0 + 0.1 * ns.randn(D)), "feature_decoder.1.bias": t(0.05 * ns.randn(D)),
+            "feature_decoder.4.weight": t(ns.randn(L, D) / np.sqrt(D)), "feature_decoder.4.bias": t(0.05 * ns.randn(L))}

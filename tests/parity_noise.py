@@ -13,9 +13,10 @@ def dev(x):
 
 
 class ParityNoise(NoiseSource):
-    def __init__(self, key: int, pixel: bool = False):
+    def __init__(self, key: int, pixel: bool = False, burn_epistemic_samples: int = 0):
         super().__init__(seed=0)
         self.ns = NoiseStream(key)
+        self.burn_epistemic_samples = burn_epistemic_samples   # >0: consume the reference's pixel-estimator draws (alignment with reference goldens)
         self.pixel = pixel        # pixel mode: feature-decoder mask instead of the 3 decoder masks, no estimator draws in the EFE
 
     def encoder(self, B, L, pad):
@@ -69,6 +70,8 @@ class ParityNoise(NoiseSource):
                 for t in range(H):
                     n["policy_eps"][t, k * B:(k + 1) * B] = ns.randn(B, A)
                     n["reparam_eps"][t, k * B:(k + 1) * B] = ns.randn(B, L)
+                    if self.burn_epistemic_samples:
+                        orc.burn_pixel_epistemic_draws(ns, B, L, self.burn_epistemic_samples, True)
             return {k: dev(v) for k, v in n.items()}
         M, R = K * B, K * S * B
         n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),

@@ -232,3 +232,53 @@ def test_pixel_agent_philox_run():
     assert action.shape == (A,) and np.all(np.isfinite(action)) and np.all(np.abs(action) <= 1)
     import aid_amd.agents as ag
     assert ag.PixelBasedAgent is ag.DiffusionPixelAgent
+
+
+def test_pixel_agent_train_step_reference_golden(golden_dir):
+    """One whole DiffusionPixelAgent.train_step against the REFERENCE's own post-step state (tests/golden/pixel_step.npz, written by
+    oracle/gen_golden_pixel_step.py from a run of the reference): every parameter of every optimiser group (checksums + selected
+    tensors) and every non-epistemic metric."""
+    import functools
+    from oracle.weights import draw_feature_decoder
+    g = np.load(os.path.join(golden_dir, "pixel_step.npz"))
+    L, A, D, N, H, B, K, S, CAP = (int(v) for v in g["dims"])
+    kw, ke, kf, ks, kstep = (int(v) for v in g["keys"])
+    import aid_amd
+    from test_hip_agent import Box
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=L, hidden_dim=D, pixel_observation=True)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+
+    class Env:
+        observation_space, action_space = Box((3, 3, 84, 84)), Box((A,))
+    agent = aid_amd.DiffusionPixelAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=CAP), aid_amd.PixelObservationConfig())
+    ai = agent.active_inference
+    p = draw_params(param_specs(L, A, L, D, N), kw, orc.schedule_tables(N))
+    p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}
+    p.update(draw_feature_decoder(L, D, kf))
+    sd = ai.state_dict()
+    assert set(p) == set(sd), set(p) ^ set(sd)
+    ai.load_state_dict(p, strict=True)
+    agent.encoder.load_state_dict(draw_encoder_params(encoder_specs(L), ke), strict=True)
+    bs = NoiseStream(ks)
+    obs = bs.rand(CAP, 3, 3, 84, 84); act = np.tanh(bs.randn(CAP, A)).astype(np.float32); rew = bs.randn(CAP); nobs = bs.rand(CAP, 3, 3, 84, 84)
+    for i in range(CAP):
+        agent.replay_buffer.add(obs[i], act[i], float(rew[i]), nobs[i], False)
+    pn = ParityNoise(kstep, pixel=True, burn_epistemic_samples=S); ai.noise = pn; agent.replay_buffer.index_source = pn
+    ai.compute_expected_free_energy_diffusion = functools.partial(ai.compute_expected_free_energy_diffusion, num_trajectories=K)
+    m = agent.train_step()
+    for k in g.files:
+        if k.startswith("metric/"):
+            name = k.split("/", 1)[1]
+            assert name in m, name
+            np.testing.assert_allclose(m[name], float(g[k]), rtol=5e-3, atol=5e-5, err_msg=name)
+    got = {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}
+    for k in g.files:
+        if k.startswith("param/"):
+            n = k.split("/", 1)[1]
+            np.testing.assert_allclose(got[n].cpu().numpy(), g[k], rtol=1e-3, atol=3e-6, err_msg=n)
+    np.testing.assert_allclose(got["encoder.output_layers.0.weight"].reshape(-1)[::9973].cpu().numpy(), g["param_sample/encoder.output_layers.0.weight"],
+                               rtol=1e-3, atol=3e-6)
+    names = [str(n) for n in g["names"]]
+    cs = np.array([float(got[n].double().sum()) for n in names])
+    bad = np.abs(cs - g["checksum"]) > 2e-5 * g["abssum"] + 2e-5
+    assert not bad.any(), [names[i] for i in np.nonzero(bad)[0]]

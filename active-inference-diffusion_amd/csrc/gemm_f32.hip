@@ -887,9 +887,10 @@ static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
     else     hipLaunchKernelGGL((gemm_tile_kernel<BM, BN, AKM, BKM, false>), dim3(tm * tn, ny), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
-static int g_big_map = 0;
+static int g_big_map = 0;     // benches only (aid_gemm_force_kernel bits 8+); the automatic dispatcher passes the map explicitly
 template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD = 1>
-static int launch_big(const GemmArgs& g, hipStream_t s) {
+static int launch_big(const GemmArgs& g, hipStream_t s, int map = -1) {
+    if (map < 0) map = g_big_map;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const size_t lds = sizeof(float) * 2 * (TileK<BM, AKM, BKT>::FLOATS + TileK<BN, BKM, BKT>::FLOATS);
     static bool attr_done = false;
@@ -897,7 +898,7 @@ static int launch_big(const GemmArgs& g, hipStream_t s) {
         AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn), dim3(256), lds, s, g, tn, g_big_map);
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn), dim3(256), lds, s, g, tn, map);
     return AID_OK;
 }
 template <bool AKM, bool BKM>
@@ -942,12 +943,10 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     const long t64a = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
     // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): same 64x64x32 tile with prefetch distance 2 and the
     // XCD-grouped tile map (+3..20 % on these shapes, profiles/gemm_big_r01.txt); below that the plain kernel is as fast.
-    if (g_force_kernel == 0 && vec && t64a >= 2048 && g.K >= 64) { const int keep = g_big_map; g_big_map = 1;
-        const int r = launch_big<64, 64, 32, AKM, BKM, 2>(g, s); g_big_map = keep; return r; }
+    if (g_force_kernel == 0 && vec && t64a >= 2048 && g.K >= 64) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 1);
     // 160..2047 tiles: the same branch-free, two-tile-deep kernel with the plain tile map (gemm_tile_kernel stays for unaligned
     // operands, K < 64 and the deterministic slab split-K mode)
-    if (g_force_kernel == 0 && t64a >= 160 && vec && g.K >= 64) { const int keep = g_big_map; g_big_map = 0;
-        const int r = launch_big<64, 64, 32, AKM, BKM, 2>(g, s); g_big_map = keep; return r; }
+    if (g_force_kernel == 0 && t64a >= 160 && vec && g.K >= 64) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 0);
     if (g_force_kernel == 0 && t64a >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
     {
     const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&

@@ -909,57 +909,47 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     else     hipLaunchKernelGGL((gemm_splitk_kernel<AKM, BKM, false>), dim3(tm * tn), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
-static int g_force_kernel = 0;   // 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk  (aid_gemm_force_kernel)
+
+static int g_force_kernel = 0;   // aid_gemm_force_kernel: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
 
 template <bool AKM, bool BKM>
 static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32);
-    {
-        const bool r64_ok = vec && g.K >= 128 && g.K % 128 == 0 && (!AKM || g.M % 64 == 0) && (!BKM || g.N % 64 == 0);
-        const bool r128_ok = vec && g.K >= 64 && g.K % 64 == 0 && (!AKM || g.M % 128 == 0) && (!BKM || g.N % 128 == 0);
-        const bool p32_ok = vec && g.K >= KS && g.K % KS == 0 && (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0);
-        switch (g_force_kernel) {
-            case 1: if (p32_ok) return launch_panel<AKM, BKM>(g, s); break;
-            case 2: if (r64_ok) return launch_ring<64, 64, 128, AKM, BKM>(g, s); break;
-            case 3: if (r128_ok) return launch_ring<128, 128, 64, AKM, BKM>(g, s); break;
-            case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
-            case 5: return launch_tile<128, 128, AKM, BKM>(g, vec, s);
-            case 6: return launch_splitk<AKM, BKM>(g, vec, s);
-            case 7: if (vec) return launch_big<64, 64, 16, AKM, BKM, 2>(g, s); break;
-            case 8: if (vec) return launch_big<128, 64, 16, AKM, BKM>(g, s); break;
-            case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
-            case 10: if (vec) return launch_big<64, 64, 16, AKM, BKM>(g, s); break;
-            case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM>(g, s); break;
-            case 12: if (vec) return launch_big<128, 64, 16, AKM, BKM, 2>(g, s); break;
-            case 13: if (vec) return launch_big<64, 128, 16, AKM, BKM>(g, s); break;
-            case 14: if (p32_ok && (!AKM || g.M % 32 == 0)) return launch_panel128<AKM, BKM>(g, s); break;
-            default: break;
-        }
-    }
-    // Automatic selection, set by measurement on MI355X (profiles/gemm_shapes_r01.txt): the register-staged 64x64 tile at
-    // 4 workgroups/CU (16 waves hide the global-load latency behind the slow fp32 MFMA) wins whenever it yields >= ~160
-    // tiles; below that the grid cannot fill the chip and the 32x32 LDS-DMA panel kernel (whole K in flight at once,
-    // 4-way in-workgroup split-K) has the shortest critical path.
-    const long t64a = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-    // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): same 64x64x32 tile with prefetch distance 2 and the
-    // XCD-grouped tile map (+3..20 % on these shapes, profiles/gemm_big_r01.txt); below that the plain kernel is as fast.
-    if (g_force_kernel == 0 && vec && t64a >= 2048 && g.K >= 64) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 1);
-    // 160..2047 tiles: the same branch-free, two-tile-deep kernel with the plain tile map (gemm_tile_kernel stays for unaligned
-    // operands, K < 64 and the deterministic slab split-K mode)
-    if (g_force_kernel == 0 && t64a >= 160 && vec && g.K >= 64) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 0);
-    if (g_force_kernel == 0 && t64a >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
-    {
-    const bool panel_ok = vec && g.K >= KS && g.K % KS == 0 && g.M >= 1 && g.N >= 1 &&
-                          (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0) && t32 <= 1536;
-    // more tiles than CUs and >= 16 row tiles (the 768-row reverse loop, 1024-row batches): two 67 KB workgroups per CU beat two
-    // rounds of the 133 KB kernel by 12-18 us per launch in situ; a 256-row x 2048-column layer is the exception (cold_chain.py)
-    if (panel_ok && t32 > 272 && g.M >= 512 && g.ksplit <= 1) return launch_panel128<AKM, BKM>(g, s);
-    if (panel_ok) return launch_panel<AKM, BKM>(g, s);
-    }
-    const long t128 = (long)((g.M + 127) / 128) * ((g.N + 127) / 128);
     const long t64 = (long)((g.M + 63) / 64) * ((g.N + 63) / 64);
-    if (t128 >= 384) return launch_tile<128, 128, AKM, BKM>(g, vec, s);
-    if (t64 >= 256 || g.K <= 64) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+    const bool r64_ok = vec && g.K >= 128 && g.K % 128 == 0 && (!AKM || g.M % 64 == 0) && (!BKM || g.N % 64 == 0);
+    const bool p32_ok = vec && g.K >= KS && g.K % KS == 0 && (!AKM || g.M % 32 == 0) && (!BKM || g.N % 32 == 0);
+    switch (g_force_kernel) {          // benches / tests only
+        case 1: if (p32_ok) return launch_panel<AKM, BKM>(g, s); break;
+        case 2: if (r64_ok) return launch_ring<64, 64, 128, AKM, BKM>(g, s); break;
+        case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+        case 6: return launch_splitk<AKM, BKM>(g, vec, s);
+        case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
+        case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM, 1>(g, s); break;
+        case 14: if (p32_ok) return launch_panel128<AKM, BKM>(g, s); break;
+        default: break;
+    }
+    // Automatic selection, set by measurement on MI355X (profiles/gemm_*_r01.txt, tools/perf/cold_chain.py).
+    // K <= 32 (first layer of every network, K = latent / observation dim): VALU kernel, output-write bound.
+    if (!AKM && !BKM && g.K >= 1 && g.K <= 32) return launch_smallk(g, s);
+    if (vec && g.K >= 64) {
+        // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): 64x64x32 tile at 4 workgroups/CU, branch-free loads, two
+        // tiles of prefetch, XCD-grouped tile map (+3..20 % on these shapes); 160..2047 tiles: the same kernel, plain tile map.
+        if (t64 >= 2048) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 1);
+        // exactly one 64x64 tile per CU with K >= 512 (M = 512 x N = 2048 in a 2B-row reverse loop): the LDS-DMA ring keeps two
+        // 128-deep stages in flight and is 2.4 us per launch faster in situ (cold weights)
+        if (t64 >= 224 && t64 <= 288 && r64_ok && g.K >= 512) return launch_ring<64, 64, 128, AKM, BKM>(g, s);
+        if (t64 >= 160) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s, 0);
+    }
+    if (t64 >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);        // unaligned operands / K < 64
+    // < 160 tiles: the grid cannot fill the chip with 64x64 tiles; the 32x32 LDS-DMA panel kernel (whole K in flight, 4-way
+    // in-workgroup split-K) has the shortest critical path.
+    if (p32_ok && t32 <= 1536) {
+        // more tiles than CUs and >= 16 row tiles (the 768-row reverse loop, 1024-row batches): two 67 KB workgroups per CU beat two
+        // rounds of the 133 KB kernel by 12-18 us per launch in situ; a 256-row x 2048-column layer is the exception
+        if (t32 > 272 && g.M >= 512 && g.ksplit <= 1) return launch_panel128<AKM, BKM>(g, s);
+        return launch_panel<AKM, BKM>(g, s);
+    }
+    if (g.K <= 64) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
     return launch_splitk<AKM, BKM>(g, vec, s);
 }
 

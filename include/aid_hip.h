@@ -64,8 +64,8 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream);
-/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk,
- * 7-13 gemm_big_kernel variants (tools/perf/big_gemm.py); bits 8+ select the XCD-grouped tile map of gemm_big_kernel */
+/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 / 11 gemm_big_kernel with prefetch
+ * distance 2 / 1, 14 panel128; bit 8 selects the XCD-grouped tile map of gemm_big_kernel */
 int aid_gemm_force_kernel(int k);
 
 /* ---- Philox fills (production RNG; parity tests pass explicit tensors instead) ---------------- */

@@ -4,7 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aid_amd import _native as nat
 nat.lib()
-NAMES = {0: "auto", 4: "tile64", 7: "b64x64x16p2", 8: "b128x64x16", 9: "b64x64x32p2", 10: "b64x64x16", 11: "b64x64x32", 12: "b128x64x16p2", 13: "b64x128x16"}
+NAMES = {0: "auto", 4: "tile64", 9: "big_pd2", 11: "big_pd1", 2: "ring64"}
 def timeit(fn, reps):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -18,7 +18,7 @@ for (M, N, K) in shapes:
     # a chain of distinct activations (as in situ: every GEMM reads a freshly produced A), weights re-used
     As = [torch.randn(M, K, device="cuda") for _ in range(3)]; W = torch.randn(N, K, device="cuda"); C = torch.empty(M, N, device="cuda")
     ref = None; line = f"M={M:6d} N={N:6d} K={K:5d}: "
-    for code in (4, 11, 11 + 256, 9, 9 + 256, 10 + 256, 7, 7 + 256, 8 + 256, 12, 12 + 256):
+    for code in (4, 11, 11 + 256, 9, 9 + 256, 2, 0):
         nat.gemm_force_kernel(code)
         i = [0]
         def fn():

@@ -32,7 +32,7 @@ base = run({})
 print(f"M={M}: auto chain {base:.1f} us per step ({base/18:.1f} us/GEMM)", flush=True)
 for kind in kinds:
     row = []
-    for code in (1, 14, 2, 9):
+    for code in (1, 14, 2, 9, 4):
         try:
             t = run({kind: code})
             row.append(f"{NAMES[code]}={t - base:+.1f}")

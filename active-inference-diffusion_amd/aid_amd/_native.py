@@ -232,7 +232,7 @@ def lib() -> C.CDLL:
     L.aid_version.restype = C.c_int
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
-                 "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace"):
+                 "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -672,3 +672,29 @@ def adamw_step_ext(p, g, m, v, ema, lr, weight_decay, step, clip_norm, scratch, 
     check(lib().aid_adamw_step_ext(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(ema), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay),
                                    C.c_float(beta1), C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), C.c_float(ema_decay),
                                    _ptr(scratch), _ptr(ext_sumsq), _stream()), "aid_adamw_step_ext")
+
+
+def mine_train_step(dyn: AidDynamicsNet, dec: AidDecoderNet, epi: AidEpistemicNet, egrads: AidEpistemicNet, latents, actions, running_mean,
+                    num_samples=5, noise=None, train=True, seed=0, offset=0, alpha=0.01, ws: Workspace = None):
+    """train_epistemic_estimator forward + backward (estimator gradients accumulate into `egrads`). -> out [4] = mi, joint, marginal, loss"""
+    B = latents.shape[0]
+    nz = AidEfeNoise(); noise = noise or {}
+    for k, _ in AidEfeNoise._fields_:
+        v = noise.get(k)
+        if k == "perms" and v is not None:
+            assert v.dtype == torch.int32 and v.is_cuda and v.is_contiguous()
+            setattr(nz, k, v.data_ptr())
+        else:
+            setattr(nz, k, _ptr(v).value)
+    out = torch.zeros(4, device=latents.device, dtype=torch.float32)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_mine_train_workspace(C.byref(dec), C.byref(dyn), B, num_samples))
+    check(lib().aid_mine_train_step(C.byref(dyn), C.byref(dec), C.byref(epi), C.byref(egrads), B, num_samples, _ptr(latents), _ptr(actions), C.byref(nz),
+                                    int(bool(train)), C.c_uint64(seed), C.c_uint64(offset), C.c_float(alpha), _ptr(running_mean), _ptr(out),
+                                    C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_mine_train_step")
+    return out
+
+
+def adam_l2_step(p, g, m, v, lr, weight_decay, step, clip_norm, scratch, beta1=0.9, beta2=0.999, eps=1e-8):
+    check(lib().aid_adam_l2_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay), C.c_float(beta1),
+                                 C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), _ptr(scratch), _stream()), "aid_adam_l2_step")

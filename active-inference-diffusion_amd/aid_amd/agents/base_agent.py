@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 from .. import _native as nat
-from ..arena import ArenaOptimizer
+from ..arena import AdamL2Optimizer, ArenaOptimizer
 from ..configs.config import ActiveInferenceConfig, TrainingConfig
 from ..core.active_inference import EMAModel
 
@@ -79,6 +79,9 @@ class BaseActiveInferenceAgent(ABC):
         self.policy_optimizer = ArenaOptimizer(a["policy"], lr, 1e-5, clip)
         self.value_optimizer = ArenaOptimizer(a["value"], lr, 1e-2, clip)
         self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip)
+        if "epistemic" in a:   # base_agent.py:134-139 (the reference's concrete agents forget to create it: SURVEY D3)
+            self.epistemic_optimizer = AdamL2Optimizer(a["epistemic"], lr * 0.1, 1e-5, clip)
+            self.active_inference.epistemic_optimizer = self.epistemic_optimizer
 
     def act(self, observation: np.ndarray, deterministic: bool = False) -> Tuple[np.ndarray, Dict[str, Any]]:
         obs = self._process_observation(observation).to(self.device)

@@ -136,6 +136,10 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
                                        cfg.discount_factor, 0.95, 5, ws=ai._ws)
         self.value_optimizer.step()
+        epi_metrics = {}
+        if self.train_epistemic_every and self.total_steps % self.train_epistemic_every == 0:   # state_agent.py:216-222
+            epistemic_mi, epi_metrics = ai.train_epistemic_estimator(latents, actions, next_latents)
+            epi_metrics = {"epistemic_mi": epistemic_mi, **epi_metrics}
         # 5. dynamics
         self.dynamics_optimizer.zero_grad()
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
@@ -149,8 +153,13 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         host = torch.cat(vals).cpu().tolist()
         metrics = dict(zip(keys, host))
         metrics.update({"num_trajectories": efe_info["num_trajectories"], "horizon": efe_info["horizon"]})
+        metrics.update(epi_metrics)
         self._last = {"latents": latents, "next_latents": next_latents}
         return metrics
+
+    # The reference trains the MINE estimator when `total_steps % 5 == 0` (state_agent.py:216-222) but its concrete agents never create
+    # the optimiser that branch needs, so it raises there.  Opt in with 5 to get the behaviour the code intends.
+    train_epistemic_every = 0
 
     # -- cross-step prefetch of the next minibatch's belief latents ------------------------------------------------------------
     prefetch_next_batch = True     # False: never look ahead (every train_step samples and denoises its own minibatch)

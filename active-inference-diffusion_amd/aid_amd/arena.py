@@ -140,3 +140,27 @@ class ArenaOptimizer:
 
     def load_state_dict(self, sd):
         self.arena.load_state_dict(sd)
+
+
+class AdamL2Optimizer:
+    """torch.optim.Adam(weight_decay=...) semantics (L2 folded into the gradient) + clip_grad_norm_ over one arena: the estimator's
+    optimiser of base_agent.py:134-139 (lr * 0.1, weight_decay 1e-5)."""
+
+    def __init__(self, arena: ParamArena, lr: float, weight_decay: float, clip_norm: float):
+        self.arena, self.clip_norm = arena, clip_norm
+        self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": (0.9, 0.999), "eps": 1e-8}]
+
+    def zero_grad(self, set_to_none: bool = False):
+        self.arena.zero_grad()
+
+    def step(self):
+        parallel.allreduce_mean_(self.arena.grad)
+        a, g = self.arena, self.param_groups[0]
+        a.step_count += 1
+        nat.adam_l2_step(a.flat, a.grad, a.exp_avg, a.exp_avg_sq, g["lr"], g["weight_decay"], a.step_count, self.clip_norm, a._scratch)
+
+    def state_dict(self):
+        return self.arena.state_dict()
+
+    def load_state_dict(self, sd):
+        self.arena.load_state_dict(sd)

@@ -28,8 +28,8 @@ from .diffusion import LatentDiffusionProcess
 
 
 class FunctionSpaceEpistemicEstimator(nn.Module):
-    """Parameter holder of the MINE estimator (active_inference.py:839-1063, state branch).  Evaluated inside
-    `aid_efe_step`; never trained in any runnable reference configuration."""
+    """Parameter holder of the MINE estimator (active_inference.py:839-1063, state branch).  Evaluated inside `aid_efe_step`;
+    trained by `DiffusionActiveInference.train_epistemic_estimator` (`aid_mine_train_step`)."""
 
     def __init__(self, decoder: nn.Module, latent_dim: int, observation_shape: int, hidden_dim: int = 256,
                  spatial_aggregator_output_dim: int = 256, is_pixel_observation: bool = False, device="cuda"):
@@ -148,7 +148,11 @@ class DiffusionActiveInference(nn.Module):
             self._running_mean = torch.zeros(1, device=device)
         else:
             frozen += [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
-            frozen += [("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters() if not n.startswith("decoder.")]
+            # the estimator's own parameters (everything but its alias of the decoder): trained only by train_epistemic_estimator
+            self.arenas["epistemic"] = ParamArena([("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters()
+                                                   if not n.startswith("decoder.")], device)
+            self._epi_gtab = TableCache(lambda: nat.epistemic_table({n: p.grad for n, p in self.epistemic_estimator.named_parameters()
+                                                                      if not n.startswith("decoder.")}, ""))
             self._dec_tab = TableCache(lambda: nat.decoder_table(params_dict(self.observation_decoder), ""))
             self._epi_tab = TableCache(lambda: nat.epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
                                                                      if not n.startswith("decoder.")}, ""))
@@ -287,9 +291,28 @@ class DiffusionActiveInference(nn.Module):
     def compute_epistemic_value(self, next_latent_mean, next_latent_logvar, num_samples: int = 5):
         raise NotImplementedError("the MINE estimator is evaluated inside compute_expected_free_energy_diffusion (aid_efe_step)")
 
-    def train_epistemic_estimator(self, latents, actions, next_latents):
-        raise NotImplementedError("never runs in the reference either: `epistemic_optimizer` is not created by the concrete agents "
-                                  "(SURVEY Appendix A, D3); parity unpinned, scheduled after §8(a-e)")
+    def train_epistemic_estimator(self, latents: torch.Tensor, actions: torch.Tensor, next_latents: torch.Tensor = None, noise: Optional[dict] = None):
+        """active_inference.py:420-445: one optimiser step of the MINE estimator on -clamp(MI lower bound, 0).  Needs
+        `self.epistemic_optimizer` (the agents attach the one base_agent.py:134-139 defines).  -> (mi, metrics of floats)"""
+        if self.is_pixel_observation:
+            raise NotImplementedError("pixel-mode epistemic estimator (ConvDecoder) is SURVEY 8(f) rank 1: not built")
+        opt = getattr(self, "epistemic_optimizer", None)
+        if opt is None:
+            raise AttributeError("epistemic_optimizer is not set (the reference's concrete agents never create it, SURVEY D3); "
+                                 "aid_amd agents attach it in _setup_optimizers")
+        latents = latents.to(self.device).contiguous().float(); actions = actions.to(self.device).contiguous().float()
+        S = 5
+        if noise is None:
+            hook = getattr(self.noise, "mine_train", None)
+            noise = hook(latents.shape[0], self.latent_dim, S) if hook is not None else None
+        opt.zero_grad()
+        out = nat.mine_train_step(self.latent_dynamics.table(), self.decoder_table(), self.epistemic_table(), self._epi_gtab.get(self.epistemic_estimator),
+                                  latents, actions, self._running_mean, num_samples=S, noise=noise, train=self.epistemic_estimator.training,
+                                  seed=self.noise.seed, offset=self.noise.next_offset(), alpha=self.epistemic_estimator.alpha, ws=self._ws)
+        opt.step()
+        mi, joint, marg, _ = out.cpu().tolist()
+        return max(mi, 0.0), {"epistemic/mi_estimate": mi, "epistemic/joint_term": joint, "epistemic/marginal_term": marg,
+                              "epistemic/running_mean": float(self._running_mean[0])}
 
     def reparameterize(self, mean: torch.Tensor, logvar: torch.Tensor) -> torch.Tensor:
         eps = torch.empty_like(mean)

@@ -223,6 +223,42 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     return AID_OK;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// MINE estimator training step (DiffusionActiveInference.train_epistemic_estimator, active_inference.py:420-445):
+// loss = -(mean t_joint - EMALoss(t_marginal)); gradients for every estimator-owned parameter (feature extractor, projector,
+// latent processor, MINE network, perturbation_scale); the decoder runs under no_grad in the reference and gets none.
+// ---------------------------------------------------------------------------------------------------------------------------
+// d t_joint = -1/R ; d t_marg = exp(t_marg) / (running_mean_new + 1e-6) / R   (EMALoss.backward :822-826, loss = -mi)
+// the estimator returns clamp(mi, min=0) (:1063): the whole gradient is gated by mi >= 0
+__global__ void mine_loss_grad_kernel(const float* __restrict__ tm, const float* __restrict__ rm, const float* __restrict__ red, float* __restrict__ dtj,
+                                      float* __restrict__ dtm, int R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const float gate = red[3] >= 0.f ? 1.f : 0.f;
+    dtj[i] = -gate / (float)R;
+    dtm[i] = gate * expf(tm[i]) / (rm[0] + 1e-6f) / (float)R;
+}
+// running mean EMA for ONE estimator call (ema_loss :828-836), then out = {mi, joint, tlog, loss}
+__global__ void mine_train_finish_kernel(const float* __restrict__ red /*[4]: joint, tlog, texp, mi*/, float alpha, float* __restrict__ rm, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float te = red[2];
+    rm[0] = (rm[0] == 0.f) ? te : alpha * te + (1.0f - alpha) * rm[0];
+    out[0] = red[3]; out[1] = red[0]; out[2] = red[1]; out[3] = -fmaxf(red[3], 0.f);
+}
+// dcomb[blk*B + perm[r], c] += dm[r, c] for the first nc columns (the marginal pass saw row-permuted Jacobian features)
+__global__ void perm_rows_scatter_add_kernel(const float* __restrict__ dm, int ldm, const int32_t* __restrict__ perms, float* __restrict__ dst, int ldd,
+                                             size_t R, int B, int nc) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R * nc) return;
+    const size_t r = i / nc; const int c = i % nc;
+    const size_t blk = r / B;
+    dst[(blk * B + (size_t)perms[r]) * ldd + c] += dm[r * ldm + c];     // perms is a bijection inside each block: no two r collide
+}
+__global__ void scale_out_kernel(float* __restrict__ dst, const float* __restrict__ acc, const float* __restrict__ eps) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) dst[0] += acc[0] / eps[0];
+}
+
 static size_t mine_ws_bytes(const AidDecoderNet& dec, int K, int S, int B) {
     const size_t R = (size_t)K * S * B;
     return decoder_ws_bytes(dec, (int)R) + sizeof(float) * R * (2 * 128 + 2 * dec.O + 128 + 256 + 512 + 2 * 384 + 128 + 1024 + 2 + 1024 + 16) + (1 << 16);
@@ -343,4 +379,145 @@ int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidD
     return AID_OK;
 }
 
+
+size_t aid_mine_train_workspace(const AidDecoderNet* dec, const AidDynamicsNet* dyn, int B, int S) {
+    if (!dec || !dyn || B <= 0 || S <= 0) return 0;
+    const size_t R = (size_t)S * B;
+    // decoder scratch + saved activations of every trainable stage (4 feature-extractor passes, projector, latent processor, two MINE
+    // passes) + their gradients + Philox noise when none is given + dynamics forward
+    return decoder_ws_bytes(*dec, (int)R) + sizeof(float) * R * (size_t)(16384 + 12 * dec->O + 8 * dec->L) + sizeof(float) * (size_t)B * (40 * dyn->D + 64)
+           + sizeof(int32_t) * R + (1 << 20);
+}
+
+int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, const AidEpistemicNet* epi, const AidEpistemicNet* grads, int B, int S,
+                        const float* latents, const float* actions, const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset,
+                        float alpha, float* running_mean, float* out4, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dyn && dec && epi && grads && latents && actions && noise && running_mean && out4, AID_E_NULL, "aid_mine_train_step: null argument");
+    AID_REQUIRE(B > 0 && S > 0 && B <= 2048, AID_E_SHAPE, "aid_mine_train_step: B=%d S=%d", B, S);
+    hipStream_t s = (hipStream_t)stream;
+    const AidEpistemicNet& e = *epi; const AidEpistemicNet& ge = *grads;
+    const int L = e.L, O = e.O, Rm = S * B, FE = e.fe4.out, JW = e.jp4.out, CW = e.jp4.out + e.lp2.out, MH = e.mn0.out;
+    const size_t R = (size_t)Rm;
+    Workspace ws(wsp, ws_bytes);
+    uint64_t ctr = offset;
+    auto draw = [&](const float* given, size_t cnt, int kind, float p, const float** out) -> int {
+        if (given) { *out = given; return AID_OK; }
+        float* buf = ws.f32(cnt); AID_WS_OK(ws);
+        AID_TRY(philox_fill(buf, cnt, kind, p, seed, ctr, s)); ctr += (cnt + 3) / 4; *out = buf; return AID_OK;
+    };
+    const float *z_eps, *delta, *pmask = nullptr, *mmask = nullptr;
+    AID_TRY(draw(noise->mine_z_eps, R * L, 0, 0.f, &z_eps));
+    AID_TRY(draw(noise->mine_delta, 4 * R * L, 0, 0.f, &delta));
+    if (train) {
+        AID_TRY(draw(noise->proj_mask, R * e.jp0.out, 2, 0.1f, &pmask));
+        AID_TRY(draw(noise->mine_mask, 4 * R * MH, 2, 0.1f, &mmask));
+    }
+    const int32_t* perms = noise->perms;
+    if (!perms) {
+        const float* keys; AID_TRY(draw(nullptr, R, 1, 0.f, &keys));
+        int32_t* pb = (int32_t*)ws.raw(sizeof(int32_t) * R); AID_WS_OK(ws);
+        int P2 = 1; while (P2 < B) P2 <<= 1;
+        hipLaunchKernelGGL(randperm_blocks_kernel, dim3((unsigned)S), dim3(256), (size_t)P2 * 8, s, keys, pb, B, P2);
+        AID_LAUNCH_CHECK(); perms = pb;
+    }
+    // ---- forward, everything trainable saved
+    float* next_mean = ws.f32((size_t)B * L);
+    DynSave dsv;
+    AID_TRY(dynamics_fwd(*dyn, B, latents, L, actions, dyn->A, next_mean, dsv, ws, s));
+    float* z_all = ws.f32(R * L); float* zp = ws.f32(R * L); float* fz = ws.f32(R * O); float* fp = ws.f32(R * O);
+    float* diff[4]; LaSave f0[4], f1[4];
+    for (int j = 0; j < 4; ++j) { diff[j] = ws.f32(R * O); la_alloc(Rm, e.fe0.out, true, ws, f0[j]); la_alloc(Rm, e.fe2.out, true, ws, f1[j]); }
+    float* jin = ws.f32(R * 4 * FE);
+    LlaSave pj; lla_alloc(Rm, e.jp0.out, ws, pj);
+    float* comb = ws.f32(R * CW); float* comb_m = ws.f32(R * CW);
+    LaSave l0; la_alloc(Rm, e.lp0.out, true, ws, l0);
+    LaSave mj0, mj1, mm0, mm1;
+    la_alloc(Rm, MH, true, ws, mj0); la_alloc(Rm, e.mn3.out, true, ws, mj1); la_alloc(Rm, MH, true, ws, mm0); la_alloc(Rm, e.mn3.out, true, ws, mm1);
+    float* tj = ws.f32(R); float* tm = ws.f32(R); float* red = ws.f32(8);
+    AID_WS_OK(ws);
+    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), z_all, 1, S, B, L);
+    AID_TRY(decoder_fwd(*dec, Rm, z_all, L, nullptr, fz, O, ws, s));                     // decoder: eval mode, no gradient (:949-953)
+    for (int j = 0; j < 4; ++j) {
+        LAUNCH1D(perturb_kernel, R, s, z_all, delta + (size_t)j * R * L, e.perturbation_scale, zp, R, L);
+        AID_TRY(decoder_fwd(*dec, Rm, zp, L, nullptr, fp, O, ws, s));
+        LAUNCH1D(fd_kernel, R * O, s, fp, fz, e.perturbation_scale, diff[j], R * O);
+        AID_TRY(la_fwd(e.fe0, ACT_RELU, nullptr, diff[j], O, Rm, f0[j], e.fe0.out, s));
+        AID_TRY(la_fwd(e.fe2, ACT_RELU, nullptr, f0[j].y, e.fe0.out, Rm, f1[j], e.fe2.out, s));
+        AID_TRY(linear_fwd(f1[j].y, e.fe2.out, e.fe4.w, e.fe4.b, jin + (size_t)j * FE, 4 * FE, Rm, FE, e.fe2.out, ACT_NONE, s));
+    }
+    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? pmask : nullptr, jin, 4 * FE, Rm, pj, s));
+    AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, comb, CW, Rm, JW, e.jp0.out, ACT_NONE, s));
+    AID_TRY(la_fwd(e.lp0, ACT_RELU, nullptr, z_all, L, Rm, l0, e.lp0.out, s));
+    AID_TRY(linear_fwd(l0.y, e.lp0.out, e.lp2.w, e.lp2.b, comb + JW, CW, Rm, e.lp2.out, e.lp0.out, ACT_NONE, s));
+    const size_t MSZ = R * MH;
+    auto mine_fwd = [&](const float* x, const float* k0, const float* k1, LaSave& a0, LaSave& a1, float* out) -> int {
+        AID_TRY(la_fwd(e.mn0, ACT_RELU, train ? k0 : nullptr, x, CW, Rm, a0, MH, s));
+        AID_TRY(la_fwd(e.mn3, ACT_RELU, train ? k1 : nullptr, a0.y, MH, Rm, a1, e.mn3.out, s));
+        AID_TRY(linear_fwd(a1.y, e.mn3.out, e.mn6.w, e.mn6.b, out, 1, Rm, 1, e.mn3.out, ACT_NONE, s));
+        return AID_OK;
+    };
+    AID_TRY(mine_fwd(comb, mmask, mmask ? mmask + MSZ : nullptr, mj0, mj1, tj));
+    LAUNCH1D(perm_rows_kernel, R * JW, s, comb, CW, perms, comb_m, CW, R, B, JW);
+    AID_TRY(copy_cols(comb + JW, CW, comb_m + JW, CW, Rm, e.lp2.out, s));
+    AID_TRY(mine_fwd(comb_m, mmask ? mmask + 2 * MSZ : nullptr, mmask ? mmask + 3 * MSZ : nullptr, mm0, mm1, tm));
+    hipLaunchKernelGGL(mine_reduce_kernel, dim3(1), dim3(1024), 0, s, tj, tm, Rm, red);
+    hipLaunchKernelGGL(mine_train_finish_kernel, dim3(1), dim3(64), 0, s, red, alpha, running_mean, out4);
+    AID_LAUNCH_CHECK();
+    // ---- backward
+    float* dtj = ws.f32(R); float* dtm = ws.f32(R);
+    float* d1 = ws.f32(R * e.mn3.out); float* d0 = ws.f32(R * MH);
+    float* dcomb = ws.f32(R * CW); float* dcm = ws.f32(R * CW);
+    AID_WS_OK(ws);
+    hipLaunchKernelGGL(mine_loss_grad_kernel, dim3((Rm + 255) / 256), dim3(256), 0, s, tm, running_mean, red, dtj, dtm, Rm);
+    AID_LAUNCH_CHECK();
+    auto mine_bwd = [&](const float* x, const float* k0, const float* k1, const LaSave& a0, const LaSave& a1, float* dt, float* dx) -> int {
+        AID_TRY(linear_bwd_weight(dt, 1, a1.y, e.mn3.out, ge.mn6.w, Rm, 1, e.mn3.out, s, 1));
+        AID_TRY(colsum(dt, 1, ge.mn6.b, Rm, 1, 1, s, &ws));
+        AID_TRY(linear_bwd_data(dt, 1, e.mn6.w, e.mn3.out, d1, e.mn3.out, Rm, 1, s, 0));
+        AID_TRY(la_bwd(e.mn3, &ge.mn3, ACT_RELU, train ? k1 : nullptr, a0.y, MH, Rm, a1, d1, e.mn3.out, d0, MH, s, 0, &ws));
+        AID_TRY(la_bwd(e.mn0, &ge.mn0, ACT_RELU, train ? k0 : nullptr, x, CW, Rm, a0, d0, MH, dx, CW, s, 0, &ws));
+        return AID_OK;
+    };
+    AID_TRY(mine_bwd(comb, mmask, mmask ? mmask + MSZ : nullptr, mj0, mj1, dtj, dcomb));
+    AID_TRY(mine_bwd(comb_m, mmask ? mmask + 2 * MSZ : nullptr, mmask ? mmask + 3 * MSZ : nullptr, mm0, mm1, dtm, dcm));
+    LAUNCH1D(perm_rows_scatter_add_kernel, R * JW, s, dcm, CW, perms, dcomb, CW, R, B, JW);
+    AID_TRY(axpby_cols(dcomb + JW, CW, 1.0f, dcm + JW, CW, 1.0f, dcomb + JW, CW, Rm, e.lp2.out, s));
+    // latent processor
+    {
+        float* dl = ws.f32(R * e.lp2.out); float* dl0 = ws.f32(R * e.lp0.out); AID_WS_OK(ws);
+        AID_TRY(copy_cols(dcomb + JW, CW, dl, e.lp2.out, Rm, e.lp2.out, s));
+        AID_TRY(linear_bwd_weight(dl, e.lp2.out, l0.y, e.lp0.out, ge.lp2.w, Rm, e.lp2.out, e.lp0.out, s, 1));
+        AID_TRY(colsum(dl, e.lp2.out, ge.lp2.b, Rm, e.lp2.out, 1, s, &ws));
+        AID_TRY(linear_bwd_data(dl, e.lp2.out, e.lp2.w, e.lp0.out, dl0, e.lp0.out, Rm, e.lp2.out, s, 0));
+        AID_TRY(la_bwd(e.lp0, &ge.lp0, ACT_RELU, nullptr, z_all, L, Rm, l0, dl0, e.lp0.out, nullptr, 0, s, 0, &ws));
+    }
+    // projector
+    float* djin = ws.f32(R * 4 * FE);
+    {
+        float* dj = ws.f32(R * JW); float* dpy = ws.f32(R * e.jp0.out); AID_WS_OK(ws);
+        AID_TRY(copy_cols(dcomb, CW, dj, JW, Rm, JW, s));
+        AID_TRY(linear_bwd_weight(dj, JW, pj.y, e.jp0.out, ge.jp4.w, Rm, JW, e.jp0.out, s, 1));
+        AID_TRY(colsum(dj, JW, ge.jp4.b, Rm, JW, 1, s, &ws));
+        AID_TRY(linear_bwd_data(dj, JW, e.jp4.w, e.jp0.out, dpy, e.jp0.out, Rm, JW, s, 0));
+        AID_TRY(lla_bwd(e.jp0, e.jp_ln, &ge.jp0, &ge.jp_ln, ACT_RELU, train ? pmask : nullptr, jin, 4 * FE, Rm, pj, dpy, djin, 4 * FE, ws, s));
+    }
+    // feature extractor x4 and the perturbation scale (diff = (f(z+d) - f(z)) / eps is the only place eps carries a gradient)
+    {
+        float* dfe = ws.f32(R * FE); float* df1 = ws.f32(R * e.fe2.out); float* df0 = ws.f32(R * e.fe0.out); float* ddiff = ws.f32(R * O);
+        float* acc = ws.f32(8); AID_WS_OK(ws);
+        AID_CHECK_HIP(hipMemsetAsync(acc, 0, 8 * sizeof(float), s));
+        for (int j = 0; j < 4; ++j) {
+            AID_TRY(copy_cols(djin + (size_t)j * FE, 4 * FE, dfe, FE, Rm, FE, s));
+            AID_TRY(linear_bwd_weight(dfe, FE, f1[j].y, e.fe2.out, ge.fe4.w, Rm, FE, e.fe2.out, s, 1));
+            AID_TRY(colsum(dfe, FE, ge.fe4.b, Rm, FE, 1, s, &ws));
+            AID_TRY(linear_bwd_data(dfe, FE, e.fe4.w, e.fe2.out, df1, e.fe2.out, Rm, FE, s, 0));
+            AID_TRY(la_bwd(e.fe2, &ge.fe2, ACT_RELU, nullptr, f0[j].y, e.fe0.out, Rm, f1[j], df1, e.fe2.out, df0, e.fe0.out, s, 0, &ws));
+            AID_TRY(la_bwd(e.fe0, &ge.fe0, ACT_RELU, nullptr, diff[j], O, Rm, f0[j], df0, e.fe0.out, ddiff, O, s, 0, &ws));
+            AID_TRY(dot_accum(ddiff, diff[j], R * O, -1.0f, acc, s));                    // d eps += -sum(ddiff * diff) / eps
+        }
+        hipLaunchKernelGGL(scale_out_kernel, dim3(1), dim3(64), 0, s, ge.perturbation_scale, acc, e.perturbation_scale);
+        AID_LAUNCH_CHECK();
+    }
+    return AID_OK;
+}
 }  // extern "C"

@@ -211,12 +211,14 @@ __global__ void finalize_norm_kernel(const float* __restrict__ partial, int nb, 
 // torch.optim.AdamW single-tensor update + EMAModel.update, one pass: 5 reads + 4 writes per parameter
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              float* __restrict__ ema, size_t n, float lr, float wd, float b1, float b2, float eps, float bc1,
-                             float sqrt_bc2, const float* __restrict__ coef, float ema_decay) {
+                             float sqrt_bc2, const float* __restrict__ coef, float ema_decay, int coupled_l2) {
     const float c = coef[1];
     const float step_size = lr / bc1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const float gi = g[i] * c;
-        float pi = p[i] * (1.f - lr * wd);
+        float gi = g[i] * c;
+        float pi = p[i];
+        if (coupled_l2) gi += wd * pi;            // torch.optim.Adam(weight_decay=wd): L2 term folded into the gradient
+        else pi *= (1.f - lr * wd);                // torch.optim.AdamW: decoupled decay
         const float mi = m[i] + (gi - m[i]) * (1.f - b1);
         const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
         const float denom = sqrtf(vi) / sqrt_bc2 + eps;
@@ -249,8 +251,23 @@ int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, siz
     return aid_adamw_step_ext(p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, step, clip_norm, ema_decay, scratch, nullptr, stream);
 }
 
+static int adam_step_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
+                          float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq, int coupled_l2,
+                          void* stream);
+
+int aid_adam_l2_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float weight_decay, float beta1, float beta2, float eps,
+                     int step, float clip_norm, float* scratch, void* stream) {
+    return adam_step_impl(p, g, m, v, nullptr, n, lr, weight_decay, beta1, beta2, eps, step, clip_norm, 0.f, scratch, nullptr, 1, stream);
+}
+
 int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
                        float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq, void* stream) {
+    return adam_step_impl(p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, step, clip_norm, ema_decay, scratch, ext_sumsq, 0, stream);
+}
+
+static int adam_step_impl(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
+                          float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq, int coupled_l2,
+                          void* stream) {
     AID_REQUIRE(p && g && m && v && scratch, AID_E_NULL, "aid_adamw_step: null arena");
     AID_REQUIRE(step >= 1, AID_E_SHAPE, "aid_adamw_step: step must be 1-based");
     hipStream_t s = (hipStream_t)stream;
@@ -262,7 +279,7 @@ int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema,
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     const int ub = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
     hipLaunchKernelGGL(adamw_kernel, dim3(ub), dim3(256), 0, s, p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, (float)bc1,
-                       (float)sqrt(bc2), scratch, ema_decay);
+                       (float)sqrt(bc2), scratch, ema_decay, coupled_l2);
     AID_LAUNCH_CHECK();
     return AID_OK;
 }

@@ -241,6 +241,15 @@ typedef struct AidEfeCfg {
     float epistemic_weight, pragmatic_weight, consistency_weight, discount, temperature, mine_alpha;
     uint64_t seed, offset;
 } AidEfeCfg;
+/* DiffusionActiveInference.train_epistemic_estimator (active_inference.py:420-445): one forward + backward of the MINE estimator on
+ * S samples of N(predict_next_latent(latents, actions), 0.1): loss = -(mean t_joint - EMALoss(t_marginal)).  Gradients of every
+ * estimator-owned parameter are ACCUMULATED into `grads` (same table type; the decoder gets none - it runs under no_grad in the
+ * reference); running_mean (device scalar) gets its EMA update; out4 = {mi, joint, marginal_term, loss}.  noise: mine_z_eps [S*B,L],
+ * mine_delta [4,S*B,L], proj_mask [S*B,512], mine_mask [4,S*B,512], perms [S,B] (NULL members => device Philox from seed/offset). */
+size_t aid_mine_train_workspace(const AidDecoderNet* dec, const AidDynamicsNet* dyn, int B, int S);
+int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, const AidEpistemicNet* epi, const AidEpistemicNet* grads, int B, int S,
+                        const float* latents, const float* actions, const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset,
+                        float alpha, float* running_mean, float* out4, void* ws, size_t ws_bytes, void* stream);
 size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg);
 int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
                  const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
@@ -254,6 +263,10 @@ int aid_grad_sumsq(const float* g, size_t n, float* scratch, void* stream);
 int aid_adamw_step_ext(float* p, const float* g, float* m, float* v, float* ema, size_t n, float lr, float weight_decay, float beta1,
                        float beta2, float eps, int step, float clip_norm, float ema_decay, float* scratch, const float* ext_sumsq,
                        void* stream);
+/* torch.optim.Adam with weight_decay (L2 folded into the gradient, NOT decoupled) after clip_grad_norm_: the estimator's optimiser,
+ * base_agent.py:134-139. */
+int aid_adam_l2_step(float* p, const float* g, float* m, float* v, size_t n, float lr, float weight_decay, float beta1, float beta2, float eps,
+                     int step, float clip_norm, float* scratch, void* stream);
 
 /* ---- pixel mode (aid/agents/pixel_agent.py:273-437, aid/core/active_inference.py:142-149) --------------------------------------
  * feature decoder Linear(L,D) LN ReLU Dropout(.2) Linear(D,L) Tanh: recon = mse(fd(latents), target); loss contribution +recon.

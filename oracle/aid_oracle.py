@@ -471,6 +471,93 @@ def burn_pixel_epistemic_draws(noise, B: int, L: int, S: int, train: bool, ntk: 
         noise.dropout_mask((S * B, 512), 0.1); noise.dropout_mask((S * B, 512), 0.1)
 
 
+class _EMALoss(torch.autograd.Function):
+    """EMALoss (active_inference.py:815-826): log-mean-exp forward, gradient exp(x) / (running_mean + 1e-6) / N."""
+
+    @staticmethod
+    def forward(ctx, x, running_mean):
+        ctx.save_for_backward(x, running_mean)
+        return x.exp().mean().log()
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, rm = ctx.saved_tensors
+        return grad_output * x.exp().detach() / (rm + 1e-6) / x.shape[0], None
+
+
+EPI_TRAINED = ("feature_extractor.", "jacobian_projector.", "latent_processor.", "mine_network.", "perturbation_scale")
+
+
+def epistemic_training_loss(p: Params, latents: Tensor, actions: Tensor, running_mean: float, noise, num_samples: int = 5,
+                            train: bool = True, ntk_samples: int = 4, alpha: float = 0.01):
+    """Loss of train_epistemic_estimator (active_inference.py:420-445) = -MI lower bound, WITH gradients: the estimator's forward
+    (:995-1063) on predict_next_latent(latents, actions); the decoder runs under no_grad (:949-967), the finite difference is divided
+    by the learnable perturbation_scale outside it (:970).  Same draw order as epistemic_value.  -> (loss, mi, joint, tlog, new_rm)"""
+    next_mean, next_logvar = predict_next_latent(p, latents, actions)
+    B = next_mean.shape[0]
+    zs = [next_mean + _t(noise.randn(*next_mean.shape)) * torch.exp(0.5 * next_logvar) for _ in range(num_samples)]
+    z_all = torch.cat(zs, dim=0)
+    eps_scale = p[EPI + "perturbation_scale"]
+    with torch.no_grad():
+        f_z = decode_observation(p, z_all, None, False)
+    feats = []
+    for _ in range(ntk_samples):
+        delta = F.normalize(_t(noise.randn(*z_all.shape)), dim=-1) * eps_scale
+        with torch.no_grad():
+            f_p = decode_observation(p, z_all + delta, None, False)
+        feats.append(_feature_extractor(p, (f_p - f_z) / eps_scale))
+    jf = torch.cat(feats, dim=1)
+    jf = F.relu(_ln(p, EPI + "jacobian_projector.1", _lin(p, EPI + "jacobian_projector.0", jf)))
+    jf = _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+    lf = _lin(p, EPI + "latent_processor.2", F.relu(_lin(p, EPI + "latent_processor.0", z_all)))
+    t_joint = _mine_net(p, torch.cat([jf, lf], dim=1), noise, train)
+    marg = []
+    for i in range(num_samples):
+        perm = _t(noise.randperm(B), torch.int64)
+        marg.append(jf[i * B:(i + 1) * B][perm])
+    t_marg = _mine_net(p, torch.cat([torch.cat(marg, dim=0), lf], dim=1), noise, train)
+    t_exp = torch.exp(torch.logsumexp(t_marg, 0) - math.log(t_marg.shape[0])).detach()
+    new_rm = t_exp if running_mean == 0 else alpha * t_exp + (1.0 - alpha) * running_mean
+    t_log = _EMALoss.apply(t_marg, torch.as_tensor(new_rm, dtype=torch.float32).reshape(-1))
+    joint = t_joint.mean()
+    mi = joint - t_log
+    # the estimator returns clamp(mi, min=0) (:1063) and the loss is its negation (:434): no gradient while the bound is negative
+    return -torch.clamp(mi, min=0.0), mi.detach(), joint.detach(), t_log.detach(), float(np.float32(new_rm))
+
+
+def adam_l2_step(param: Tensor, grad: Tensor, m: Tensor, v: Tensor, step: int, lr: float, wd: float,
+                 b1: float = 0.9, b2: float = 0.999, eps: float = 1e-8):
+    """torch.optim.Adam with weight_decay (coupled L2), single-tensor path, in place."""
+    g = grad + wd * param
+    m.mul_(b1).add_(g, alpha=1 - b1)
+    v.mul_(b2).addcmul_(g, g, value=1 - b2)
+    bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    param.addcdiv_(m, denom, value=-lr / bc1)
+
+
+def train_epistemic_estimator(st, latents: Tensor, actions: Tensor, noise, lr: float = 5e-5, clip: float = 0.5, num_samples: int = 5,
+                              train: bool = True):
+    """One call of DiffusionActiveInference.train_epistemic_estimator with the optimiser base_agent.py:134-139 defines
+    (Adam, lr*0.1, weight_decay 1e-5; clip_grad_norm_ over the estimator's parameters).  Mutates st.p / st.running_mean and the
+    `epistemic` optimiser state.  -> (mi, metrics, grads)"""
+    p = st.p
+    names = [n for n in p if n.startswith(EPI) and n[len(EPI):].startswith(EPI_TRAINED)]
+    for n in p:
+        p[n].requires_grad_(n in names)
+    loss, mi, joint, tlog, st.running_mean = epistemic_training_loss(p, latents, actions, st.running_mean, noise, num_samples, train)
+    grads = torch.autograd.grad(loss, [p[n] for n in names])
+    grads = [g.clone() for g in grads]
+    clip_grad_norm(grads, clip)
+    o = st.opt.setdefault("epistemic", {"step": 0, "m": {n: torch.zeros_like(p[n]) for n in names}, "v": {n: torch.zeros_like(p[n]) for n in names}})
+    o["step"] += 1
+    with torch.no_grad():
+        for n, g in zip(names, grads):
+            adam_l2_step(p[n], g, o["m"][n], o["v"][n], o["step"], lr * 0.1, 1e-5)
+    return max(float(mi), 0.0), {"epistemic/mi_estimate": float(mi), "epistemic/joint_term": float(joint), "epistemic/marginal_term": float(tlog),
+                       "epistemic/running_mean": st.running_mean}, dict(zip(names, grads))
+
+
 # ---------------------------------------------------------------------------------------------
 # A8  Expected Free Energy rollout                     aid/core/active_inference.py:314-396
 # ---------------------------------------------------------------------------------------------

@@ -62,6 +62,20 @@ class ParityNoise(NoiseSource):
         n["prior_eps"] = ns.randn(B, L)
         return {k: dev(v) for k, v in n.items()}
 
+    def mine_train(self, B, L, S):
+        """train_epistemic_estimator: the draws of ONE estimator forward (same order as inside the EFE rollout, K = 1)."""
+        ns = self.ns
+        R = S * B
+        n = {"mine_z_eps": np.concatenate([ns.randn(B, L) for _ in range(S)]), "mine_delta": np.stack([ns.randn(R, L) for _ in range(4)])}
+        n["proj_mask"] = ns.dropout_mask((R, 512), 0.1)
+        mm = [ns.dropout_mask((R, 512), 0.1), ns.dropout_mask((R, 512), 0.1)]
+        perms = np.stack([ns.randperm(B) for _ in range(S)]).astype(np.int32)
+        mm += [ns.dropout_mask((R, 512), 0.1), ns.dropout_mask((R, 512), 0.1)]
+        n["mine_mask"] = np.stack(mm)
+        out = {k: dev(v) for k, v in n.items()}
+        out["perms"] = torch.from_numpy(perms).cuda().contiguous()
+        return out
+
     def efe(self, B, L, A, H, K, S):
         ns = self.ns
         if self.pixel:

@@ -130,6 +130,13 @@ def test_act_and_philox_train_step_run():
     assert np.isfinite(info["expected_free_energy"]) and info["latent"].shape == (1, O)
     import aid_amd.agents as ag
     assert ag.StateBasedAgent is ag.DiffusionStateAgent
+    # opt-in estimator training every 5th step (state_agent.py:216-222; raises in the reference)
+    w0 = agent.active_inference.epistemic_estimator.mine_network[0].weight.detach().clone()
+    agent.train_epistemic_every = 5; agent.total_steps = 5
+    m = agent.train_step()
+    assert {"epistemic_mi", "epistemic/mi_estimate", "epistemic/running_mean"} <= set(m) and np.isfinite(m["epistemic_mi"])
+    assert not torch.equal(w0, agent.active_inference.epistemic_estimator.mine_network[0].weight)
+    m = agent.train_step(); assert "epistemic_mi" not in m
 
 
 def test_cross_step_prefetch_equals_reference_order():

@@ -336,3 +336,54 @@ def test_fokker_planck_fp64(nat, golden_dir):
     g = m["fp_grad"]
     expect = mu[0] + (-0.1 * g) * (0.01 / (1 + 0.1 * np.linalg.norm(g)))
     np.testing.assert_allclose(md.cpu().numpy()[0], expect, rtol=1e-12)
+
+
+def test_train_epistemic_estimator_reference_golden(golden_dir):
+    """DiffusionActiveInference.train_epistemic_estimator x3 against a run of the REFERENCE (tests/golden/mine_train.npz; the harness
+    attached the optimiser base_agent.py:134-139 defines): steps 1-2 have a positive bound (live gradient through both MINE passes, the
+    projector, the 4 feature-extractor passes, the latent processor and perturbation_scale), step 3 a negative one (clamp gates the
+    gradient; only Adam's L2 term moves the weights)."""
+    from parity_noise import ParityNoise
+    from test_hip_agent import _agent
+    g = np.load(os.path.join(golden_dir, "mine_train.npz"))
+    O, A, D, N, B = (int(v) for v in g["dims"])
+    kw, kd, k1, k2, k3 = (int(v) for v in g["keys"])
+    agent = _agent(O, A, D, N, 2, B)
+    ai = agent.active_inference
+    p = draw_params(param_specs(O, A, O, D, N), kw, orc.schedule_tables(N))
+    sd0 = ai.state_dict()
+    ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+    ds = NoiseStream(kd)
+    lat, act = dev(ds.randn(B, O)), dev(np.tanh(ds.randn(B, A)).astype(np.float32))
+    names = [str(n) for n in g["names"]]
+    pn = ParityNoise(0); ai.noise = pn
+    for step, key in ((1, k1), (2, k2), (3, k3)):
+        pn.rekey(key)
+        mi, met = ai.train_epistemic_estimator(lat, act, None)
+        np.testing.assert_allclose(mi, float(g[f"s{step}_mi"]), rtol=2e-3, atol=2e-5)
+        for k in ("epistemic/mi_estimate", "epistemic/joint_term", "epistemic/marginal_term", "epistemic/running_mean"):
+            np.testing.assert_allclose(met[k], float(g[f"s{step}_metric/{k}"]), rtol=2e-3, atol=2e-5, err_msg=f"step {step} {k}")
+        if step == 1:   # gradients (the golden holds them after clip_grad_norm_)
+            gv = ai.arenas["epistemic"].grad_views()
+            total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in gv.values())))
+            coef = min(1.0, agent.config.gradient_clip / (total + 1e-6))
+            gmax = max(float(np.abs(g[f"s1_grad/{n}"]).max()) for n in names)
+            for n in names:
+                ref = g[f"s1_grad/{n}"]; got = gv[n].reshape(-1)
+                got = (got if got.numel() <= 4096 else got[::97]).cpu().numpy() * coef
+                # mine_network.6.bias is -1 + mean(exp(t_marg)) / running_mean = 0 up to rounding on the first call: absolute floor
+                scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
+                assert np.abs(got - ref).max() / scale < 3e-3, (n, np.abs(got - ref).max(), scale)
+                np.testing.assert_allclose(float(gv[n].double().abs().sum()) * coef, g[f"s1_gradsum/{n}"][1], rtol=2e-3, atol=1e-4 * gmax)
+        sd = ai.state_dict()
+        cs = np.array([float(sd[n].double().sum()) for n in names])
+        bad = np.abs(cs - g[f"s{step}_checksum"]) > 2e-6 * g[f"s{step}_abssum"] + 2e-6
+        assert not bad.any(), (step, [names[i] for i in np.nonzero(bad)[0]])
+        for n in names:
+            t = sd[n].reshape(-1)
+            # Adam's normalised update is +-lr (5e-6) per step wherever |g| >> eps and anything in between where the gradient is
+            # rounding noise (|g| ~ 1e-8): absolute tolerance = a fraction of the accumulated step size
+            np.testing.assert_allclose((t if t.numel() <= 4096 else t[::97]).cpu().numpy(), g[f"s{step}_param/{n}"], rtol=1e-4, atol=3e-6 * step, err_msg=f"step {step} {n}")
+    # nothing outside the estimator moved
+    for n in ("observation_decoder.3.weight", "latent_dynamics.network.0.weight"):
+        assert torch.equal(ai.state_dict()[n].cpu(), p[n])

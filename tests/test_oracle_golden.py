@@ -186,3 +186,23 @@ def test_pixel_train_step_golden(golden_dir):
     names = [str(n) for n in g["names"]]
     cs = np.array([float(st.p[n].detach().double().sum()) for n in names])
     assert np.all(np.abs(cs - g["checksum"]) <= 1e-6 * g["abssum"] + 1e-6)
+
+
+def test_train_epistemic_estimator_golden(golden_dir):
+    """The oracle's train_epistemic_estimator (clamped MINE bound, EMALoss gradient, Adam with L2) against the reference's own run."""
+    from oracle.weights import draw_params, param_specs
+    g = np.load(os.path.join(golden_dir, "mine_train.npz"))
+    O, A, D, N, B = (int(v) for v in g["dims"])
+    kw, kd, k1, k2, k3 = (int(v) for v in g["keys"])
+    st = orc.OracleAgentState(draw_params(param_specs(O, A, O, D, N), kw, orc.schedule_tables(N)), N)
+    ds = NoiseStream(kd)
+    lat, act = torch.from_numpy(ds.randn(B, O)), torch.from_numpy(np.tanh(ds.randn(B, A)).astype(np.float32))
+    names = [str(n) for n in g["names"]]
+    for step, key in ((1, k1), (2, k2), (3, k3)):
+        mi, met, grads = orc.train_epistemic_estimator(st, lat, act, NoiseStream(key))
+        np.testing.assert_allclose(mi, float(g[f"s{step}_mi"]), rtol=1e-5, atol=1e-7)
+        for k, v in met.items():
+            np.testing.assert_allclose(v, float(g[f"s{step}_metric/{k}"]), rtol=1e-5, atol=1e-7, err_msg=k)
+        cs = np.array([float(st.p[n].detach().double().sum()) for n in names])
+        assert np.all(np.abs(cs - g[f"s{step}_checksum"]) <= 2e-6 * g[f"s{step}_abssum"] + 2e-6)
+    assert float(g["s1_mi"]) > 0 and float(g["s3_mi"]) == 0.0     # both branches of the clamp are covered

@@ -117,6 +117,14 @@ class AidElboNoise(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2", "d_obs_out")]
 
 
+class AidSNConv(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w", "u", "v", "bias")]
+
+
+class AidDecoderBlock(C.Structure):
+    _fields_ = [("main0", AidSNConv), ("main1", AidSNConv), ("res", AidSNConv)]
+
+
 class AidFeatureDecoder(C.Structure):
     _fields_ = [("l0", AidLinear), ("ln", AidLN), ("l4", AidLinear)]
 
@@ -232,7 +240,8 @@ def lib() -> C.CDLL:
     L.aid_version.restype = C.c_int
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
-                 "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace"):
+                 "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
+                 "aid_conv_decoder_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -698,3 +707,44 @@ def mine_train_step(dyn: AidDynamicsNet, dec: AidDecoderNet, epi: AidEpistemicNe
 def adam_l2_step(p, g, m, v, lr, weight_decay, step, clip_norm, scratch, beta1=0.9, beta2=0.999, eps=1e-8):
     check(lib().aid_adam_l2_step(_ptr(p), _ptr(g), _ptr(m), _ptr(v), C.c_size_t(p.numel()), C.c_float(lr), C.c_float(weight_decay), C.c_float(beta1),
                                  C.c_float(beta2), C.c_float(eps), int(step), C.c_float(clip_norm), _ptr(scratch), _stream()), "aid_adam_l2_step")
+
+
+class AidConvDecoder(C.Structure):
+    _fields_ = ([("L", C.c_int32), ("hidden", C.c_int32), ("l0", AidLinear), ("ln1", AidLN), ("l4", AidLinear), ("ln5", AidLN), ("blk", AidDecoderBlock * 4)]
+                + [(n, C.c_void_p) for n in ("out0_w", "out0_b", "out3_w", "out3_b", "out6_w", "out6_b")])
+
+
+def conv_decoder_table(params, prefix: str = "observation_decoder.") -> AidConvDecoder:
+    """Table over ConvDecoder state_dict tensors (visual_encoders.py:243-330; legacy spectral-norm keys weight_orig / weight_u / weight_v)."""
+    t = AidConvDecoder()
+    g = lambda k: _ptr(params[prefix + k]).value
+    t.L, t.hidden = params[prefix + "latent_proj.0.weight"].shape[1], params[prefix + "latent_proj.0.weight"].shape[0] // 4
+    t.l0 = _lin(params, prefix + "latent_proj.0"); t.ln1 = _ln(params, prefix + "latent_proj.1")
+    t.l4 = _lin(params, prefix + "latent_proj.4"); t.ln5 = _ln(params, prefix + "latent_proj.5")
+
+    def sn(name):
+        c = AidSNConv(); c.w, c.u, c.v, c.bias = g(name + ".weight_orig"), g(name + ".weight_u"), g(name + ".weight_v"), g(name + ".bias")
+        return c
+    for i, up in enumerate((False, True, True, True)):
+        b = f"decoder_blocks.{i}."
+        t.blk[i].main0 = sn(b + "main_path.0"); t.blk[i].main1 = sn(b + ("main_path.5" if up else "main_path.4"))
+        if up:
+            t.blk[i].res = sn(b + "residual_path.0")
+    for i in (0, 3, 6):
+        setattr(t, f"out{i}_w", g(f"output_proj.{i}.weight")); setattr(t, f"out{i}_b", g(f"output_proj.{i}.bias"))
+    return t
+
+
+def conv_decoder_forward(dec: AidConvDecoder, z, chunk: int = 16, ws: Workspace = None):
+    """ConvDecoder.forward, eval mode: z [R, L] -> images [R, 3, 168, 168]; rows are processed `chunk` at a time (the im2col of the
+    32-channel 168x168 convs is 32.5 MB per image)."""
+    R = z.shape[0]
+    z = z.contiguous().float()
+    out = torch.empty(R, 3, 168, 168, device=z.device, dtype=torch.float32)
+    ws = ws or Workspace(z.device)
+    for r0 in range(0, R, chunk):
+        n = min(chunk, R - r0)
+        buf = ws.get(lib().aid_conv_decoder_workspace(C.byref(dec), n))
+        check(lib().aid_conv_decoder_forward(C.byref(dec), n, _ptr(z[r0:r0 + n]), _ptr(out[r0:r0 + n]), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()),
+                                             _stream()), "aid_conv_decoder_forward")
+    return out

@@ -386,6 +386,117 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
 
 static int conv_slabs(size_t N) { int s = (int)(N / 8192); return s < 1 ? 1 : (s > 96 ? 96 : s); }
 
+
+// =================================================================================================================================
+// ConvDecoder forward, eval mode (active_inference_diffusion/encoder/visual_encoders.py:228-459): latent -> 3 x 168 x 168 image.
+// Activations are CNHW like the encoder's; every conv is W_eff[Cout, 9 Cin] x im2col (or a plain GEMM for the 1x1 residual convs).
+// Conv bias, PixelShuffle(2), InstanceNorm2d, the residual add and Mish are ONE pass over the conv output (instnorm_kernel): the
+// sub-pixel shuffle is an index transform of the read, the bias of the source channel is added on the fly.
+// =================================================================================================================================
+// legacy spectral norm, eval mode: sigma = u . (W v) with the stored u, v; any Cout, K
+__global__ void sn_rowdot_kernel(const float* __restrict__ w, const float* __restrict__ u, const float* __restrict__ v, int K, float* __restrict__ part) {
+    __shared__ float sh[16];
+    const int c = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) s += w[(size_t)c * K + k] * v[k];
+    const float t = wg_sum256(s, sh);
+    if (threadIdx.x == 0) part[c] = u[c] * t;
+}
+__global__ void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ part, int Cout, int K, int Kp, float* __restrict__ w_eff) {
+    __shared__ float sh[16];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < Cout; c += blockDim.x) s += part[c];
+    const float sigma = wg_sum256(s, sh);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)Cout * Kp; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = i / Kp, k = i % Kp;
+        w_eff[i] = k < K ? w[(size_t)c * K + k] / sigma : 0.f;
+    }
+}
+__global__ void pad_weight_kernel(const float* __restrict__ w, int Cout, int K, int Kp, float* __restrict__ w_eff) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)Cout * Kp) return;
+    const int c = i / Kp, k = i % Kp;
+    w_eff[i] = k < K ? w[(size_t)c * K + k] : 0.f;
+}
+// y[c][r][Y][X] = act( IN( src + bias ) [+ add] ),  src = x[c][r][Y][X]  or, with shuffle, x[4c + 2(Y&1) + (X&1)][r][Y/2][X/2]
+// one workgroup per (c, r); H, W are the OUTPUT sizes
+__global__ void __launch_bounds__(256) instnorm_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ add,
+                                                        float* __restrict__ y, int C, int R, int H, int W, int shuffle, int act) {
+    __shared__ float sh[16];
+    const int c = blockIdx.x / R, r = blockIdx.x % R, HW = H * W;
+    auto src = [&](int i) -> float {
+        if (!shuffle) return x[((size_t)c * R + r) * HW + i] + (bias ? bias[c] : 0.f);
+        const int Y = i / W, X = i % W, cs = 4 * c + 2 * (Y & 1) + (X & 1), h = H >> 1, w = W >> 1;
+        return x[(((size_t)cs * R + r) * h + (Y >> 1)) * w + (X >> 1)] + (bias ? bias[cs] : 0.f);
+    };
+    float s = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) s += src(i);
+    const float mean = wg_sum256(s, sh) / (float)HW;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) { const float d = src(i) - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)HW + 1e-5f);
+    const size_t o = ((size_t)c * R + r) * HW;
+    for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+        float v = (src(i) - mean) * rstd;
+        if (add) v += add[o + i];
+        y[o + i] = act_apply(v, act);
+    }
+}
+// latent_proj tail: LayerNorm over F = C*HW features of a row, Mish, stored CNHW ([C][R][HW]) for the conv stack
+__global__ void __launch_bounds__(1024) bigln_mish_cnhw_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                float* __restrict__ y, int R, int C, int HW) {
+    __shared__ float sh[16];
+    const int r = blockIdx.x; const size_t F = (size_t)C * HW;
+    const float* xr = x + (size_t)r * F;
+    float s = 0.f;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
+    const float mean = wg_sum256(s, sh) / (float)F;
+    float q = 0.f;
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
+    for (size_t i = threadIdx.x; i < F; i += blockDim.x) {
+        const int c = i / HW, p = i % HW;
+        y[((size_t)c * R + r) * HW + p] = act_apply((xr[i] - mean) * rstd * gamma[i] + beta[i], ACT_MISH);
+    }
+}
+// out[r][c][p] = sigmoid(x[c][r][p] + bias[c])      (CNHW -> NCHW)
+__global__ void sigmoid_nchw_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, int C, int R, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * R * HW) return;
+    const int p = i % HW, r = (i / HW) % R, c = i / ((size_t)HW * R);
+    const float v = x[i] + bias[c];
+    out[((size_t)r * C + c) * HW + p] = 1.0f / (1.0f + expf(-v));
+}
+
+struct ConvW { const float* w_eff; int cin, cout, Kp; };
+// out[Cout][R*H*W] = W_eff x im2col3(x)   (stride 1, pad 1);  col: scratch of Kp * R*H*W floats
+static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* col, float* out, hipStream_t s) {
+    const size_t N = (size_t)R * H * H;
+    L1D(im2col3_kernel, (size_t)cw.Kp * N, s, x, col, cw.cin, R, H, H, H, H, 1, cw.cin * 9, (size_t)cw.Kp * N);
+    GemmArgs ga = gemm_args(cw.w_eff, cw.Kp, col, (int)N, out, (int)N, cw.cout, (int)N, cw.Kp);
+    ga.b_kmajor = 1;
+    return gemm_f32(ga, s);
+}
+static int conv1_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
+    const size_t N = (size_t)R * H * H;
+    GemmArgs ga = gemm_args(cw.w_eff, cw.Kp, x, (int)N, out, (int)N, cw.cout, (int)N, cw.cin);
+    ga.b_kmajor = 1;
+    return gemm_f32(ga, s);
+}
+static int prep_weight(const AidSNConv& c, int cin, int cout, int k, Workspace& ws, ConvW& out, hipStream_t s) {
+    const int K = cin * k * k, Kp = (K + 31) / 32 * 32;
+    float* w_eff = ws.f32((size_t)cout * Kp); AID_WS_OK(ws);
+    if (c.u) {
+        float* part = ws.f32(cout); AID_WS_OK(ws);
+        hipLaunchKernelGGL(sn_rowdot_kernel, dim3(cout), dim3(256), 0, s, c.w, c.u, c.v, K, part);
+        hipLaunchKernelGGL(sn_scale_kernel, dim3(64), dim3(256), 0, s, c.w, part, cout, K, Kp, w_eff);
+    } else {
+        L1D(pad_weight_kernel, (size_t)cout * Kp, s, c.w, cout, K, Kp, w_eff);
+    }
+    AID_LAUNCH_CHECK();
+    out.w_eff = w_eff; out.cin = cin; out.cout = cout; out.Kp = Kp;
+    return AID_OK;
+}
 }  // namespace aid
 
 using namespace aid;
@@ -663,4 +774,75 @@ int aid_infonce_step(const AidDynamicsNet* dyn, int B, const float* latents, con
     return AID_OK;
 }
 
+
+size_t aid_conv_decoder_workspace(const AidConvDecoder* d, int R) {
+    if (!d || R <= 0) return 0;
+    const size_t H = d->hidden, hw = 21 * 21;
+    size_t n = 0;
+    n += (size_t)R * (4 * H) * 2 + (size_t)R * H * hw * 2;                  // latent_proj activations
+    n += 4u * 1024 * 1024;                                                  // W_eff images of every conv (< 3.2 M floats)
+    n += (size_t)R * 32 * 168 * 168 * 5;                                    // ping-pong activations + conv outputs at the largest resolution
+    n += (size_t)R * 288 * 168 * 168;                                       // im2col of the 32-channel 168x168 convs (the largest)
+    return sizeof(float) * n + (1 << 20);
+}
+
+int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, float* out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dec && z && out, AID_E_NULL, "aid_conv_decoder_forward: null argument");
+    AID_REQUIRE(R > 0 && R <= 64 && dec->hidden == 256 && dec->L > 0, AID_E_SHAPE, "aid_conv_decoder_forward: R=%d (chunk rows to <= 64), hidden=%d", R, dec->hidden);
+    hipStream_t s = (hipStream_t)stream;
+    const AidConvDecoder& d = *dec;
+    Workspace ws(wsp, ws_bytes);
+    const int H = d.hidden, L = d.L, HW0 = 441;
+    // ---- conv weights (eval-mode spectral norm: W / (u . W v))
+    ConvW m0[4], m1[4], rs[4], o0, o3, o6;
+    const int cin[4] = {H, H, H / 2, H / 4}, cout[4] = {H, H / 2, H / 4, H / 8}; const int up[4] = {0, 1, 1, 1};
+    for (int i = 0; i < 4; ++i) {
+        AID_TRY(prep_weight(d.blk[i].main0, cin[i], up[i] ? 4 * cout[i] : cout[i], 3, ws, m0[i], s));
+        AID_TRY(prep_weight(d.blk[i].main1, cout[i], cout[i], 3, ws, m1[i], s));
+        if (up[i]) AID_TRY(prep_weight(d.blk[i].res, cin[i], 4 * cout[i], 1, ws, rs[i], s));
+    }
+    AidSNConv t0 = {d.out0_w, nullptr, nullptr, d.out0_b}, t3 = {d.out3_w, nullptr, nullptr, d.out3_b}, t6 = {d.out6_w, nullptr, nullptr, d.out6_b};
+    AID_TRY(prep_weight(t0, H / 8, 32, 3, ws, o0, s)); AID_TRY(prep_weight(t3, 32, 32, 3, ws, o3, s)); AID_TRY(prep_weight(t6, 32, 3, 3, ws, o6, s));
+    // ---- latent_proj: Linear, LN, Mish, (Dropout: eval), Linear, LN over 112 896, Mish -> CNHW [256][R][21x21]
+    float* a0 = ws.f32((size_t)R * 4 * H); float* a1 = ws.f32((size_t)R * 4 * H); float* big = ws.f32((size_t)R * H * HW0);
+    const size_t amax = (size_t)R * 32 * 168 * 168;
+    float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
+    float* col = ws.f32((size_t)R * 288 * 168 * 168);
+    AID_WS_OK(ws);
+    AID_TRY(linear_fwd(z, L, d.l0.w, d.l0.b, a0, 4 * H, R, 4 * H, L, ACT_NONE, s));
+    AID_TRY(ln_act(a0, 4 * H, d.ln1.g, d.ln1.b, ACT_MISH, nullptr, a1, 4 * H, nullptr, R, 4 * H, s));
+    AID_TRY(linear_fwd(a1, 4 * H, d.l4.w, d.l4.b, big, H * HW0, R, H * HW0, 4 * H, ACT_NONE, s));
+    hipLaunchKernelGGL(bigln_mish_cnhw_kernel, dim3(R), dim3(1024), 0, s, big, d.ln5.g, d.ln5.b, xa, R, H, HW0);
+    AID_LAUNCH_CHECK();
+    // ---- decoder blocks
+    int hsz = 21;
+    float* x = xa; float* y = xb;
+    for (int i = 0; i < 4; ++i) {
+        const int ho = up[i] ? 2 * hsz : hsz, co = cout[i];
+        AID_TRY(conv3_fwd(m0[i], x, R, hsz, col, cv, s));                                                       // [co or 4co][R][hsz^2]
+        hipLaunchKernelGGL(instnorm_kernel, dim3(co * R), dim3(256), 0, s, cv, d.blk[i].main0.bias, (const float*)nullptr, y, co, R, ho, ho, up[i], ACT_MISH);
+        AID_LAUNCH_CHECK();
+        AID_TRY(conv3_fwd(m1[i], y, R, ho, col, cv, s));                                                        // [co][R][ho^2]
+        const float* resid = x;                                                                                 // identity residual (block 0)
+        if (up[i]) {
+            AID_TRY(conv1_fwd(rs[i], x, R, hsz, cr, s));                                                        // [4co][R][hsz^2]
+            hipLaunchKernelGGL(instnorm_kernel, dim3(co * R), dim3(256), 0, s, cr, d.blk[i].res.bias, (const float*)nullptr, cr + (size_t)4 * co * R * hsz * hsz,
+                               co, R, ho, ho, 1, ACT_NONE);
+            AID_LAUNCH_CHECK();
+            resid = cr + (size_t)4 * co * R * hsz * hsz;
+        }
+        // main = IN(conv2 + bias); out = Mish(main + residual)
+        hipLaunchKernelGGL(instnorm_kernel, dim3(co * R), dim3(256), 0, s, cv, d.blk[i].main1.bias, resid, y, co, R, ho, ho, 0, ACT_MISH);
+        AID_LAUNCH_CHECK();
+        float* t = x; x = y; y = t; hsz = ho;
+    }
+    // ---- output_proj: (conv, IN, Mish) x2, conv, sigmoid
+    AID_TRY(conv3_fwd(o0, x, R, hsz, col, cv, s));
+    hipLaunchKernelGGL(instnorm_kernel, dim3(32 * R), dim3(256), 0, s, cv, d.out0_b, (const float*)nullptr, y, 32, R, hsz, hsz, 0, ACT_MISH);
+    AID_TRY(conv3_fwd(o3, y, R, hsz, col, cv, s));
+    hipLaunchKernelGGL(instnorm_kernel, dim3(32 * R), dim3(256), 0, s, cv, d.out3_b, (const float*)nullptr, x, 32, R, hsz, hsz, 0, ACT_MISH);
+    AID_TRY(conv3_fwd(o6, x, R, hsz, col, cv, s));
+    L1D(sigmoid_nchw_kernel, (size_t)3 * R * hsz * hsz, s, cv, d.out6_b, out, 3, R, hsz * hsz);
+    return AID_OK;
+}
 }  // extern "C"

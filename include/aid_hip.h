@@ -322,6 +322,21 @@ int aid_reward_normalize(const float* rewards, int B, double* state, float* out,
 int aid_reward_normalize_global(const float* stats_src, int n_stats, const float* rewards, int B, double* state, float* out,
                                 void* stream);
 
+/* ---- ConvDecoder (pixel-mode observation decoder), forward / eval mode -------------------------------------------------------
+ * active_inference_diffusion/encoder/visual_encoders.py:228-459.  Spectral-normed convs carry weight_orig + u + v (legacy layout);
+ * plain convs have u = v = NULL. */
+typedef struct AidSNConv { const float *w, *u, *v, *bias; } AidSNConv;
+typedef struct AidDecoderBlock { AidSNConv main0, main1, res; } AidDecoderBlock;     /* res.w == NULL: identity residual */
+typedef struct AidConvDecoder {
+    int32_t L, hidden;
+    AidLinear l0; AidLN ln1; AidLinear l4; AidLN ln5;                    /* latent_proj.{0,1,4,5} */
+    AidDecoderBlock blk[4];
+    const float *out0_w, *out0_b, *out3_w, *out3_b, *out6_w, *out6_b;    /* output_proj.{0,3,6} */
+} AidConvDecoder;
+/* z [R, L] -> out [R, 3, 168, 168] (NCHW, in [0,1]); R <= 64 per call (callers chunk larger batches). */
+size_t aid_conv_decoder_workspace(const AidConvDecoder* dec, int R);
+int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- A13: DrQ-v2 pixel encoder (aid/encoder/visual_encoders.py:13-225) + RandomShiftAugmentation (:471-492) ----------
  * 4 x {conv3x3 (no bias, legacy spectral norm; stride 2,1,1,1; in_ch->32->64->128->256) -> GroupNorm -> Mish -> Dropout2d}
  * -> SpatialAttention -> flatten (NCHW order) -> LayerNorm(256*42*42) -> Linear -> LN -> Mish -> Dropout(.1) -> Linear -> LN -> tanh.

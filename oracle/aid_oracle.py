@@ -1015,3 +1015,46 @@ def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, 
     metrics["dynamics_loss"] = float(dloss)
     aux = {"latents": latents, "next_latents": next_latents, "encoded_obs": enc_obs.detach(), "encoded_next_obs": enc_next.detach()}
     return (metrics, grads_out, aux) if return_grads else metrics
+
+
+# ---------------------------------------------------------------------------------------------
+# (f)-1  ConvDecoder / DecoderBlock, eval mode            aid/encoder/visual_encoders.py:228-459
+# ---------------------------------------------------------------------------------------------
+def _sn_eval_weight(p: Params, name: str) -> Tensor:
+    """Legacy spectral_norm in eval mode: W / (u . W v) with the stored u, v (no power iteration)."""
+    w = p[name + ".weight_orig"]
+    wm = w.reshape(w.shape[0], -1)
+    return w / torch.dot(p[name + ".weight_u"], torch.mv(wm, p[name + ".weight_v"]))
+
+
+def decoder_block(p: Params, pre: str, x: Tensor, upsample: bool, has_residual: bool) -> Tensor:
+    """DecoderBlock.forward in eval mode (Dropout2d is the identity).  Sequential indices: non-upsample main_path = [conv0, IN, Mish,
+    Dropout2d, conv4, IN]; upsample = [conv0, PixelShuffle, IN, Mish, Dropout2d, conv5, IN]; residual_path = [conv1x1 (, PixelShuffle), IN]."""
+    i2 = 5 if upsample else 4
+    h = F.conv2d(x, _sn_eval_weight(p, pre + "main_path.0"), p[pre + "main_path.0.bias"], padding=1)
+    if upsample:
+        h = F.pixel_shuffle(h, 2)
+    h = F.mish(F.instance_norm(h, eps=1e-5))
+    h = F.instance_norm(F.conv2d(h, _sn_eval_weight(p, pre + f"main_path.{i2}"), p[pre + f"main_path.{i2}.bias"], padding=1), eps=1e-5)
+    if has_residual:
+        r = F.conv2d(x, _sn_eval_weight(p, pre + "residual_path.0"), p[pre + "residual_path.0.bias"])
+        if upsample:
+            r = F.pixel_shuffle(r, 2)
+        r = F.instance_norm(r, eps=1e-5)
+    else:
+        r = x
+    return F.mish(h + r)
+
+
+def conv_decoder_forward(p: Params, z: Tensor, pre: str = "observation_decoder.") -> Tensor:
+    """ConvDecoder.forward in eval mode: latent [R, L] -> image [R, 3, 168, 168] (three 2x sub-pixel upsamplings from 21x21)."""
+    R = z.shape[0]
+    h = F.mish(_ln(p, pre + "latent_proj.1", _lin(p, pre + "latent_proj.0", z)))
+    h = F.mish(_ln(p, pre + "latent_proj.5", _lin(p, pre + "latent_proj.4", h)))
+    h = h.view(R, -1, 21, 21)
+    for i, (up, res) in enumerate(((False, False), (True, True), (True, True), (True, True))):
+        h = decoder_block(p, pre + f"decoder_blocks.{i}.", h, up, res)
+    o = pre + "output_proj."
+    h = F.mish(F.instance_norm(F.conv2d(h, p[o + "0.weight"], p[o + "0.bias"], padding=1), eps=1e-5))
+    h = F.mish(F.instance_norm(F.conv2d(h, p[o + "3.weight"], p[o + "3.bias"], padding=1), eps=1e-5))
+    return torch.sigmoid(F.conv2d(h, p[o + "6.weight"], p[o + "6.bias"], padding=1))

@@ -44,3 +44,34 @@ def draw_encoder_params(specs, key: int):
             v = 1.0 + 0.1 * x
         out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).reshape(shape)
     return out
+
+
+def conv_decoder_specs(latent_dim: int, hidden: int = 256, img_channels: int = 3, spatial: int = 21):
+    """ConvDecoder.state_dict() layout (visual_encoders.py:243-330), in the reference's order."""
+    H = hidden
+    s = [("latent_proj.0.weight", (4 * H, latent_dim)), ("latent_proj.0.bias", (4 * H,)), ("latent_proj.1.weight", (4 * H,)), ("latent_proj.1.bias", (4 * H,)),
+         ("latent_proj.4.weight", (H * spatial * spatial, 4 * H)), ("latent_proj.4.bias", (H * spatial * spatial,)),
+         ("latent_proj.5.weight", (H * spatial * spatial,)), ("latent_proj.5.bias", (H * spatial * spatial,))]
+
+    def sn(name, cout, cin, k):
+        return [(name + ".bias", (cout,)), (name + ".weight_orig", (cout, cin, k, k)), (name + ".weight_u", (cout,)), (name + ".weight_v", (cin * k * k,))]
+    for i, (cin, cout, up) in enumerate(((H, H, False), (H, H // 2, True), (H // 2, H // 4, True), (H // 4, H // 8, True))):
+        b = f"decoder_blocks.{i}."
+        s += sn(b + "main_path.0", cout * 4 if up else cout, cin, 3)
+        s += sn(b + ("main_path.5" if up else "main_path.4"), cout, cout, 3)
+        if up:
+            s += sn(b + "residual_path.0", cout * 4, cin, 1)
+    for i, (cin, cout) in zip((0, 3, 6), ((H // 8, 32), (32, 32), (32, img_channels))):
+        s += [(f"output_proj.{i}.weight", (cout, cin, 3, 3)), (f"output_proj.{i}.bias", (cout,))]
+    return s
+
+
+def draw_conv_decoder_params(specs, key: int):
+    """Deterministic O(1)-activation weights for the ConvDecoder (same rules as draw_encoder_params); the last conv is scaled down so
+    that the sigmoid output stays away from saturation (a saturated image would hide errors from a parity check)."""
+    p = draw_encoder_params(specs, key)
+    for name, shape in specs:          # plain (not spectral-normed) convs of output_proj: fan-in scaling instead of the norm-gain rule
+        if len(shape) == 4 and name.endswith(".weight"):
+            p[name] = (p[name] - 1.0) / 0.1 / float(np.sqrt(np.prod(shape[1:])))
+    p["output_proj.6.weight"] = p["output_proj.6.weight"] * 0.5
+    return p

@@ -282,3 +282,19 @@ def test_pixel_agent_train_step_reference_golden(golden_dir):
     cs = np.array([float(got[n].double().sum()) for n in names])
     bad = np.abs(cs - g["checksum"]) > 2e-5 * g["abssum"] + 2e-5
     assert not bad.any(), [names[i] for i in np.nonzero(bad)[0]]
+
+
+def test_conv_decoder_forward_reference_golden(nat, golden_dir):
+    """ConvDecoder.forward (eval mode: spectral-normed 3x3 / 1x1 convs, PixelShuffle, InstanceNorm, Mish, sigmoid) against the
+    reference's own images (tests/golden/conv_decoder.npz) and the oracle."""
+    from oracle.encoder_weights import conv_decoder_specs, draw_conv_decoder_params
+    g = np.load(os.path.join(golden_dir, "conv_decoder.npz"))
+    L, R = (int(v) for v in g["dims"]); kw, kz = (int(v) for v in g["keys"])
+    p = draw_conv_decoder_params(conv_decoder_specs(L), kw)
+    pd = {"observation_decoder." + k: v.cuda().contiguous() for k, v in p.items()}
+    z = NoiseStream(kz).randn(R, L)
+    y = nat.conv_decoder_forward(nat.conv_decoder_table(pd), dev(z), chunk=2).cpu()       # chunk 2: exercises the row chunking (2 + 1)
+    assert tuple(y.shape) == (R, 3, 168, 168)
+    np.testing.assert_allclose(y.reshape(-1)[::61].numpy(), g["sample"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(y[1, :, 80, :].numpy(), g["row"], rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose([float(y[i].double().sum()) for i in range(R)], g["checksum"], rtol=2e-4)

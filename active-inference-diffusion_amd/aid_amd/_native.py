@@ -663,6 +663,16 @@ def feature_decoder_step(fd: AidFeatureDecoder, fgrads: AidFeatureDecoder, laten
     return loss
 
 
+def feature_decoder_forward(fd: AidFeatureDecoder, latents, drop_mask=None, ws: Workspace = None):
+    B = latents.shape[0]
+    out = torch.empty(B, fd.l4.out, device=latents.device, dtype=torch.float32)
+    ws = ws or Workspace(latents.device)
+    buf = ws.get(lib().aid_small_net_workspace(B, fd.l0.out))
+    check(lib().aid_feature_decoder_forward(C.byref(fd), B, _ptr(latents), _ptr(drop_mask), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()),
+                                            _stream()), "aid_feature_decoder_forward")
+    return out
+
+
 def infonce_step(dyn: AidDynamicsNet, latents, actions, next_enc, weight, d_next_enc, ws: Workspace = None):
     B = latents.shape[0]
     loss = torch.zeros(1, device=latents.device)

@@ -20,7 +20,8 @@ ALIGN = 64  # floats (256 B): keeps every tensor 16-B aligned for vector loads a
 
 
 class ParamArena:
-    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]], device, with_ema: bool = False):
+    def __init__(self, named_params: Sequence[Tuple[str, nn.Parameter]], device, with_ema: bool = False, trainable: bool = True):
+        """trainable=False: parameters only (no gradient / moment buffers) - the never-stepped decoder, reward predictor, ConvDecoder."""
         self.device = torch.device(device)
         self.names: List[str] = [n for n, _ in named_params]
         self.params: List[nn.Parameter] = [p for _, p in named_params]
@@ -31,9 +32,10 @@ class ParamArena:
             off += (p.numel() + ALIGN - 1) // ALIGN * ALIGN
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=self.device)
-        self.grad = torch.zeros_like(self.flat)
-        self.exp_avg = torch.zeros_like(self.flat)
-        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.trainable = trainable
+        self.grad = torch.zeros_like(self.flat) if trainable else self.flat.new_zeros(0)
+        self.exp_avg = torch.zeros_like(self.grad)
+        self.exp_avg_sq = torch.zeros_like(self.grad)
         self.ema = None
         self.step_count = 0
         self._scratch = torch.zeros(8192, dtype=torch.float32, device=self.device)
@@ -43,7 +45,7 @@ class ParamArena:
                 view = self.flat[o:o + p.numel()].view(shp)
                 view.copy_(p.data.to(self.device, torch.float32))
                 p.data = view
-                p.grad = self.grad[o:o + p.numel()].view(shp)
+                p.grad = self.grad[o:o + p.numel()].view(shp) if trainable else None
         if with_ema:
             self.ema = self.flat.clone()
 
@@ -70,7 +72,7 @@ class ParamArena:
                 with torch.no_grad():
                     self.flat[o:o + p.numel()].view(shp).copy_(p.data)
                 p.data = self.flat[o:o + p.numel()].view(shp)
-            p.grad = self.grad[o:o + p.numel()].view(shp)
+            p.grad = self.grad[o:o + p.numel()].view(shp) if self.trainable else None
 
     # -- fused clip -> AdamW -> EMA -----------------------------------------------------------------
     def step(self, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999, ext_sumsq: torch.Tensor = None):

@@ -118,6 +118,9 @@ class DiffusionActiveInference(nn.Module):
             self.feature_decoder = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Dropout(self.epistemic_dropout_rate),
                                                  nn.Linear(D, L), nn.Tanh())
             self.reward_predictor = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Linear(D, D // 2), nn.ReLU(), nn.Linear(D // 2, 2))
+            if self.pixel_shape is not None:      # ConvDecoder (active_inference.py:133-141): latent -> pixels, inference only
+                from ..encoder.visual_encoders import ConvDecoder
+                self.observation_decoder = ConvDecoder(latent_dim=L, output_dim=int(np.prod(self.pixel_shape)), img_channels=self.pixel_shape[0], hidden_dim=256)
             return
         p = self.epistemic_dropout_rate
         stage = lambda i, o: nn.Sequential(nn.Linear(i, o), nn.LayerNorm(o), nn.SiLU(), nn.Dropout(p))
@@ -157,7 +160,9 @@ class DiffusionActiveInference(nn.Module):
             self._epi_tab = TableCache(lambda: nat.epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
                                                                      if not n.startswith("decoder.")}, ""))
             self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
-        self.arenas["frozen"] = ParamArena(frozen, device)   # never stepped; an arena only for alignment + one-shot zeroing
+        if self.is_pixel_observation and hasattr(self, "observation_decoder"):
+            frozen += [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
+        self.arenas["frozen"] = ParamArena(frozen, device, trainable=False)   # never stepped: parameters only
         self.device = torch.device(device)
 
     def to(self, device, *a, **k):
@@ -199,7 +204,18 @@ class DiffusionActiveInference(nn.Module):
 
     # ------------------------------------------------------------------------------------------ A4
     def decode_observation(self, latent: torch.Tensor, decode_to_pixels: bool = True, masks=None) -> torch.Tensor:
+        """active_inference.py:217-242.  Pixel mode: the ConvDecoder image (inference only: the decoder must be in eval mode) or, with
+        decode_to_pixels=False, the feature decoder's reconstruction of the encoder features."""
         latent = latent.to(self.device).contiguous().float()
+        if self.is_pixel_observation:
+            if decode_to_pixels:
+                return self.observation_decoder(latent)
+            fd = self._fd_tab.get(self.feature_decoder)
+            m = None
+            if self.feature_decoder.training:
+                m = torch.empty(latent.shape[0], self.config.hidden_dim, device=self.device)
+                nat.fill_dropout_mask(m, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(m.numel()))
+            return nat.feature_decoder_forward(fd, latent, m, self._ws)
         if self.observation_decoder.training and masks is None:
             D, B = self.config.hidden_dim, latent.shape[0]
             masks = [torch.empty(B, w, device=self.device) for w in (2 * D, 2 * D, D)]

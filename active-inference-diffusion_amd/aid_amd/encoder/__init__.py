@@ -1,3 +1,3 @@
-from .visual_encoders import DrQV2Encoder, RandomShiftAugmentation, SpatialAttention
+from .visual_encoders import ConvDecoder, DecoderBlock, DrQV2Encoder, RandomShiftAugmentation, SpatialAttention
 
-__all__ = ["DrQV2Encoder", "RandomShiftAugmentation", "SpatialAttention"]
+__all__ = ["ConvDecoder", "DecoderBlock", "DrQV2Encoder", "RandomShiftAugmentation", "SpatialAttention"]

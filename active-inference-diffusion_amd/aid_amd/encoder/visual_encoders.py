@@ -127,6 +127,74 @@ class DrQV2Encoder(nn.Module):
                              train=train, ws=self._ws)
 
 
+class _SNConvBias(nn.Module):
+    """Holder for a conv with bias under legacy spectral_norm (state_dict order: bias, weight_orig, weight_u, weight_v)."""
+
+    def __init__(self, cin: int, cout: int, k: int):
+        super().__init__()
+        conv = nn.Conv2d(cin, cout, k, padding=k // 2)
+        nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")      # ConvDecoder._initialize_weights sees `weight`
+        self.bias = nn.Parameter(torch.zeros(cout))
+        self.weight_orig = nn.Parameter(conv.weight.detach().clone())
+        self.register_buffer("weight_u", F.normalize(torch.randn(cout), dim=0, eps=1e-12))
+        self.register_buffer("weight_v", F.normalize(torch.randn(cin * k * k), dim=0, eps=1e-12))
+
+    forward = native_only("spectral-norm conv")
+
+
+class DecoderBlock(nn.Module):
+    """visual_encoders.py:355-459 (parameter holder; indices of the reference's nn.Sequential are kept so the keys match)."""
+
+    def __init__(self, in_channels: int, out_channels: int, upsample: bool = False, use_spectral_norm: bool = True):
+        super().__init__()
+        self.upsample = upsample
+        noop = nn.Identity
+        main = [_SNConvBias(in_channels, out_channels * 4 if upsample else out_channels, 3)]
+        main += ([noop()] if upsample else []) + [noop(), noop(), noop(), _SNConvBias(out_channels, out_channels, 3), noop()]
+        self.main_path = nn.Sequential(*main)
+        if in_channels != out_channels or upsample:
+            self.residual_path = nn.Sequential(_SNConvBias(in_channels, out_channels * 4 if upsample else out_channels, 1), noop(), noop())
+        else:
+            self.residual_path = nn.Identity()
+
+    forward = native_only("DecoderBlock")
+
+
+class ConvDecoder(nn.Module):
+    """ConvDecoder (visual_encoders.py:228-352): latent -> [B, 3, 168, 168] image in [0, 1]; state_dict layout of the reference.
+    Forward (inference only: the reference never trains it - SURVEY D11 - and the estimator runs it in eval mode) on HIP
+    (`aid_conv_decoder_forward`)."""
+
+    def __init__(self, latent_dim: int, output_dim: int = 0, img_channels: int = 3, hidden_dim: int = 256, spatial_size: int = 21,
+                 use_spectral_norm: bool = True, device=None):
+        super().__init__()
+        if hidden_dim != 256 or spatial_size != 21 or img_channels != 3 or not use_spectral_norm:
+            raise NotImplementedError("only the configuration the reference instantiates is built (active_inference.py:133-141)")
+        self.latent_dim, self.output_dim, self.spatial_size, self.img_channels = latent_dim, output_dim, spatial_size, img_channels
+        H = hidden_dim
+        self.latent_proj = nn.Sequential(nn.Linear(latent_dim, 4 * H), nn.LayerNorm(4 * H), nn.Mish(), nn.Dropout(0.2),
+                                         nn.Linear(4 * H, H * spatial_size * spatial_size), nn.LayerNorm(H * spatial_size * spatial_size), nn.Mish())
+        for m in self.latent_proj:
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight); nn.init.zeros_(m.bias)
+        self.decoder_blocks = nn.ModuleList([DecoderBlock(H, H, False), DecoderBlock(H, H // 2, True), DecoderBlock(H // 2, H // 4, True),
+                                             DecoderBlock(H // 4, H // 8, True)])
+        self.output_proj = nn.Sequential(nn.Conv2d(H // 8, 32, 3, padding=1), nn.Identity(), nn.Identity(), nn.Conv2d(32, 32, 3, padding=1), nn.Identity(),
+                                         nn.Identity(), nn.Conv2d(32, img_channels, 3, padding=1), nn.Identity())
+        for m in self.output_proj:
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu"); nn.init.zeros_(m.bias)
+        self._tab = TableCache(lambda: nat.conv_decoder_table({**{n: p.data for n, p in self.named_parameters()}, **dict(self.named_buffers())}, ""))
+        self._ws = None
+
+    def forward(self, latent: torch.Tensor, chunk: int = 16) -> torch.Tensor:
+        if self.training:
+            raise NotImplementedError("ConvDecoder is built for inference (eval mode): call .eval() first; the reference never trains it")
+        if self._ws is None:
+            self._ws = nat.Workspace(latent.device)
+        return nat.conv_decoder_forward(self._tab.get(self), latent.contiguous().float(), chunk=chunk, ws=self._ws)
+
+
 class RandomShiftAugmentation(nn.Module):
     """Reflect-pad by `pad`, then crop each sample at an independent random offset (visual_encoders.py:471-492)."""
 

@@ -747,6 +747,17 @@ int aid_feature_decoder_step(const AidFeatureDecoder* fd, const AidFeatureDecode
     return AID_OK;
 }
 
+int aid_feature_decoder_forward(const AidFeatureDecoder* fd, int B, const float* latents, const float* drop_mask, float* out, void* wsp, size_t ws_bytes,
+                                void* stream) {
+    AID_REQUIRE(fd && latents && out, AID_E_NULL, "aid_feature_decoder_forward: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const int L = fd->l0.in, D = fd->l0.out, Lo = fd->l4.out;
+    LlaSave s0; lla_alloc(B, D, ws, s0); AID_WS_OK(ws);
+    AID_TRY(lla_fwd(fd->l0, fd->ln, ACT_RELU, drop_mask, latents, L, B, s0, s));
+    return linear_fwd(s0.y, D, fd->l4.w, fd->l4.b, out, Lo, B, Lo, D, ACT_TANH, s);
+}
+
 int aid_infonce_step(const AidDynamicsNet* dyn, int B, const float* latents, const float* actions, const float* next_enc, float weight,
                      float* d_next_enc, float* loss_out, void* wsp, size_t ws_bytes, void* stream) {
     AID_REQUIRE(dyn && latents && actions && next_enc && d_next_enc && loss_out, AID_E_NULL, "aid_infonce_step: null argument");

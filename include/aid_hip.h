@@ -272,6 +272,9 @@ int aid_adam_l2_step(float* p, const float* g, float* m, float* v, size_t n, flo
  * feature decoder Linear(L,D) LN ReLU Dropout(.2) Linear(D,L) Tanh: recon = mse(fd(latents), target); loss contribution +recon.
  * Accumulates parameter gradients into fgrads and d(recon)/d(target) into d_target [B,L]; recon -> *loss_out (device). */
 typedef struct AidFeatureDecoder { AidLinear l0; AidLN ln; AidLinear l4; } AidFeatureDecoder;
+/* forward only: out [B, L] = tanh(Linear(Dropout(ReLU(LN(Linear(latents))))))  (decode_observation(decode_to_pixels=False), :227-231) */
+int aid_feature_decoder_forward(const AidFeatureDecoder* fd, int B, const float* latents, const float* drop_mask, float* out, void* ws, size_t ws_bytes,
+                                void* stream);
 int aid_feature_decoder_step(const AidFeatureDecoder* fd, const AidFeatureDecoder* fgrads, int B, const float* latents,
                              const float* target, const float* drop_mask, float* d_target, float* loss_out, void* ws, size_t ws_bytes,
                              void* stream);

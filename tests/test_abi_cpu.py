@@ -42,11 +42,11 @@ def test_library_exports_every_declared_symbol(nat):
 def test_ctypes_structs_match_c_layout(nat, tmp_path):
     structs = ["AidDiTBlock", "AidScoreNet", "AidLinear", "AidLN", "AidPolicyNet", "AidValueNet", "AidDynamicsNet", "AidRewardNet",
                "AidDecoderNet", "AidEpistemicNet", "AidDiffusionParams", "AidElboNoise", "AidElboCfg", "AidEfeNoise", "AidEfeCfg",
-               "AidEncoderNet", "AidFeatureDecoder"]
+               "AidEncoderNet", "AidFeatureDecoder", "AidSNConv", "AidDecoderBlock", "AidConvDecoder"]
     probes = {"AidScoreNet": ["blk", "adaf_w", "op2_w"], "AidPolicyNet": ["trunk", "lstd2"], "AidValueNet": ["net", "out"],
               "AidEpistemicNet": ["jp_ln", "mn6"], "AidElboCfg": ["seed", "defer_time_importance"], "AidEfeCfg": ["epistemic_weight", "seed"],
               "AidDecoderNet": ["ln", "out"], "AidLinear": ["out"], "AidElboNoise": ["d_obs_out"], "AidEncoderNet": ["att_conv_b", "out5"],
-              "AidFeatureDecoder": ["l4"]}
+              "AidFeatureDecoder": ["l4"], "AidConvDecoder": ["blk", "out6_b"], "AidDecoderBlock": ["res"]}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for s in structs:
         lines.append(f'printf("{s} %zu\\n", sizeof({s}));')

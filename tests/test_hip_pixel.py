@@ -143,6 +143,7 @@ def _load_pixel_params(agent, L, A, D, N, key):
     sd = ai.state_dict()
     full = {k: (p[k] if k in p else v.cpu().clone()) for k, v in sd.items()}
     ai.load_state_dict(full, strict=True)
+    full = {k: v for k, v in full.items() if not k.startswith("observation_decoder.")}      # the oracle's train_step does not model the ConvDecoder
     pe = draw_encoder_params(encoder_specs(L), key + 1)
     agent.encoder.load_state_dict(pe, strict=True)
     merged = {k: v.clone() for k, v in full.items()}
@@ -256,8 +257,8 @@ def test_pixel_agent_train_step_reference_golden(golden_dir):
     p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}
     p.update(draw_feature_decoder(L, D, kf))
     sd = ai.state_dict()
-    assert set(p) == set(sd), set(p) ^ set(sd)
-    ai.load_state_dict(p, strict=True)
+    assert set(p) == {k for k in sd if not k.startswith("observation_decoder.")}, set(p) ^ set(sd)     # + the ConvDecoder (own init)
+    ai.load_state_dict({**sd, **p}, strict=True)
     agent.encoder.load_state_dict(draw_encoder_params(encoder_specs(L), ke), strict=True)
     bs = NoiseStream(ks)
     obs = bs.rand(CAP, 3, 3, 84, 84); act = np.tanh(bs.randn(CAP, A)).astype(np.float32); rew = bs.randn(CAP); nobs = bs.rand(CAP, 3, 3, 84, 84)
@@ -298,3 +299,24 @@ def test_conv_decoder_forward_reference_golden(nat, golden_dir):
     np.testing.assert_allclose(y.reshape(-1)[::61].numpy(), g["sample"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose(y[1, :, 80, :].numpy(), g["row"], rtol=2e-3, atol=2e-4)
     np.testing.assert_allclose([float(y[i].double().sum()) for i in range(R)], g["checksum"], rtol=2e-4)
+
+
+def test_pixel_decode_observation_paths():
+    """decode_observation in pixel mode: ConvDecoder image (eval) == oracle; feature reconstruction == oracle's feature_decoder."""
+    L, A, D, N = 16, 4, 64, 3
+    agent = _pixel_agent(L, A, D, N, 1, 2, cap=4)
+    ai = agent.active_inference
+    sd = {k: v.cpu() for k, v in ai.state_dict().items()}
+    z = NoiseStream(3).randn(3, L)
+    ai.eval()
+    img = ai.decode_observation(dev(z), decode_to_pixels=True)
+    assert tuple(img.shape) == (3, 3, 168, 168)
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        ref = orc.conv_decoder_forward(sd, torch.from_numpy(z))
+        ref_f = orc.feature_decoder(sd, torch.from_numpy(z), None, False)
+    np.testing.assert_allclose(img.cpu().numpy(), ref.numpy(), rtol=2e-3, atol=2e-4)
+    np.testing.assert_allclose(ai.decode_observation(dev(z), decode_to_pixels=False).cpu().numpy(), ref_f.numpy(), rtol=1e-3, atol=2e-5)
+    ai.train()
+    with pytest.raises(NotImplementedError):
+        ai.decode_observation(dev(z), decode_to_pixels=True)

@@ -241,7 +241,7 @@ def lib() -> C.CDLL:
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
                  "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
-                 "aid_conv_decoder_workspace"):
+                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -425,9 +425,10 @@ EFE_INFO = ("policy_loss", "epistemic_mean", "pragmatic_mean", "consistency_mean
 
 def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizon=5, num_trajectories=10, num_samples=10, noise=None,
              train=True, skip_epistemic=False, epistemic_weight=0.1, pragmatic_weight=1.0, consistency_weight=0.1, discount=0.99,
-             temperature=1.0, mine_alpha=0.01, seed=0, offset=0, ws: Workspace = None):
+             temperature=1.0, mine_alpha=0.01, seed=0, offset=0, ws: Workspace = None, next_means_out=None):
     """compute_expected_free_energy_diffusion (+ policy backward when pgrads is given).
-    -> (efe [B], info [16] device tensor); running_mean (device scalar tensor) is updated in place."""
+    -> (efe [B], info [16] device tensor); running_mean (device scalar tensor) is updated in place.  next_means_out [H, K*B, L]
+    (optional) receives the dynamics means of every horizon step."""
     B = latents.shape[0]
     nz = AidEfeNoise(); noise = noise or {}
     for k, _ in AidEfeNoise._fields_:
@@ -444,9 +445,9 @@ def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizo
     ws = ws or Workspace(latents.device)
     decp = C.byref(dec) if dec is not None else None
     buf = ws.get(lib().aid_efe_step_workspace(C.byref(pol), decp, B, C.byref(cfg)))
-    check(lib().aid_efe_step(C.byref(pol), C.byref(pgrads) if pgrads is not None else None, C.byref(dyn), C.byref(rew), C.byref(val),
-                             decp, C.byref(epi) if epi is not None else None, B, _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(running_mean), _ptr(efe), _ptr(info),
-                             C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_efe_step")
+    check(lib().aid_efe_step_ex(C.byref(pol), C.byref(pgrads) if pgrads is not None else None, C.byref(dyn), C.byref(rew), C.byref(val),
+                                decp, C.byref(epi) if epi is not None else None, B, _ptr(latents), C.byref(nz), C.byref(cfg), _ptr(running_mean), _ptr(efe), _ptr(info),
+                                _ptr(next_means_out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_efe_step")
     return efe, info
 
 
@@ -758,3 +759,54 @@ def conv_decoder_forward(dec: AidConvDecoder, z, chunk: int = 16, ws: Workspace 
         check(lib().aid_conv_decoder_forward(C.byref(dec), n, _ptr(z[r0:r0 + n]), _ptr(out[r0:r0 + n]), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()),
                                              _stream()), "aid_conv_decoder_forward")
     return out
+
+
+class AidPixelEpistemicNet(C.Structure):
+    _fields_ = ([("L", C.c_int32), ("_pad", C.c_int32), ("perturbation_scale", C.c_void_p)]
+                + [(n, C.c_void_p) for n in ("pp0_w", "pp0_b", "pp2_w", "pp2_b", "pp4_w", "pp4_b", "pos", "queries", "in_proj_w", "in_proj_b")]
+                + [("att_out", AidLinear), ("agg0", AidLinear), ("agg_ln", AidLN), ("agg3", AidLinear), ("jp0", AidLinear), ("jp_ln", AidLN), ("jp4", AidLinear),
+                   ("lp0", AidLinear), ("lp2", AidLinear), ("mn0", AidLinear), ("mn3", AidLinear), ("mn6", AidLinear)])
+
+
+def pixel_epistemic_table(params, prefix: str = "epistemic_estimator.") -> AidPixelEpistemicNet:
+    t = AidPixelEpistemicNet()
+    g = lambda k: _ptr(params[prefix + k]).value
+    t.L = params[prefix + "latent_processor.0.weight"].shape[1]
+    t.perturbation_scale = g("perturbation_scale")
+    for i in (0, 2, 4):
+        setattr(t, f"pp{i}_w", g(f"pixel_processor.{i}.weight")); setattr(t, f"pp{i}_b", g(f"pixel_processor.{i}.bias"))
+    a = "spatial_aggregator."
+    t.pos, t.queries, t.in_proj_w, t.in_proj_b = g(a + "pos_encoding"), g(a + "epistemic_queries"), g(a + "attention.in_proj_weight"), g(a + "attention.in_proj_bias")
+    t.att_out = _lin(params, prefix + a + "attention.out_proj"); t.agg0 = _lin(params, prefix + a + "output_proj.0")
+    t.agg_ln = _ln(params, prefix + a + "output_proj.1"); t.agg3 = _lin(params, prefix + a + "output_proj.3")
+    t.jp0 = _lin(params, prefix + "jacobian_projector.0"); t.jp_ln = _ln(params, prefix + "jacobian_projector.1"); t.jp4 = _lin(params, prefix + "jacobian_projector.4")
+    t.lp0, t.lp2 = _lin(params, prefix + "latent_processor.0"), _lin(params, prefix + "latent_processor.2")
+    t.mn0, t.mn3, t.mn6 = (_lin(params, prefix + f"mine_network.{k}") for k in (0, 3, 6))
+    return t
+
+
+def pixel_epistemic_value(dec: AidConvDecoder, epi: AidPixelEpistemicNet, next_mean, K: int, S: int, noise=None, train=True, seed=0, offset=0,
+                          ws: Workspace = None):
+    """One horizon step's pixel-mode MINE statistics for all K trajectories.  -> mine [K, 4] = joint, marginal term, t_exp, mi"""
+    B = next_mean.shape[0] // K
+    nz = AidEfeNoise(); noise = noise or {}
+    for k, _ in AidEfeNoise._fields_:
+        v = noise.get(k)
+        if k == "perms" and v is not None:
+            assert v.dtype == torch.int32 and v.is_cuda and v.is_contiguous()
+            setattr(nz, k, v.data_ptr())
+        else:
+            setattr(nz, k, _ptr(v).value)
+    out = torch.zeros(K, 4, device=next_mean.device, dtype=torch.float32)
+    ws = ws or Workspace(next_mean.device)
+    buf = ws.get(lib().aid_pixel_epistemic_workspace(C.byref(dec), K, S, B))
+    check(lib().aid_pixel_epistemic_value(C.byref(dec), C.byref(epi), K, S, B, _ptr(next_mean.contiguous()), C.byref(nz), _ptr(noise.get("attn_mask")),
+                                          int(bool(train)), C.c_uint64(seed), C.c_uint64(offset), _ptr(out), C.c_void_p(buf.data_ptr()),
+                                          C.c_size_t(buf.numel()), _stream()), "aid_pixel_epistemic_value")
+    return out
+
+
+def efe_add_epistemic(mine_all, efe, info, running_mean, epistemic_weight=0.1, discount=0.99, alpha=0.01):
+    H, K = mine_all.shape[0], mine_all.shape[1]
+    check(lib().aid_efe_add_epistemic(_ptr(mine_all.contiguous()), H, K, efe.shape[0], C.c_float(epistemic_weight), C.c_float(discount), C.c_float(alpha),
+                                      _ptr(running_mean), _ptr(efe), _ptr(info), _stream()), "aid_efe_add_epistemic")

@@ -27,6 +27,21 @@ from ..noise import NoiseSource, PhiloxNoise
 from .diffusion import LatentDiffusionProcess
 
 
+class SpatialAttentionAggregator(nn.Module):
+    """Parameter holder of utils/util.py:7-75: 16 learnable queries attend over the 21x21 feature tokens (nn.MultiheadAttention, 8 heads,
+    attention dropout 0.1), then Linear-LN-GELU-Linear.  Evaluated by `aid_pixel_epistemic_value`."""
+
+    def __init__(self, feature_dim: int = 128, num_heads: int = 8, spatial_dim: int = 21):
+        super().__init__()
+        self.feature_dim, self.num_heads, self.head_dim = feature_dim, num_heads, feature_dim // num_heads
+        self.pos_encoding = nn.Parameter(torch.randn(1, spatial_dim * spatial_dim, feature_dim) * 0.02)
+        self.attention = nn.MultiheadAttention(embed_dim=feature_dim, num_heads=num_heads, dropout=0.1, batch_first=True)
+        self.epistemic_queries = nn.Parameter(torch.randn(1, 16, feature_dim) * 0.02)
+        self.output_proj = nn.Sequential(nn.Linear(16 * feature_dim, 512), nn.LayerNorm(512), nn.GELU(), nn.Linear(512, 256))
+
+    forward = native_only("SpatialAttentionAggregator")
+
+
 class FunctionSpaceEpistemicEstimator(nn.Module):
     """Parameter holder of the MINE estimator (active_inference.py:839-1063, state branch).  Evaluated inside `aid_efe_step`;
     trained by `DiffusionActiveInference.train_epistemic_estimator` (`aid_mine_train_step`)."""
@@ -34,14 +49,21 @@ class FunctionSpaceEpistemicEstimator(nn.Module):
     def __init__(self, decoder: nn.Module, latent_dim: int, observation_shape: int, hidden_dim: int = 256,
                  spatial_aggregator_output_dim: int = 256, is_pixel_observation: bool = False, device="cuda"):
         super().__init__()
-        if is_pixel_observation:
-            raise NotImplementedError("pixel-mode epistemic path (ConvDecoder / SpatialAttentionAggregator) is SURVEY §8(f) rank 1: next")
-        self.decoder, self.latent_dim, self.is_pixel = decoder, latent_dim, False
-        self.ntk_samples, self.alpha, self.state_dim = 4, 0.01, observation_shape
+        self.decoder, self.latent_dim, self.is_pixel = decoder, latent_dim, bool(is_pixel_observation)
+        self.ntk_samples, self.alpha = 4, 0.01
         self.perturbation_scale = nn.Parameter(torch.tensor(0.1))
         self.register_buffer("running_mean", torch.tensor(0.0))
-        self.feature_extractor = nn.Sequential(nn.Linear(observation_shape, 128), nn.ReLU(), nn.Linear(128, 256), nn.ReLU(), nn.Linear(256, 128))
-        self.jacobian_projector = nn.Sequential(nn.Linear(128 * self.ntk_samples, 512), nn.LayerNorm(512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 256))
+        if self.is_pixel:       # active_inference.py:865-883
+            self.pixel_shape = observation_shape
+            self.pixel_processor = nn.Sequential(nn.Conv2d(observation_shape[0], 32, 5, stride=2, padding=2), nn.ReLU(), nn.Conv2d(32, 64, 5, stride=2, padding=2),
+                                                 nn.ReLU(), nn.Conv2d(64, 128, 5, stride=2, padding=2), nn.ReLU())
+            self.spatial_aggregator = SpatialAttentionAggregator(feature_dim=128, num_heads=8, spatial_dim=21)
+            jacobian_dim = spatial_aggregator_output_dim * self.ntk_samples
+        else:
+            self.state_dim = observation_shape
+            self.feature_extractor = nn.Sequential(nn.Linear(observation_shape, 128), nn.ReLU(), nn.Linear(128, 256), nn.ReLU(), nn.Linear(256, 128))
+            jacobian_dim = 128 * self.ntk_samples
+        self.jacobian_projector = nn.Sequential(nn.Linear(jacobian_dim, 512), nn.LayerNorm(512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 256))
         self.latent_processor = nn.Sequential(nn.Linear(latent_dim, 128), nn.ReLU(), nn.Linear(128, 128))
         self.mine_network = nn.Sequential(nn.Linear(spatial_aggregator_output_dim + 128, 512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 512),
                                           nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 1))
@@ -94,6 +116,9 @@ class DiffusionActiveInference(nn.Module):
         self._to_device_and_flatten(self.device)
         self.current_latent, self.latent_trajectory = None, []
         self._ws = nat.Workspace(self.device)
+        # Pixel mode: the reference always evaluates its ConvDecoder-based estimator inside the EFE (40 GFLOP per sample row, K*S*B = 25 600
+        # rows per horizon step at the default sizes: ~5 PFLOP per train_step).  It is gradient-free, so it is opt-in here.
+        self.pixel_epistemic = False
         self.param_version = 0          # bumped whenever parameters change outside an optimiser step (load_state_dict, broadcast)
 
     # ------------------------------------------------------------------------------------------ construction
@@ -120,7 +145,9 @@ class DiffusionActiveInference(nn.Module):
             self.reward_predictor = nn.Sequential(nn.Linear(L, D), nn.LayerNorm(D), nn.ReLU(), nn.Linear(D, D // 2), nn.ReLU(), nn.Linear(D // 2, 2))
             if self.pixel_shape is not None:      # ConvDecoder (active_inference.py:133-141): latent -> pixels, inference only
                 from ..encoder.visual_encoders import ConvDecoder
-                self.observation_decoder = ConvDecoder(latent_dim=L, output_dim=int(np.prod(self.pixel_shape)), img_channels=self.pixel_shape[0], hidden_dim=256)
+                self.observation_decoder = ConvDecoder(latent_dim=L, output_dim=int(np.prod(self.pixel_shape)), img_channels=self.pixel_shape[0], hidden_dim=D)
+                self.epistemic_estimator = FunctionSpaceEpistemicEstimator(self.observation_decoder, L, tuple(self.pixel_shape), D,
+                                                                           self.config.spatial_aggregator_output_dim, True, self.device)
             return
         p = self.epistemic_dropout_rate
         stage = lambda i, o: nn.Sequential(nn.Linear(i, o), nn.LayerNorm(o), nn.SiLU(), nn.Dropout(p))
@@ -162,6 +189,10 @@ class DiffusionActiveInference(nn.Module):
             self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
         if self.is_pixel_observation and hasattr(self, "observation_decoder"):
             frozen += [("observation_decoder." + n, p) for n, p in self.observation_decoder.named_parameters()]
+            frozen += [("epistemic_estimator." + n, p) for n, p in self.epistemic_estimator.named_parameters() if not n.startswith("decoder.")]
+            self._pepi_tab = TableCache(lambda: nat.pixel_epistemic_table({n: p.data for n, p in self.epistemic_estimator.named_parameters()
+                                                                            if not n.startswith("decoder.")}, ""))
+            self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
         self.arenas["frozen"] = ParamArena(frozen, device, trainable=False)   # never stepped: parameters only
         self.device = torch.device(device)
 
@@ -179,13 +210,13 @@ class DiffusionActiveInference(nn.Module):
         return t
 
     def state_dict(self, *a, **k):
-        if not self.is_pixel_observation:
+        if hasattr(self, "epistemic_estimator"):
             self.epistemic_estimator.running_mean = self._running_mean.reshape(()).clone()
         return super().state_dict(*a, **k)
 
     def load_state_dict(self, sd, strict: bool = True):
         out = super().load_state_dict(sd, strict=strict)
-        if not self.is_pixel_observation:
+        if hasattr(self, "epistemic_estimator"):
             self._running_mean = self.epistemic_estimator.running_mean.reshape(1).float().contiguous()
         self.arenas["score"].reset_ema()
         self.latent_diffusion._coefs = None
@@ -292,13 +323,22 @@ class DiffusionActiveInference(nn.Module):
         if noise is None:
             noise = self.noise.efe(latent.shape[0], self.latent_dim, self.action_dim, horizon, num_trajectories, num_ambiguity_samples)
         pix = self.is_pixel_observation
+        pix_epi = pix and self.pixel_epistemic and hasattr(self, "epistemic_estimator")
+        B, K, S, H = latent.shape[0], num_trajectories, num_ambiguity_samples, horizon
+        next_means = torch.empty(H, K * B, self.latent_dim, device=self.device) if pix_epi else None
         efe, info = nat.efe_step(self.policy_network.table(), self.policy_network.grad_table() if backward else None, self.latent_dynamics.table(),
                                  self.reward_table(), self.value_network.table(), None if pix else self.decoder_table(),
                                  None if pix else self.epistemic_table(), latent,
                                  self._running_mean, horizon, num_trajectories, num_ambiguity_samples, noise=noise,
                                  train=self.training, skip_epistemic=pix, epistemic_weight=c.epistemic_weight, pragmatic_weight=c.pragmatic_weight,
                                  consistency_weight=c.consistency_weight, discount=c.discount_factor, temperature=float(c.preference_temperature),
-                                 mine_alpha=0.01, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
+                                 mine_alpha=0.01, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws, next_means_out=next_means)
+        if pix_epi:   # gradient-free pixel estimator on the rollout's dynamics means, added to the EFE afterwards (same value, no gradient)
+            dec, epi = self.observation_decoder._tab.get(self.observation_decoder), self._pepi_tab.get(self.epistemic_estimator)
+            per_t = (noise or {}).get("pixel_epistemic")
+            mine_all = torch.stack([nat.pixel_epistemic_value(dec, epi, next_means[t], K, S, noise=per_t[t] if per_t else None, train=self.training,
+                                                              seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws) for t in range(H)])
+            nat.efe_add_epistemic(mine_all, efe, info, self._running_mean, c.epistemic_weight, c.discount_factor, 0.01)
         out = {k: info[i] for i, k in enumerate(nat.EFE_INFO) if k != "policy_loss"}
         out.update({"num_trajectories": num_trajectories, "horizon": horizon, "epistemic/running_mean": self._running_mean[0],
                     "policy_loss": info[0]})

@@ -168,8 +168,9 @@ class ConvDecoder(nn.Module):
     def __init__(self, latent_dim: int, output_dim: int = 0, img_channels: int = 3, hidden_dim: int = 256, spatial_size: int = 21,
                  use_spectral_norm: bool = True, device=None):
         super().__init__()
-        if hidden_dim != 256 or spatial_size != 21 or img_channels != 3 or not use_spectral_norm:
-            raise NotImplementedError("only the configuration the reference instantiates is built (active_inference.py:133-141)")
+        if hidden_dim < 64 or hidden_dim % 32 or spatial_size != 21 or img_channels != 3 or not use_spectral_norm:
+            raise NotImplementedError("built for hidden_dim % 32 == 0 (>= 64), spatial_size 21, 3 image channels, spectral norm "
+                                      "(what active_inference.py:133-141 instantiates)")
         self.latent_dim, self.output_dim, self.spatial_size, self.img_channels = latent_dim, output_dim, spatial_size, img_channels
         H = hidden_dim
         self.latent_proj = nn.Sequential(nn.Linear(latent_dim, 4 * H), nn.LayerNorm(4 * H), nn.Mish(), nn.Dropout(0.2),

@@ -9,6 +9,7 @@
 // Spectral normalisation follows the LEGACY torch.nn.utils.spectral_norm semantics the reference uses: one power iteration per
 // training forward mutating u/v, sigma = u.(W v) with u, v constant in the backward.
 #include "mlp.h"
+#include "score_net.h"   // philox_fill
 
 namespace aid {
 
@@ -792,17 +793,24 @@ size_t aid_conv_decoder_workspace(const AidConvDecoder* d, int R) {
     size_t n = 0;
     n += (size_t)R * (4 * H) * 2 + (size_t)R * H * hw * 2;                  // latent_proj activations
     n += 4u * 1024 * 1024;                                                  // W_eff images of every conv (< 3.2 M floats)
-    n += (size_t)R * 32 * 168 * 168 * 5;                                    // ping-pong activations + conv outputs at the largest resolution
-    n += (size_t)R * 288 * 168 * 168;                                       // im2col of the 32-channel 168x168 convs (the largest)
+    const size_t amax = (size_t)R * (3528 * H > 32u * 168 * 168 ? 3528 * H : 32u * 168 * 168);   // largest stage: (H/8) x 168^2 = 8H x 21^2 per image
+    n += amax * 5;                                                          // ping-pong activations + conv outputs
+    n += (size_t)R * 168 * 168 * (9 * H / 8 > 288 ? 9 * H / 8 + 32 : 288 + 32);   // im2col of the widest 168x168 conv
     return sizeof(float) * n + (1 << 20);
 }
 
 int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, float* out, void* wsp, size_t ws_bytes, void* stream) {
     AID_REQUIRE(dec && z && out, AID_E_NULL, "aid_conv_decoder_forward: null argument");
-    AID_REQUIRE(R > 0 && R <= 64 && dec->hidden == 256 && dec->L > 0, AID_E_SHAPE, "aid_conv_decoder_forward: R=%d (chunk rows to <= 64), hidden=%d", R, dec->hidden);
-    hipStream_t s = (hipStream_t)stream;
-    const AidConvDecoder& d = *dec;
+    AID_REQUIRE(R > 0 && R <= 64 && dec->hidden >= 64 && dec->hidden % 32 == 0 && dec->L > 0, AID_E_SHAPE,
+                "aid_conv_decoder_forward: R=%d (chunk rows to <= 64), hidden=%d", R, dec->hidden);
     Workspace ws(wsp, ws_bytes);
+    return conv_decoder_fwd(*dec, R, z, out, ws, (hipStream_t)stream);
+}
+}  // extern "C"
+
+namespace aid {
+int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s) {
+    const size_t mark0 = ws.mark();
     const int H = d.hidden, L = d.L, HW0 = 441;
     // ---- conv weights (eval-mode spectral norm: W / (u . W v))
     ConvW m0[4], m1[4], rs[4], o0, o3, o6;
@@ -816,9 +824,9 @@ int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, f
     AID_TRY(prep_weight(t0, H / 8, 32, 3, ws, o0, s)); AID_TRY(prep_weight(t3, 32, 32, 3, ws, o3, s)); AID_TRY(prep_weight(t6, 32, 3, 3, ws, o6, s));
     // ---- latent_proj: Linear, LN, Mish, (Dropout: eval), Linear, LN over 112 896, Mish -> CNHW [256][R][21x21]
     float* a0 = ws.f32((size_t)R * 4 * H); float* a1 = ws.f32((size_t)R * 4 * H); float* big = ws.f32((size_t)R * H * HW0);
-    const size_t amax = (size_t)R * 32 * 168 * 168;
+    const size_t amax = (size_t)R * ((size_t)3528 * H > 32u * 168 * 168 ? (size_t)3528 * H : 32u * 168 * 168);
     float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
-    float* col = ws.f32((size_t)R * 288 * 168 * 168);
+    float* col = ws.f32((size_t)R * 168 * 168 * (9 * H / 8 > 288 ? 9 * H / 8 + 32 : 288 + 32));
     AID_WS_OK(ws);
     AID_TRY(linear_fwd(z, L, d.l0.w, d.l0.b, a0, 4 * H, R, 4 * H, L, ACT_NONE, s));
     AID_TRY(ln_act(a0, 4 * H, d.ln1.g, d.ln1.b, ACT_MISH, nullptr, a1, 4 * H, nullptr, R, 4 * H, s));
@@ -854,6 +862,187 @@ int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, f
     hipLaunchKernelGGL(instnorm_kernel, dim3(32 * R), dim3(256), 0, s, cv, d.out3_b, (const float*)nullptr, x, 32, R, hsz, hsz, 0, ACT_MISH);
     AID_TRY(conv3_fwd(o6, x, R, hsz, col, cv, s));
     L1D(sigmoid_nchw_kernel, (size_t)3 * R * hsz * hsz, s, cv, d.out6_b, out, 3, R, hsz * hsz);
+    ws.release(mark0);
     return AID_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Pixel branch of the epistemic estimator, feature side (active_inference.py:865-883,940-993; utils/util.py:7-75):
+// (decoder(z + delta) - decoder(z)) / eps  ->  three 5x5 stride-2 convs + ReLU  ->  SpatialAttentionAggregator  ->  jin [R, 4*256]
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ void perturb_rows_kernel(const float* __restrict__ z, const float* __restrict__ d, const float* __restrict__ scale, float* __restrict__ zp, int R, int L) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    float n2 = 0.f;
+    for (int l = 0; l < L; ++l) { const float v = d[(size_t)r * L + l]; n2 += v * v; }
+    const float inv = scale[0] / fmaxf(sqrtf(n2), 1e-12f);
+    for (int l = 0; l < L; ++l) zp[(size_t)r * L + l] = z[(size_t)r * L + l] + d[(size_t)r * L + l] * inv;
+}
+// diff[c][r][p] = (fp[r][c][p] - fz[r][c][p]) / eps        (NCHW images -> CNHW difference)
+__global__ void fd_to_cnhw_kernel(const float* __restrict__ fp, const float* __restrict__ fz, const float* __restrict__ eps, float* __restrict__ out, int C, int R, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * R * HW) return;
+    const int p = i % HW, r = (i / HW) % R, c = i / ((size_t)HW * R);
+    const size_t src = ((size_t)r * C + c) * HW + p;
+    out[i] = (fp[src] - fz[src]) / eps[0];
+}
+// im2col for 5x5, stride 2, pad 2; x CNHW [Cin][R][Hi][Hi]; col [Kp][R*Ho*Ho], k = ci*25 + kh*5 + kw
+__global__ void im2col5s2_kernel(const float* __restrict__ x, float* __restrict__ col, int Cin, int R, int Hi, int Ho, int K, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t N = (size_t)R * Ho * Ho;
+    const int k = i / N; const size_t n = i % N;
+    float v = 0.f;
+    if (k < K) {
+        const int ci = k / 25, kh = (k % 25) / 5, kw = k % 5;
+        const int wo = n % Ho, ho = (n / Ho) % Ho, r = n / ((size_t)Ho * Ho);
+        const int hi = 2 * ho + kh - 2, wi = 2 * wo + kw - 2;
+        if (hi >= 0 && hi < Hi && wi >= 0 && wi < Hi) v = x[(((size_t)ci * R + r) * Hi + hi) * Hi + wi];
+    }
+    col[i] = v;
+}
+// x[c][n] = act(x[c][n] + bias[c])
+__global__ void bias_rows_act_kernel(float* __restrict__ x, const float* __restrict__ bias, int C, size_t N, int act) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * N) return;
+    x[i] = act_apply(x[i] + bias[i / N], act);
+}
+// tokens: x[c][r][t] += pos[t][c]
+__global__ void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos, int C, int R, int T) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * R * T) return;
+    const int t = i % T, c = i / ((size_t)T * R);
+    x[i] += pos[(size_t)t * C + c];
+}
+// nn.MultiheadAttention with 16 query tokens over T key tokens, one workgroup per (row r, head h), head dim 16:
+// kv CNHW-like [2*C][R][T] (K rows 0..C-1, V rows C..2C-1, biases already added); q [16][C] (shared by every row, bias added);
+// mask [R*heads][16][T] scaled keep mask or NULL; out [R][16][C]
+__global__ void __launch_bounds__(256) agg_attention_kernel(const float* __restrict__ kv, const float* __restrict__ q, const float* __restrict__ mask,
+                                                             float* __restrict__ out, int C, int R, int T, int heads) {
+    extern __shared__ float sm[];
+    constexpr int NQ = 16, HD = 16;
+    float* sc = sm;                       // [NQ][T]
+    float* qs = sm + (size_t)NQ * T;      // [NQ][HD]
+    float* red = qs + NQ * HD;            // [NQ][2]
+    const int r = blockIdx.x / heads, h = blockIdx.x % heads, tid = threadIdx.x;
+    for (int i = tid; i < NQ * HD; i += blockDim.x) qs[i] = q[(size_t)(i / HD) * C + h * HD + i % HD] * 0.25f;     // 1/sqrt(head_dim), applied to q like torch
+    __syncthreads();
+    const float* Kh = kv + ((size_t)(h * HD) * R + r) * T;           // row d at + d * R * T
+    const float* Vh = kv + ((size_t)(C + h * HD) * R + r) * T;
+    for (int i = tid; i < NQ * T; i += blockDim.x) {
+        const int qi = i / T, t = i % T;
+        float a = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) a = fmaf(qs[qi * HD + d], Kh[(size_t)d * R * T + t], a);
+        sc[i] = a;
+    }
+    __syncthreads();
+    // softmax over T per query: one wave per 4 queries
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int qi = wave; qi < NQ; qi += 4) {
+        float mx = -3.4e38f;
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, sc[qi * T + t]);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        float sum = 0.f;
+        for (int t = lane; t < T; t += 64) { const float e = expf(sc[qi * T + t] - mx); sc[qi * T + t] = e; sum += e; }
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        const float* mk = mask ? mask + ((size_t)(r * heads + h) * NQ + qi) * T : nullptr;
+        for (int t = lane; t < T; t += 64) sc[qi * T + t] = sc[qi * T + t] * inv * (mk ? mk[t] : 1.0f);
+    }
+    __syncthreads();
+    // out[qi][d] = sum_t P[qi][t] V[d][t] : thread (qi, d)
+    {
+        const int qi = tid / HD, d = tid % HD;
+        float a = 0.f;
+        const float* v = Vh + (size_t)d * R * T;
+        for (int t = 0; t < T; ++t) a = fmaf(sc[qi * T + t], v[t], a);
+        out[((size_t)r * NQ + qi) * C + h * HD + d] = a;
+    }
+    (void)red;
+}
+
+struct PlainConv { const float* w_eff; int cin, cout, K, Kp; };
+static int prep_plain(const float* w, int cin, int cout, int k, Workspace& ws, PlainConv& out, hipStream_t s) {
+    const int K = cin * k * k, Kp = (K + 31) / 32 * 32;
+    float* w_eff = ws.f32((size_t)cout * Kp); AID_WS_OK(ws);
+    L1D(pad_weight_kernel, (size_t)cout * Kp, s, w, cout, K, Kp, w_eff);
+    out.w_eff = w_eff; out.cin = cin; out.cout = cout; out.K = K; out.Kp = Kp;
+    return AID_OK;
+}
+
+int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNet& e, int R, const float* z_all, const float* delta,
+                            const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* jin, Workspace& ws, hipStream_t s) {
+    constexpr int RC = 16, C = 128, T = 441, NQ = 16, HEADS = 8;
+    const int L = dec.L;
+    const size_t mark = ws.mark();
+    PlainConv p0, p2, p4;
+    AID_TRY(prep_plain(e.pp0_w, 3, 32, 5, ws, p0, s)); AID_TRY(prep_plain(e.pp2_w, 32, 64, 5, ws, p2, s)); AID_TRY(prep_plain(e.pp4_w, 64, 128, 5, ws, p4, s));
+    // q = queries Wq^T + bq  (identical for every row)
+    float* q = ws.f32((size_t)NQ * C); AID_WS_OK(ws);
+    AID_TRY(linear_fwd(e.queries, C, e.in_proj_w, e.in_proj_b, q, C, NQ, C, C, ACT_NONE, s));
+    float* zp = ws.f32((size_t)RC * L); float* fz = ws.f32((size_t)RC * 3 * 168 * 168); float* fp = ws.f32((size_t)RC * 3 * 168 * 168);
+    float* dimg = ws.f32((size_t)3 * RC * 168 * 168);
+    float* c1 = ws.f32((size_t)32 * RC * 84 * 84); float* c2 = ws.f32((size_t)64 * RC * 42 * 42); float* c3 = ws.f32((size_t)C * RC * T);
+    float* col = ws.f32((size_t)p2.Kp * RC * 42 * 42 > (size_t)p0.Kp * RC * 84 * 84 ? (size_t)p2.Kp * RC * 42 * 42 : (size_t)p0.Kp * RC * 84 * 84);
+    float* kv = ws.f32((size_t)2 * C * RC * T); float* att = ws.f32((size_t)RC * NQ * C); float* ao = ws.f32((size_t)RC * NQ * C);
+    float* a0 = ws.f32((size_t)RC * e.agg0.out); float* a1 = ws.f32((size_t)RC * e.agg0.out);
+    float* mask_buf = (train && !attn_mask) ? ws.f32((size_t)RC * HEADS * NQ * T) : nullptr;
+    AID_WS_OK(ws);
+    uint64_t ctr = offset;
+    for (int r0 = 0; r0 < R; r0 += RC) {
+        const int n = R - r0 < RC ? R - r0 : RC;
+        const float* z = z_all + (size_t)r0 * L;
+        AID_TRY(conv_decoder_fwd(dec, n, z, fz, ws, s));
+        for (int j = 0; j < 4; ++j) {
+            hipLaunchKernelGGL(perturb_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, s, z, delta + ((size_t)j * R + r0) * L, e.perturbation_scale, zp, n, L);
+            AID_LAUNCH_CHECK();
+            AID_TRY(conv_decoder_fwd(dec, n, zp, fp, ws, s));
+            L1D(fd_to_cnhw_kernel, (size_t)3 * n * 168 * 168, s, fp, fz, e.perturbation_scale, dimg, 3, n, 168 * 168);
+            // pixel_processor: 168 -> 84 -> 42 -> 21
+            const PlainConv* pcs[3] = {&p0, &p2, &p4}; const float* bs[3] = {e.pp0_b, e.pp2_b, e.pp4_b};
+            const float* xin = dimg; float* outs[3] = {c1, c2, c3}; int hi = 168;
+            for (int l = 0; l < 3; ++l) {
+                const int ho = hi / 2; const size_t N = (size_t)n * ho * ho;
+                L1D(im2col5s2_kernel, (size_t)pcs[l]->Kp * N, s, xin, col, pcs[l]->cin, n, hi, ho, pcs[l]->K, (size_t)pcs[l]->Kp * N);
+                GemmArgs ga = gemm_args(pcs[l]->w_eff, pcs[l]->Kp, col, (int)N, outs[l], (int)N, pcs[l]->cout, (int)N, pcs[l]->Kp);
+                ga.b_kmajor = 1;
+                AID_TRY(gemm_f32(ga, s));
+                L1D(bias_rows_act_kernel, (size_t)pcs[l]->cout * N, s, outs[l], bs[l], pcs[l]->cout, N, ACT_RELU);
+                xin = outs[l]; hi = ho;
+            }
+            // aggregator: tokens + positional encoding, K/V projections, 16-query attention, out_proj, Linear-LN-GELU-Linear
+            const size_t NT = (size_t)n * T;
+            L1D(add_pos_kernel, (size_t)C * NT, s, c3, e.pos, C, n, T);
+            {
+                GemmArgs ga = gemm_args(e.in_proj_w + (size_t)C * C, C, c3, (int)NT, kv, (int)NT, 2 * C, (int)NT, C);    // rows C..3C of in_proj: Wk, Wv
+                ga.b_kmajor = 1;
+                AID_TRY(gemm_f32(ga, s));
+                L1D(bias_rows_act_kernel, (size_t)2 * C * NT, s, kv, e.in_proj_b + C, 2 * C, NT, ACT_NONE);
+            }
+            const float* mk = nullptr;
+            if (train) {
+                if (attn_mask) mk = attn_mask + ((size_t)j * R + r0) * HEADS * NQ * T;
+                else { AID_TRY(philox_fill(mask_buf, (size_t)n * HEADS * NQ * T, 2, 0.1f, seed, ctr, s)); ctr += ((size_t)n * HEADS * NQ * T + 3) / 4; mk = mask_buf; }
+            }
+            hipLaunchKernelGGL(agg_attention_kernel, dim3(n * HEADS), dim3(256), sizeof(float) * ((size_t)NQ * T + NQ * 16 + 64), s, kv, q, mk, att, C, n, T, HEADS);
+            AID_LAUNCH_CHECK();
+            AID_TRY(linear_fwd(att, C, e.att_out.w, e.att_out.b, ao, C, n * NQ, C, C, ACT_NONE, s));
+            AID_TRY(linear_fwd(ao, NQ * C, e.agg0.w, e.agg0.b, a0, e.agg0.out, n, e.agg0.out, NQ * C, ACT_NONE, s));
+            AID_TRY(ln_act(a0, e.agg0.out, e.agg_ln.g, e.agg_ln.b, ACT_GELU, nullptr, a1, e.agg0.out, nullptr, n, e.agg0.out, s));
+            AID_TRY(linear_fwd(a1, e.agg0.out, e.agg3.w, e.agg3.b, jin + (size_t)r0 * 4 * e.agg3.out + (size_t)j * e.agg3.out, 4 * e.agg3.out, n, e.agg3.out,
+                               e.agg0.out, ACT_NONE, s));
+        }
+    }
+    ws.release(mark);
+    return AID_OK;
+}
+size_t pixel_jacobian_ws_bytes(const AidConvDecoder& dec) {
+    return aid_conv_decoder_workspace(&dec, 16) + sizeof(float) * (size_t)16 * (3 * 168 * 168 * 3 + 32 * 84 * 84 + 64 * 42 * 42 + 128 * 441 * 3 + 96 * 84 * 84 + 800 * 42 * 42
+                                                                               + 16 * 128 * 2 + 8 * 16 * 441 + 4096) + (4u << 20);
+}
+}  // namespace aid
+
+extern "C" {
 }  // extern "C"

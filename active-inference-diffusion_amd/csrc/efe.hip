@@ -174,10 +174,11 @@ __global__ void randperm_blocks_kernel(const float* __restrict__ keys, int32_t* 
     } while (0)
 
 // ---- MINE forward for one horizon step, all K trajectories: fills mine_out [K][4]
+struct PixelBackend { const AidConvDecoder* dec; const AidPixelEpistemicNet* epi; const float* attn_mask; uint64_t seed, offset; };
 static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int K, int S, int B, const float* next_mean,
                         const float* z_eps, const float* delta, const float* proj_mask, const float* mine_mask, const int32_t* perms,
-                        bool train, float* mine_out, Workspace& ws, hipStream_t s) {
-    const int L = e.L, O = e.O;
+                        bool train, float* mine_out, Workspace& ws, hipStream_t s, const PixelBackend* px = nullptr) {
+    const int L = e.L, O = px ? 1 : e.O;
     const size_t R = (size_t)K * S * B;
     const int Rm = (int)R;
     const size_t mark = ws.mark();
@@ -192,8 +193,11 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     const float sd = sqrtf(0.1f);   // exp(0.5 * ln 0.1)  (predict_next_latent :463)
     LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), z_all, K, S, B, L);
     (void)sd;
-    AID_TRY(decoder_fwd(dec, Rm, z_all, L, nullptr, fz, O, ws, s));           // decoder in eval mode (:949)
     const int FE = e.fe4.out, CW = e.jp4.out + e.lp2.out;
+    if (px) {   // pixel branch: ConvDecoder finite differences -> 5x5 convs -> attention aggregator (conv.hip)
+        AID_TRY(pixel_jacobian_features(*px->dec, *px->epi, Rm, z_all, delta, px->attn_mask, train, px->seed, px->offset, jin, ws, s));
+    } else {
+    AID_TRY(decoder_fwd(dec, Rm, z_all, L, nullptr, fz, O, ws, s));           // decoder in eval mode (:949)
     for (int j = 0; j < 4; ++j) {
         LAUNCH1D(perturb_kernel, R, s, z_all, delta + (size_t)j * R * L, e.perturbation_scale, zp, R, L);
         AID_TRY(decoder_fwd(dec, Rm, zp, L, nullptr, fp, O, ws, s));
@@ -201,6 +205,7 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
         AID_TRY(linear_fwd(fp, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, Rm, e.fe0.out, O, ACT_RELU, s));
         AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, Rm, e.fe2.out, e.fe0.out, ACT_RELU, s));
         AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin + (size_t)j * FE, 4 * FE, Rm, FE, e.fe2.out, ACT_NONE, s));
+    }
     }
     AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s));
     AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, comb, CW, Rm, e.jp4.out, e.jp0.out, ACT_NONE, s));
@@ -285,6 +290,13 @@ int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidD
                  const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
                  const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, void* wsp,
                  size_t ws_bytes, void* stream) {
+    return aid_efe_step_ex(pol, pgrads, dyn, rew, val, dec, epi, B, latents, noise, cfg, running_mean, efe_out, info, nullptr, wsp, ws_bytes, stream);
+}
+
+int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
+                    const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
+                    const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, float* next_means_out,
+                    void* wsp, size_t ws_bytes, void* stream) {
     AID_REQUIRE(pol && dyn && rew && val && latents && noise && cfg && running_mean && efe_out && info, AID_E_NULL,
                 "aid_efe_step: null argument");
     AID_REQUIRE(cfg->skip_epistemic || (dec && epi), AID_E_NULL, "aid_efe_step: decoder / estimator tables are required unless skip_epistemic");
@@ -336,6 +348,7 @@ int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidD
         AID_WS_OK(ws);
         AID_TRY(policy_fwd(*pol, M, cur, L, pol_eps + (size_t)t * M * A, q.ps, ws, s));
         AID_TRY(dynamics_fwd(*dyn, M, cur, L, q.ps.action, A, q.next_mean, q.ds, ws, s));
+        if (next_means_out) AID_TRY(copy_f32(q.next_mean, next_means_out + (size_t)t * M * L, (size_t)M * L, s));
         LAUNCH1D(reparam_kernel, (size_t)M * L, s, q.next_mean, rep_eps + (size_t)t * M * L, sd, q.nxt, (size_t)M * L);
         AID_TRY(reward_fwd(*rew, M, q.nxt, L, q.rs, ws, s));
         AID_TRY(fill_const(q.tvec, (float)t, M, s));
@@ -518,6 +531,80 @@ int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, con
         hipLaunchKernelGGL(scale_out_kernel, dim3(1), dim3(64), 0, s, ge.perturbation_scale, acc, e.perturbation_scale);
         AID_LAUNCH_CHECK();
     }
+    return AID_OK;
+}
+
+size_t aid_pixel_epistemic_workspace(const AidConvDecoder* dec, int K, int S, int B) {
+    if (!dec || K <= 0 || S <= 0 || B <= 0) return 0;
+    const size_t R = (size_t)K * S * B;
+    return pixel_jacobian_ws_bytes(*dec) + sizeof(float) * R * (size_t)(2 * dec->L + 4 * 256 + 2 * 384 + 128 + 3 * 512 + 8) + (4u << 20);
+}
+
+int aid_pixel_epistemic_value(const AidConvDecoder* dec, const AidPixelEpistemicNet* pe, int K, int S, int B, const float* next_mean,
+                              const AidEfeNoise* noise, const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* mine_out,
+                              void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dec && pe && next_mean && noise && mine_out, AID_E_NULL, "aid_pixel_epistemic_value: null argument");
+    AID_REQUIRE(K > 0 && S > 0 && B > 0 && B <= 2048, AID_E_SHAPE, "aid_pixel_epistemic_value: K=%d S=%d B=%d", K, S, B);
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const size_t R = (size_t)K * S * B; const int L = pe->L;
+    // the tail (projector, latent processor, MINE statistics) is the state branch's: view the pixel table through its struct
+    AidEpistemicNet e = {};
+    e.L = L; e.O = 1; e.perturbation_scale = pe->perturbation_scale;
+    e.fe0.out = 1; e.fe2.out = 1; e.fe4.out = pe->agg3.out;
+    e.jp0 = pe->jp0; e.jp_ln = pe->jp_ln; e.jp4 = pe->jp4; e.lp0 = pe->lp0; e.lp2 = pe->lp2; e.mn0 = pe->mn0; e.mn3 = pe->mn3; e.mn6 = pe->mn6;
+    uint64_t ctr = offset;
+    auto draw = [&](const float* given, size_t cnt, int kind, float p, const float** out) -> int {
+        if (given) { *out = given; return AID_OK; }
+        float* buf = ws.f32(cnt); AID_WS_OK(ws);
+        AID_TRY(philox_fill(buf, cnt, kind, p, seed, ctr, s)); ctr += (cnt + 3) / 4; *out = buf; return AID_OK;
+    };
+    const float *z_eps, *delta, *pmask = nullptr, *mmask = nullptr;
+    AID_TRY(draw(noise->mine_z_eps, R * L, 0, 0.f, &z_eps));
+    AID_TRY(draw(noise->mine_delta, 4 * R * L, 0, 0.f, &delta));
+    if (train) {
+        AID_TRY(draw(noise->proj_mask, R * e.jp0.out, 2, 0.1f, &pmask));
+        AID_TRY(draw(noise->mine_mask, 4 * R * e.mn0.out, 2, 0.1f, &mmask));
+    }
+    const int32_t* perms = noise->perms;
+    if (!perms) {
+        const float* keys; AID_TRY(draw(nullptr, R, 1, 0.f, &keys));
+        int32_t* pb = (int32_t*)ws.raw(sizeof(int32_t) * R); AID_WS_OK(ws);
+        int P2 = 1; while (P2 < B) P2 <<= 1;
+        hipLaunchKernelGGL(randperm_blocks_kernel, dim3((unsigned)(K * S)), dim3(256), (size_t)P2 * 8, s, keys, pb, B, P2);
+        AID_LAUNCH_CHECK(); perms = pb;
+    }
+    PixelBackend px = {dec, pe, attn_mask, seed, ctr + (1ull << 36)};
+    AidDecoderNet none = {};
+    return mine_forward(none, e, K, S, B, next_mean, z_eps, delta, pmask, mmask, perms, train != 0, mine_out, ws, s, &px);
+}
+
+__global__ void efe_add_epistemic_kernel(const float* __restrict__ mine_all, int H, int K, int B, float ew, float disc, float* __restrict__ efe,
+                                         float* __restrict__ info) {
+    float add = 0.f, g = 1.f;
+    for (int t = 0; t < H; ++t) {
+        float e = 0.f;
+        for (int k = 0; k < K; ++k) e += fmaxf(mine_all[((size_t)t * K + k) * 4 + 3], 0.f);
+        add += g * ew * e / (float)K; g *= disc;
+    }
+    for (int b = threadIdx.x; b < B; b += blockDim.x) efe[b] += add;
+    if (threadIdx.x == 0) {
+        info[0] += add;                                       // policy_loss = mean_b efe_b
+        float e = 0.f;                                        // epistemic_mean: mean over trajectories of the LAST horizon step's value (:381-389)
+        for (int k = 0; k < K; ++k) e += fmaxf(mine_all[((size_t)(H - 1) * K + k) * 4 + 3], 0.f);
+        info[1] = e / (float)K;
+        const float* last = mine_all + ((size_t)(H - 1) * K + (K - 1)) * 4;
+        info[4] = last[3]; info[5] = last[0]; info[6] = last[1];
+    }
+}
+
+int aid_efe_add_epistemic(const float* mine_all, int H, int K, int B, float epistemic_weight, float discount, float alpha, float* running_mean,
+                          float* efe, float* info, void* stream) {
+    AID_REQUIRE(mine_all && running_mean && efe && info && H > 0 && K > 0 && B > 0, AID_E_NULL, "aid_efe_add_epistemic: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(efe_add_epistemic_kernel, dim3(1), dim3(256), 0, s, mine_all, H, K, B, epistemic_weight, discount, efe, info);
+    hipLaunchKernelGGL(running_mean_kernel, dim3(1), dim3(64), 0, s, mine_all, H, K, alpha, running_mean);
+    AID_LAUNCH_CHECK();
     return AID_OK;
 }
 }  // extern "C"

@@ -62,4 +62,10 @@ int policy_fwd(const AidPolicyNet& p, int M, const float* z, int ldz, const floa
 int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
                const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s);
 
+// ---- ConvDecoder + pixel estimator feature side (conv.hip)
+int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s);
+int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNet& e, int R, const float* z_all, const float* delta,
+                            const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* jin, Workspace& ws, hipStream_t s);
+size_t pixel_jacobian_ws_bytes(const AidConvDecoder& dec);
+
 }  // namespace aid

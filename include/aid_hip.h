@@ -167,6 +167,31 @@ typedef struct AidEpistemicNet {
 } AidEpistemicNet;
 typedef struct AidDiffusionParams { float *prior_mean, *prior_log_std, *log_snr_min, *log_snr_max; } AidDiffusionParams;
 
+/* ---- ConvDecoder (pixel-mode observation decoder), forward / eval mode -------------------------------------------------------
+ * active_inference_diffusion/encoder/visual_encoders.py:228-459.  Spectral-normed convs carry weight_orig + u + v (legacy layout);
+ * plain convs have u = v = NULL. */
+typedef struct AidSNConv { const float *w, *u, *v, *bias; } AidSNConv;
+typedef struct AidDecoderBlock { AidSNConv main0, main1, res; } AidDecoderBlock;     /* res.w == NULL: identity residual */
+typedef struct AidConvDecoder {
+    int32_t L, hidden;
+    AidLinear l0; AidLN ln1; AidLinear l4; AidLN ln5;                    /* latent_proj.{0,1,4,5} */
+    AidDecoderBlock blk[4];
+    const float *out0_w, *out0_b, *out3_w, *out3_b, *out6_w, *out6_b;    /* output_proj.{0,3,6} */
+} AidConvDecoder;
+/* Pixel branch of FunctionSpaceEpistemicEstimator (active_inference.py:865-925; utils/util.py:7-75), minus its alias of the decoder. */
+typedef struct AidPixelEpistemicNet {
+    int32_t L, _pad;
+    float* perturbation_scale;
+    const float *pp0_w, *pp0_b, *pp2_w, *pp2_b, *pp4_w, *pp4_b;          /* pixel_processor.{0,2,4}: 5x5 stride-2 convs */
+    const float *pos, *queries, *in_proj_w, *in_proj_b;                  /* spatial_aggregator: pos_encoding [441,128], epistemic_queries [16,128], MHA in_proj */
+    AidLinear att_out, agg0; AidLN agg_ln; AidLinear agg3;               /* attention.out_proj, output_proj.{0,1,3} */
+    AidLinear jp0; AidLN jp_ln; AidLinear jp4;                           /* jacobian_projector.{0,1,4} (in = 4 * 256) */
+    AidLinear lp0, lp2, mn0, mn3, mn6;                                   /* latent_processor, mine_network */
+} AidPixelEpistemicNet;
+/* z [R, L] -> out [R, 3, 168, 168] (NCHW, in [0,1]); R <= 64 per call (callers chunk larger batches). */
+size_t aid_conv_decoder_workspace(const AidConvDecoder* dec, int R);
+int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* decode_observation, state branch (active_inference.py:237-242).  masks: 3 scaled keep masks
  * [B,2D],[B,2D],[B,D] (Dropout 0.2) or NULL pointers for eval mode. */
 size_t aid_decode_workspace(const AidDecoderNet* dec, int B);
@@ -250,6 +275,23 @@ size_t aid_mine_train_workspace(const AidDecoderNet* dec, const AidDynamicsNet* 
 int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, const AidEpistemicNet* epi, const AidEpistemicNet* grads, int B, int S,
                         const float* latents, const float* actions, const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset,
                         float alpha, float* running_mean, float* out4, void* ws, size_t ws_bytes, void* stream);
+/* Same as aid_efe_step with one more output: next_means_out [H][K*B][L] (or NULL), the dynamics means the estimator samples around. */
+int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
+                    const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
+                    const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, float* next_means_out,
+                    void* ws, size_t ws_bytes, void* stream);
+/* Pixel-mode epistemic value for ONE horizon step of all K trajectories (gradient-free, active_inference.py:398-418 + the pixel estimator):
+ * next_mean [K*B, L]; noise: mine_z_eps [K*S*B, L], mine_delta [4, K*S*B, L], proj_mask [K*S*B, 512], mine_mask [4, K*S*B, 512], perms [K*S, B];
+ * attn_mask [4][K*S*B*8][16][441] scaled keep masks of the aggregator's attention dropout (NULL members => device Philox).
+ * mine_out [K][4] = {joint, marginal term, t_exp, mi} per trajectory.  ~40 GFLOP per sample row: callers keep K*S*B small. */
+size_t aid_pixel_epistemic_workspace(const AidConvDecoder* dec, int K, int S, int B);
+int aid_pixel_epistemic_value(const AidConvDecoder* dec, const AidPixelEpistemicNet* epi, int K, int S, int B, const float* next_mean,
+                              const AidEfeNoise* noise, const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* mine_out,
+                              void* ws, size_t ws_bytes, void* stream);
+/* Adds the epistemic term to an EFE computed with skip_epistemic: efe[b] += sum_t discount^t * w * mean_k max(mi[t][k], 0); info[1,4,5,6]
+ * (epistemic_mean and the last (k,t)'s mi / joint / marginal) and the running-mean EMA replayed in the reference's (k outer, t inner) order. */
+int aid_efe_add_epistemic(const float* mine_all /*[H][K][4]*/, int H, int K, int B, float epistemic_weight, float discount, float alpha,
+                          float* running_mean, float* efe, float* info, void* stream);
 size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg);
 int aid_efe_step(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
                  const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
@@ -325,20 +367,6 @@ int aid_reward_normalize(const float* rewards, int B, double* state, float* out,
 int aid_reward_normalize_global(const float* stats_src, int n_stats, const float* rewards, int B, double* state, float* out,
                                 void* stream);
 
-/* ---- ConvDecoder (pixel-mode observation decoder), forward / eval mode -------------------------------------------------------
- * active_inference_diffusion/encoder/visual_encoders.py:228-459.  Spectral-normed convs carry weight_orig + u + v (legacy layout);
- * plain convs have u = v = NULL. */
-typedef struct AidSNConv { const float *w, *u, *v, *bias; } AidSNConv;
-typedef struct AidDecoderBlock { AidSNConv main0, main1, res; } AidDecoderBlock;     /* res.w == NULL: identity residual */
-typedef struct AidConvDecoder {
-    int32_t L, hidden;
-    AidLinear l0; AidLN ln1; AidLinear l4; AidLN ln5;                    /* latent_proj.{0,1,4,5} */
-    AidDecoderBlock blk[4];
-    const float *out0_w, *out0_b, *out3_w, *out3_b, *out6_w, *out6_b;    /* output_proj.{0,3,6} */
-} AidConvDecoder;
-/* z [R, L] -> out [R, 3, 168, 168] (NCHW, in [0,1]); R <= 64 per call (callers chunk larger batches). */
-size_t aid_conv_decoder_workspace(const AidConvDecoder* dec, int R);
-int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, float* out, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- A13: DrQ-v2 pixel encoder (aid/encoder/visual_encoders.py:13-225) + RandomShiftAugmentation (:471-492) ----------
  * 4 x {conv3x3 (no bias, legacy spectral norm; stride 2,1,1,1; in_ch->32->64->128->256) -> GroupNorm -> Mish -> Dropout2d}

@@ -566,7 +566,7 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
                          train: bool = True, epistemic_weight: float = 0.1,
                          pragmatic_weight: float = 1.0, consistency_weight: float = 0.1,
                          discount: float = 0.99, temperature: float = 1.0, skip_epistemic: bool = False,
-                         burn_pixel_epistemic: bool = False):
+                         burn_pixel_epistemic: bool = False, pixel_epistemic: bool = False):
     """Returns (total_efe[B], info, new_running_mean).  Draw order per (k,t): rsample eps [B,A],
     reparam randn[B,L], then epistemic_value's draws.  skip_epistemic: the (no_grad) epistemic term is 0 and draws
     nothing - the pixel path of this repo, whose ConvDecoder estimator is not built."""
@@ -586,14 +586,17 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
             prag = pragmatic_weight * (r_mean / temperature)
             prag = prag + value_forward(p, nxt, torch.full((B,), float(t))).squeeze(-1)
             cons = -ent
-            if skip_epistemic:
+            if pixel_epistemic:      # the reference's pixel-mode estimator (ConvDecoder based), gradient-free
+                epi, mi, joint, tlog, running_mean = pixel_epistemic_value(p, nm.detach(), nlv, running_mean, noise, num_ambiguity_samples, train)
+                epi = epi.expand(B)
+            elif skip_epistemic:
                 epi, mi, joint, tlog = torch.zeros(()), 0.0, 0.0, 0.0
                 if burn_pixel_epistemic:   # consume exactly what the reference's pixel estimator draws here (stream alignment only)
                     burn_pixel_epistemic_draws(noise, B, nm.shape[1], num_ambiguity_samples, train)
             else:
                 epi, mi, joint, tlog, running_mean = epistemic_value(
                     p, nm.detach(), nlv, running_mean, noise, num_ambiguity_samples, train)
-            epi = epi.expand(B)
+            epi = epi.expand(B) if epi.dim() == 0 else epi
             step = epistemic_weight * epi + pragmatic_weight * prag + consistency_weight * cons
             traj = traj + (discount ** t) * step
             cur = nxt
@@ -958,7 +961,7 @@ class OraclePixelState(OracleAgentState):
 
 def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, horizon: int = 5, lr: float = 5e-5, clip: float = 0.5,
                      num_trajectories: int = 10, contrastive_weight: float = 0.5, pad: int = 4, train: bool = True, return_grads: bool = False,
-                     burn_epistemic_samples: int = 0):
+                     burn_epistemic_samples: int = 0, pixel_epistemic_samples: int = 0):
     """One DiffusionPixelAgent.train_step, with the epistemic term skipped (see expected_free_energy).  Draw order: [shift h, w;
     Dropout2d masks x2; Dropout mask] for obs, the same for next_obs; belief draws (+1 feature-decoder mask) for each; ELBO
     draws (feature-decoder mask first); per (k,t) policy eps and reparam eps."""
@@ -996,12 +999,16 @@ def pixel_train_step(st: OraclePixelState, batch: Dict[str, np.ndarray], noise, 
     metrics = {k: float(v) for k, v in info.items()}
     metrics["contrastive_loss"] = float(contrastive)
     grads_out = {"score": dict(live)}
-    efe, einfo, _ = expected_free_energy(p, latents, noise, 0.0, horizon, num_trajectories, max(burn_epistemic_samples, 1), train,
-                                         skip_epistemic=True, burn_pixel_epistemic=burn_epistemic_samples > 0)
+    if pixel_epistemic_samples > 0:   # needs the ConvDecoder under "epistemic_estimator.decoder." and the pixel estimator's own nets in p
+        efe, einfo, st.running_mean = expected_free_energy(p, latents, noise, st.running_mean, horizon, num_trajectories, pixel_epistemic_samples, train,
+                                                           pixel_epistemic=True)
+    else:
+        efe, einfo, _ = expected_free_energy(p, latents, noise, 0.0, horizon, num_trajectories, max(burn_epistemic_samples, 1), train,
+                                             skip_epistemic=True, burn_pixel_epistemic=burn_epistemic_samples > 0)
     ploss = efe.mean()
     grads_out["policy"], _ = _opt_step(st, "policy", ploss, lr, 1e-5, clip)
     metrics["policy_loss"] = float(ploss)
-    metrics.update({k: float(v) for k, v in einfo.items() if not k.startswith("epistemic/")})
+    metrics.update({k: float(v) for k, v in einfo.items() if pixel_epistemic_samples > 0 or not k.startswith("epistemic/")})
     values = value_forward(p, latents, torch.zeros(B)).squeeze(-1)
     with torch.no_grad():
         nv = value_forward(p, next_latents, torch.ones(B)).squeeze(-1)
@@ -1058,3 +1065,61 @@ def conv_decoder_forward(p: Params, z: Tensor, pre: str = "observation_decoder."
     h = F.mish(F.instance_norm(F.conv2d(h, p[o + "0.weight"], p[o + "0.bias"], padding=1), eps=1e-5))
     h = F.mish(F.instance_norm(F.conv2d(h, p[o + "3.weight"], p[o + "3.bias"], padding=1), eps=1e-5))
     return torch.sigmoid(F.conv2d(h, p[o + "6.weight"], p[o + "6.bias"], padding=1))
+
+
+# ---------------------------------------------------------------------------------------------
+# (f)-1  pixel branch of FunctionSpaceEpistemicEstimator      active_inference.py:865-883,940-1063 ; util.py:7-75
+# ---------------------------------------------------------------------------------------------
+def spatial_attention_aggregator(p: Params, pre: str, x: Tensor, noise, train: bool, heads: int = 8) -> Tensor:
+    """SpatialAttentionAggregator.forward: 16 learnable query tokens attend over the H*W feature tokens (+ positional encoding) with
+    nn.MultiheadAttention (dropout 0.1 on the attention weights, drawn as one mask [R*heads, 16, H*W]); then Linear, LN, GELU, Linear."""
+    R, C, H, W = x.shape
+    tok = x.view(R, C, H * W).permute(0, 2, 1) + p[pre + "pos_encoding"][:, :H * W, :]
+    q_in = p[pre + "epistemic_queries"].expand(R, -1, -1)
+    wq, wk, wv = p[pre + "attention.in_proj_weight"].chunk(3)
+    bq, bk, bv = p[pre + "attention.in_proj_bias"].chunk(3)
+    hd = C // heads
+    q = (q_in @ wq.t() + bq).view(R, -1, heads, hd).transpose(1, 2)            # [R, heads, 16, hd]
+    k = (tok @ wk.t() + bk).view(R, -1, heads, hd).transpose(1, 2)             # [R, heads, HW, hd]
+    v = (tok @ wv.t() + bv).view(R, -1, heads, hd).transpose(1, 2)
+    att = torch.softmax((q * (1.0 / math.sqrt(hd))) @ k.transpose(-1, -2), dim=-1)
+    if train:
+        att = att * _t(noise.dropout_mask((R * heads, att.shape[2], H * W), 0.1)).view(R, heads, att.shape[2], H * W)
+    o = (att @ v).transpose(1, 2).reshape(R, -1, C)
+    o = _lin(p, pre + "attention.out_proj", o).reshape(R, -1)
+    return _lin(p, pre + "output_proj.3", F.gelu(_ln(p, pre + "output_proj.1", _lin(p, pre + "output_proj.0", o))))
+
+
+def pixel_epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_mean: float, noise, num_samples: int = 10,
+                          train: bool = True, ntk_samples: int = 4, alpha: float = 0.01):
+    """FunctionSpaceEpistemicEstimator.forward in pixel mode under no_grad: ConvDecoder (eval) finite differences -> pixel_processor
+    (three 5x5 stride-2 convs + ReLU) -> SpatialAttentionAggregator -> the same projector / latent processor / MINE statistics as the
+    state branch.  Draw order = burn_pixel_epistemic_draws.  -> (clamped MI, mi, joint, marginal term, new running_mean)"""
+    with torch.no_grad():
+        B = next_mean.shape[0]
+        z_all = torch.cat([next_mean + _t(noise.randn(*next_mean.shape)) * torch.exp(0.5 * next_logvar) for _ in range(num_samples)], dim=0)
+        eps_scale = p[EPI + "perturbation_scale"]
+        f_z = conv_decoder_forward(p, z_all, EPI + "decoder.")
+        feats = []
+        for _ in range(ntk_samples):
+            delta = F.normalize(_t(noise.randn(*z_all.shape)), dim=-1) * eps_scale
+            h = (conv_decoder_forward(p, z_all + delta, EPI + "decoder.") - f_z) / eps_scale
+            for i in (0, 2, 4):
+                h = F.relu(F.conv2d(h, p[EPI + f"pixel_processor.{i}.weight"], p[EPI + f"pixel_processor.{i}.bias"], stride=2, padding=2))
+            feats.append(spatial_attention_aggregator(p, EPI + "spatial_aggregator.", h, noise, train))
+        jf = torch.cat(feats, dim=1)
+        jf = F.relu(_ln(p, EPI + "jacobian_projector.1", _lin(p, EPI + "jacobian_projector.0", jf)))
+        jf = _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+        lf = _lin(p, EPI + "latent_processor.2", F.relu(_lin(p, EPI + "latent_processor.0", z_all)))
+        t_joint = _mine_net(p, torch.cat([jf, lf], dim=1), noise, train)
+        marg = []
+        for i in range(num_samples):
+            perm = _t(noise.randperm(B), torch.int64)
+            marg.append(jf[i * B:(i + 1) * B][perm])
+        t_marg = _mine_net(p, torch.cat([torch.cat(marg, dim=0), lf], dim=1), noise, train)
+        t_exp = torch.exp(torch.logsumexp(t_marg, 0) - math.log(t_marg.shape[0])).item()
+        new_rm = t_exp if running_mean == 0 else alpha * t_exp + (1.0 - alpha) * running_mean
+        t_log = t_marg.exp().mean().log()
+        joint = t_joint.mean()
+        mi = joint - t_log
+        return torch.clamp(mi, min=0.0), mi, joint, t_log, float(np.float32(new_rm))

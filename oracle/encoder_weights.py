@@ -75,3 +75,47 @@ def draw_conv_decoder_params(specs, key: int):
             p[name] = (p[name] - 1.0) / 0.1 / float(np.sqrt(np.prod(shape[1:])))
     p["output_proj.6.weight"] = p["output_proj.6.weight"] * 0.5
     return p
+
+
+def pixel_estimator_specs(latent_dim: int, img_channels: int = 3):
+    """Pixel-branch FunctionSpaceEpistemicEstimator.state_dict() minus its `decoder.*` alias (active_inference.py:865-925)."""
+    e = []
+    e += [("perturbation_scale", ()), ("running_mean", ())]
+    for i, (cin, cout) in zip((0, 2, 4), ((img_channels, 32), (32, 64), (64, 128))):
+        e += [(f"pixel_processor.{i}.weight", (cout, cin, 5, 5)), (f"pixel_processor.{i}.bias", (cout,))]
+    a = "spatial_aggregator."
+    e += [(a + "pos_encoding", (1, 441, 128)), (a + "epistemic_queries", (1, 16, 128)), (a + "attention.in_proj_weight", (384, 128)),
+          (a + "attention.in_proj_bias", (384,)), (a + "attention.out_proj.weight", (128, 128)), (a + "attention.out_proj.bias", (128,)),
+          (a + "output_proj.0.weight", (512, 2048)), (a + "output_proj.0.bias", (512,)), (a + "output_proj.1.weight", (512,)), (a + "output_proj.1.bias", (512,)),
+          (a + "output_proj.3.weight", (256, 512)), (a + "output_proj.3.bias", (256,))]
+    e += [("jacobian_projector.0.weight", (512, 1024)), ("jacobian_projector.0.bias", (512,)), ("jacobian_projector.1.weight", (512,)),
+          ("jacobian_projector.1.bias", (512,)), ("jacobian_projector.4.weight", (256, 512)), ("jacobian_projector.4.bias", (256,)),
+          ("latent_processor.0.weight", (128, latent_dim)), ("latent_processor.0.bias", (128,)), ("latent_processor.2.weight", (128, 128)),
+          ("latent_processor.2.bias", (128,)), ("mine_network.0.weight", (512, 384)), ("mine_network.0.bias", (512,)),
+          ("mine_network.3.weight", (512, 512)), ("mine_network.3.bias", (512,)), ("mine_network.6.weight", (1, 512)), ("mine_network.6.bias", (1,))]
+    return e
+
+
+def draw_pixel_estimator_params(specs, key: int):
+    ns = NoiseStream(key)
+    out = {}
+    for name, shape in specs:
+        if name == "perturbation_scale":
+            v = np.float32(0.1)
+        elif name == "running_mean":
+            v = np.float32(0.0)
+        else:
+            x = ns.randn(*shape)
+            leaf = name.split(".")[-1]
+            if len(shape) == 4:
+                v = x / np.sqrt(np.prod(shape[1:]))
+            elif name.endswith(("pos_encoding", "epistemic_queries")):
+                v = 0.5 * x
+            elif len(shape) == 2 or leaf == "in_proj_weight":
+                v = x / np.sqrt(shape[-1])
+            elif leaf in ("bias", "in_proj_bias"):
+                v = 0.05 * x
+            else:
+                v = 1.0 + 0.1 * x
+        out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).reshape(shape)
+    return out

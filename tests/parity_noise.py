@@ -17,6 +17,7 @@ class ParityNoise(NoiseSource):
         super().__init__(seed=0)
         self.ns = NoiseStream(key)
         self.burn_epistemic_samples = burn_epistemic_samples   # >0: consume the reference's pixel-estimator draws (alignment with reference goldens)
+        self.live_epistemic_samples = 0                        # >0: keep them (the pixel estimator is evaluated: ai.pixel_epistemic = True)
         self.pixel = pixel        # pixel mode: feature-decoder mask instead of the 3 decoder masks, no estimator draws in the EFE
 
     def encoder(self, B, L, pad):
@@ -62,6 +63,26 @@ class ParityNoise(NoiseSource):
         n["prior_eps"] = ns.randn(B, L)
         return {k: dev(v) for k, v in n.items()}
 
+    def pixel_estimator(self, B, L, S, train=True):
+        """One pixel-mode estimator forward (K = 1): the draws of burn_pixel_epistemic_draws, kept."""
+        ns = self.ns
+        R = S * B
+        n = {"mine_z_eps": np.concatenate([ns.randn(B, L) for _ in range(S)]), "mine_delta": np.zeros((4, R, L), np.float32)}
+        am = np.ones((4, R * 8, 16, 441), np.float32)
+        for j in range(4):
+            n["mine_delta"][j] = ns.randn(R, L)
+            if train:
+                am[j] = ns.dropout_mask((R * 8, 16, 441), 0.1)
+        n["attn_mask"] = am
+        n["proj_mask"] = ns.dropout_mask((R, 512), 0.1) if train else np.ones((R, 512), np.float32)
+        mm = [ns.dropout_mask((R, 512), 0.1) if train else np.ones((R, 512), np.float32) for _ in range(2)]
+        perms = np.stack([ns.randperm(B) for _ in range(S)]).astype(np.int32)
+        mm += [ns.dropout_mask((R, 512), 0.1) if train else np.ones((R, 512), np.float32) for _ in range(2)]
+        n["mine_mask"] = np.stack(mm)
+        out = {k: dev(v) for k, v in n.items()}
+        out["perms"] = torch.from_numpy(perms).cuda().contiguous()
+        return out
+
     def mine_train(self, B, L, S):
         """train_epistemic_estimator: the draws of ONE estimator forward (same order as inside the EFE rollout, K = 1)."""
         ns = self.ns
@@ -80,13 +101,33 @@ class ParityNoise(NoiseSource):
         ns = self.ns
         if self.pixel:
             n = {"policy_eps": np.zeros((H, K * B, A), np.float32), "reparam_eps": np.zeros((H, K * B, L), np.float32)}
+            live = self.live_epistemic_samples
+            R1 = live * B
+            pe = [{"mine_z_eps": np.zeros((K * R1, L), np.float32), "mine_delta": np.zeros((4, K * R1, L), np.float32),
+                   "attn_mask": np.ones((4, K * R1 * 8, 16, 441), np.float32), "proj_mask": np.ones((K * R1, 512), np.float32),
+                   "mine_mask": np.ones((4, K * R1, 512), np.float32), "perms": np.zeros((K * live, B), np.int32)} for _ in range(H)] if live else None
             for k in range(K):
                 for t in range(H):
                     n["policy_eps"][t, k * B:(k + 1) * B] = ns.randn(B, A)
                     n["reparam_eps"][t, k * B:(k + 1) * B] = ns.randn(B, L)
-                    if self.burn_epistemic_samples:
+                    if live:      # the pixel estimator's draws for this (k, t), reference order, scattered into trajectory k's rows
+                        d, rs = pe[t], slice(k * R1, (k + 1) * R1)
+                        for s_ in range(live):
+                            d["mine_z_eps"][k * R1 + s_ * B:k * R1 + (s_ + 1) * B] = ns.randn(B, L)
+                        for j in range(4):
+                            d["mine_delta"][j, rs] = ns.randn(R1, L)
+                            d["attn_mask"][j, k * R1 * 8:(k + 1) * R1 * 8] = ns.dropout_mask((R1 * 8, 16, 441), 0.1)
+                        d["proj_mask"][rs] = ns.dropout_mask((R1, 512), 0.1)
+                        d["mine_mask"][0, rs] = ns.dropout_mask((R1, 512), 0.1); d["mine_mask"][1, rs] = ns.dropout_mask((R1, 512), 0.1)
+                        for s_ in range(live):
+                            d["perms"][k * live + s_] = ns.randperm(B)
+                        d["mine_mask"][2, rs] = ns.dropout_mask((R1, 512), 0.1); d["mine_mask"][3, rs] = ns.dropout_mask((R1, 512), 0.1)
+                    elif self.burn_epistemic_samples:
                         orc.burn_pixel_epistemic_draws(ns, B, L, self.burn_epistemic_samples, True)
-            return {k: dev(v) for k, v in n.items()}
+            out = {k: dev(v) for k, v in n.items()}
+            if live:
+                out["pixel_epistemic"] = [{k: (torch.from_numpy(v).cuda().contiguous() if k == "perms" else dev(v)) for k, v in d.items()} for d in pe]
+            return out
         M, R = K * B, K * S * B
         n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),
              "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((H, 4, R, L), np.float32),

@@ -140,10 +140,11 @@ def _load_pixel_params(agent, L, A, D, N, key):
     """Oracle-drawn weights (non-zero adaLN / heads) for everything the oracle knows; the feature decoder keeps its own init."""
     ai = agent.active_inference
     p = draw_params(param_specs(L, A, L, D, N), key, orc.schedule_tables(N))
+    p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}     # state-mode shapes
     sd = ai.state_dict()
     full = {k: (p[k] if k in p else v.cpu().clone()) for k, v in sd.items()}
     ai.load_state_dict(full, strict=True)
-    full = {k: v for k, v in full.items() if not k.startswith("observation_decoder.")}      # the oracle's train_step does not model the ConvDecoder
+    full = {k: v for k, v in full.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}   # not modelled by these oracle calls
     pe = draw_encoder_params(encoder_specs(L), key + 1)
     agent.encoder.load_state_dict(pe, strict=True)
     merged = {k: v.clone() for k, v in full.items()}
@@ -237,13 +238,14 @@ def test_pixel_agent_philox_run():
 
 def test_pixel_agent_train_step_reference_golden(golden_dir):
     """One whole DiffusionPixelAgent.train_step against the REFERENCE's own post-step state (tests/golden/pixel_step.npz, written by
-    oracle/gen_golden_pixel_step.py from a run of the reference): every parameter of every optimiser group (checksums + selected
-    tensors) and every non-epistemic metric."""
+    oracle/gen_golden_pixel_step.py from a run of the reference) WITH the pixel estimator evaluated inside the EFE: every parameter of
+    every optimiser group (checksums + selected tensors), every metric incl. policy_loss and epistemic/*, and the MINE running mean."""
     import functools
+    from oracle.encoder_weights import conv_decoder_specs, draw_conv_decoder_params, draw_pixel_estimator_params, pixel_estimator_specs
     from oracle.weights import draw_feature_decoder
     g = np.load(os.path.join(golden_dir, "pixel_step.npz"))
     L, A, D, N, H, B, K, S, CAP = (int(v) for v in g["dims"])
-    kw, ke, kf, ks, kstep = (int(v) for v in g["keys"])
+    kw, ke, kf, ks, kstep, kdec, kest = (int(v) for v in g["keys"])
     import aid_amd
     from test_hip_agent import Box
     cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=L, hidden_dim=D, pixel_observation=True)
@@ -256,23 +258,29 @@ def test_pixel_agent_train_step_reference_golden(golden_dir):
     p = draw_params(param_specs(L, A, L, D, N), kw, orc.schedule_tables(N))
     p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}
     p.update(draw_feature_decoder(L, D, kf))
+    pdec = draw_conv_decoder_params(conv_decoder_specs(L, hidden=D), kdec)
+    p.update({"observation_decoder." + k: v for k, v in pdec.items()}); p.update({"epistemic_estimator.decoder." + k: v for k, v in pdec.items()})
+    p.update({"epistemic_estimator." + k: v for k, v in draw_pixel_estimator_params(pixel_estimator_specs(L), kest).items()})
     sd = ai.state_dict()
-    assert set(p) == {k for k in sd if not k.startswith("observation_decoder.")}, set(p) ^ set(sd)     # + the ConvDecoder (own init)
-    ai.load_state_dict({**sd, **p}, strict=True)
+    assert set(p) == set(sd), sorted(set(p) ^ set(sd))[:6]          # the reference's pixel-mode state_dict layout, key for key
+    ai.load_state_dict(p, strict=True)
     agent.encoder.load_state_dict(draw_encoder_params(encoder_specs(L), ke), strict=True)
     bs = NoiseStream(ks)
     obs = bs.rand(CAP, 3, 3, 84, 84); act = np.tanh(bs.randn(CAP, A)).astype(np.float32); rew = bs.randn(CAP); nobs = bs.rand(CAP, 3, 3, 84, 84)
     for i in range(CAP):
         agent.replay_buffer.add(obs[i], act[i], float(rew[i]), nobs[i], False)
-    pn = ParityNoise(kstep, pixel=True, burn_epistemic_samples=S); ai.noise = pn; agent.replay_buffer.index_source = pn
-    ai.compute_expected_free_energy_diffusion = functools.partial(ai.compute_expected_free_energy_diffusion, num_trajectories=K)
+    pn = ParityNoise(kstep, pixel=True); pn.live_epistemic_samples = S
+    ai.noise = pn; agent.replay_buffer.index_source = pn
+    ai.pixel_epistemic = True
+    ai.compute_expected_free_energy_diffusion = functools.partial(ai.compute_expected_free_energy_diffusion, num_trajectories=K, num_ambiguity_samples=S)
     m = agent.train_step()
     for k in g.files:
         if k.startswith("metric/"):
             name = k.split("/", 1)[1]
             assert name in m, name
-            np.testing.assert_allclose(m[name], float(g[k]), rtol=5e-3, atol=5e-5, err_msg=name)
+            np.testing.assert_allclose(m[name], float(g[k]), rtol=5e-3, atol=5e-4 if name.startswith("epistemic") else 5e-5, err_msg=name)
     got = {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}
+    np.testing.assert_allclose(float(got["epistemic_estimator.running_mean"]), float(g["running_mean"]), rtol=5e-3)
     for k in g.files:
         if k.startswith("param/"):
             n = k.split("/", 1)[1]
@@ -320,3 +328,25 @@ def test_pixel_decode_observation_paths():
     ai.train()
     with pytest.raises(NotImplementedError):
         ai.decode_observation(dev(z), decode_to_pixels=True)
+
+
+def test_pixel_epistemic_value_reference_golden(nat, golden_dir):
+    """Pixel branch of the epistemic estimator (ConvDecoder finite differences -> 5x5 stride-2 convs -> 16-query multi-head attention
+    aggregator -> projector / latent processor / MINE statistics) against two calls of the REFERENCE's estimator."""
+    from oracle.encoder_weights import conv_decoder_specs, draw_conv_decoder_params, draw_pixel_estimator_params, pixel_estimator_specs
+    g = np.load(os.path.join(golden_dir, "pixel_estimator.npz"))
+    L, B, S = (int(v) for v in g["dims"]); kd, ke, kz, k1, k2 = (int(v) for v in g["keys"])
+    pd = {"observation_decoder." + k: v.cuda().contiguous() for k, v in draw_conv_decoder_params(conv_decoder_specs(L), kd).items()}
+    pe = {"epistemic_estimator." + k: v.cuda().contiguous() for k, v in draw_pixel_estimator_params(pixel_estimator_specs(L), ke).items()}
+    dec, epi = nat.conv_decoder_table(pd), nat.pixel_epistemic_table(pe)
+    nm = dev(NoiseStream(kz).randn(B, L))
+    rm = 0.0
+    for call, key in ((1, k1), (2, k2)):
+        pn = ParityNoise(key, pixel=True)
+        mine = nat.pixel_epistemic_value(dec, epi, nm, 1, S, noise=pn.pixel_estimator(B, L, S), train=True).cpu().numpy()[0]
+        joint, tlog, texp, mi = (float(v) for v in mine)
+        rm = texp if rm == 0.0 else 0.01 * texp + 0.99 * rm
+        np.testing.assert_allclose(mi, float(g[f"c{call}/epistemic/mi_estimate"]), rtol=5e-3, atol=2e-4)
+        np.testing.assert_allclose(joint, float(g[f"c{call}/epistemic/joint_term"]), rtol=5e-3, atol=2e-4)
+        np.testing.assert_allclose(tlog, float(g[f"c{call}/epistemic/marginal_term"]), rtol=5e-3, atol=2e-4)
+        np.testing.assert_allclose(rm, float(g[f"c{call}/epistemic/running_mean"]), rtol=2e-3)

@@ -160,15 +160,19 @@ def test_pixel_infonce_golden(golden_dir):
 
 
 def test_pixel_train_step_golden(golden_dir):
-    """The oracle's DiffusionPixelAgent.train_step restatement against the reference's own post-step state (pixel_step.npz)."""
-    from oracle.encoder_weights import draw_encoder_params, encoder_specs
+    """The oracle's DiffusionPixelAgent.train_step restatement (pixel estimator evaluated inside the EFE) against the reference's own
+    post-step state and metrics (pixel_step.npz)."""
+    from oracle.encoder_weights import (conv_decoder_specs, draw_conv_decoder_params, draw_encoder_params, draw_pixel_estimator_params, encoder_specs,
+                                        pixel_estimator_specs)
     from oracle.weights import draw_feature_decoder, draw_params, param_specs
     g = np.load(os.path.join(golden_dir, "pixel_step.npz"))
     L, A, D, N, H, B, K, S, CAP = (int(v) for v in g["dims"])
-    kw, ke, kf, ks, kstep = (int(v) for v in g["keys"])
+    kw, ke, kf, ks, kstep, kdec, kest = (int(v) for v in g["keys"])
     p = draw_params(param_specs(L, A, L, D, N), kw, orc.schedule_tables(N))
     p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}
     p.update(draw_feature_decoder(L, D, kf))
+    p.update({"epistemic_estimator.decoder." + k: v for k, v in draw_conv_decoder_params(conv_decoder_specs(L, hidden=D), kdec).items()})
+    p.update({"epistemic_estimator." + k: v for k, v in draw_pixel_estimator_params(pixel_estimator_specs(L), kest).items()})
     p.update({"encoder." + k: v for k, v in draw_encoder_params(encoder_specs(L), ke).items()})
     bs = NoiseStream(ks)
     store = {"observations": bs.rand(CAP, 3, 3, 84, 84), "actions": np.tanh(bs.randn(CAP, A)).astype(np.float32), "rewards": bs.randn(CAP),
@@ -177,15 +181,16 @@ def test_pixel_train_step_golden(golden_dir):
     batch = orc.replay_sample(store, CAP, B, ns)
     batch["observations"] = batch["observations"].reshape(B, 9, 84, 84); batch["next_observations"] = batch["next_observations"].reshape(B, 9, 84, 84)
     torch.set_num_threads(8)
-    m = orc.pixel_train_step(st, batch, ns, horizon=H, num_trajectories=K, burn_epistemic_samples=S)
+    m = orc.pixel_train_step(st, batch, ns, horizon=H, num_trajectories=K, pixel_epistemic_samples=S)
     for k in g.files:
         if k.startswith("metric/"):
-            np.testing.assert_allclose(m[k.split("/", 1)[1]], float(g[k]), rtol=2e-4, atol=1e-6, err_msg=k)
+            np.testing.assert_allclose(m[k.split("/", 1)[1]], float(g[k]), rtol=2e-4, atol=2e-5, err_msg=k)
         if k.startswith("param/"):
             np.testing.assert_allclose(st.p[k.split("/", 1)[1]].detach().numpy(), g[k], rtol=1e-4, atol=2e-7, err_msg=k)
+    np.testing.assert_allclose(st.running_mean, float(g["running_mean"]), rtol=1e-4)
     names = [str(n) for n in g["names"]]
     cs = np.array([float(st.p[n].detach().double().sum()) for n in names])
-    assert np.all(np.abs(cs - g["checksum"]) <= 1e-6 * g["abssum"] + 1e-6)
+    assert np.all(np.abs(cs - g["checksum"]) <= 2e-6 * g["abssum"] + 2e-6)
 
 
 def test_train_epistemic_estimator_golden(golden_dir):

@@ -177,3 +177,36 @@ def test_cross_step_prefetch_equals_reference_order():
     agent.train_step(); assert agent._prefetch is not None
     ai.load_state_dict(ai.state_dict())
     assert agent._take_prefetch(B) is None
+
+
+def test_graphed_small_batch_denoise_matches_eager():
+    """act()-sized reverse loops are replayed from a captured hipGraph: same latents as the eager loop fed the same Philox draws, still
+    valid after an optimiser step (weights are read in place), and per-call randomness differs."""
+    from aid_amd import _native as nat
+    O, A = 17, 6
+    agent = _agent(O, A, 64, 6, 2, 8, cap=32)
+    ai = agent.active_inference
+    rng = np.random.default_rng(1)
+    for _ in range(32):
+        agent.replay_buffer.add(rng.standard_normal(O), rng.uniform(-1, 1, A), float(rng.standard_normal()), rng.standard_normal(O), False)
+    obs = torch.randn(4, O, device="cuda")
+    for train in (False, True):
+        ai.train(train)
+        for rep in range(2):
+            off0 = ai.noise._offset
+            z_graph = ai.denoise_only(obs)
+            # eager loop with the very draws the graphed call made
+            N, L, D = 6, O, 64
+            z0 = torch.empty(4, L, device="cuda"); eps = torch.empty(N, 4, L, device="cuda")
+            o = off0; nat.fill_normal(z0, ai.noise.seed, o); o += z0.numel(); nat.fill_normal(eps, ai.noise.seed, o); o += eps.numel()
+            mask = None
+            if train:
+                mask = torch.empty(N, 4, D, device="cuda"); nat.fill_dropout_mask(mask, 0.1, ai.noise.seed, o)
+            z_eager = nat.denoise_loop(ai.latent_score_network.table(), ai.latent_diffusion.coefs(), obs, N, z0, eps, mask, train=train)
+            assert torch.equal(z_graph, z_eager)
+            if rep == 0:
+                first = z_graph.clone()
+                ai.train(True); agent.train_step(); ai.train(train)          # parameters move; the captured graph must see them
+            else:
+                assert not torch.equal(first, z_graph)
+    assert len(ai._denoise_graphs) == 2

@@ -527,6 +527,11 @@ def replay_gather(obs, next_obs, actions, rewards, dones, idx):
     dev = obs.device
     o, n, a = torch.empty(B, O, device=dev), torch.empty(B, O, device=dev), torch.empty(B, A, device=dev)
     r, d = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    if obs.dtype == torch.uint8:      # byte frame storage: widened on the fly
+        assert next_obs.dtype == torch.uint8 and obs.is_cuda and obs.is_contiguous() and next_obs.is_contiguous()
+        check(lib().aid_replay_gather_u8(C.c_void_p(obs.data_ptr()), C.c_void_p(next_obs.data_ptr()), _ptr(actions), _ptr(rewards), _ptr(dones),
+                                         C.c_void_p(idx.data_ptr()), B, O, A, _ptr(o), _ptr(n), _ptr(a), _ptr(r), _ptr(d), _stream()), "aid_replay_gather_u8")
+        return o, n, a, r, d
     check(lib().aid_replay_gather(_ptr(obs), _ptr(next_obs), _ptr(actions), _ptr(rewards), _ptr(dones), C.c_void_p(idx.data_ptr()), B, O, A,
                                   _ptr(o), _ptr(n), _ptr(a), _ptr(r), _ptr(d), _stream()), "aid_replay_gather")
     return o, n, a, r, d

@@ -81,6 +81,23 @@ __global__ void replay_gather_kernel(const float* __restrict__ obs, const float*
     else d_out[b] = done[row];
 }
 
+// uint8 frame storage (pixel replay, 4x less HBM): obs / next_obs rows are bytes, widened to float with the same value (0..255)
+__global__ void replay_gather_u8_kernel(const uint8_t* __restrict__ obs, const uint8_t* __restrict__ nobs, const float* __restrict__ act,
+                                        const float* __restrict__ rew, const float* __restrict__ done, const int64_t* __restrict__ idx,
+                                        int B, int O, int A, float* __restrict__ o_out, float* __restrict__ n_out, float* __restrict__ a_out,
+                                        float* __restrict__ r_out, float* __restrict__ d_out) {
+    const size_t W = (size_t)2 * O + A + 2;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * W) return;
+    const int b = i / W; const size_t c = i % W;
+    const int64_t row = idx[b];
+    if (c < (size_t)O) o_out[(size_t)b * O + c] = (float)obs[row * O + c];
+    else if (c < (size_t)2 * O) n_out[(size_t)b * O + (c - O)] = (float)nobs[row * O + (c - O)];
+    else if (c < (size_t)2 * O + A) a_out[(size_t)b * A + (c - 2 * O)] = act[row * A + (c - 2 * O)];
+    else if (c == (size_t)2 * O + A) r_out[b] = rew[row];
+    else d_out[b] = done[row];
+}
+
 // fp64 diagonal Fokker-Planck belief step (closed form; see oracle.aid_oracle.fokker_planck_step)
 __global__ void fokker_planck_kernel(double* __restrict__ mean, double* __restrict__ var, const double* __restrict__ obs,
                                      const double* __restrict__ score, const double* __restrict__ xi, int n, int L, double dt, double D,
@@ -291,6 +308,18 @@ int aid_replay_gather(const float* obs, const float* next_obs, const float* acti
     if (n == 0) return AID_OK;
     hipLaunchKernelGGL(replay_gather_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, obs, next_obs, actions, rewards, dones,
                        idx, B, O, A, obs_out, next_obs_out, act_out, rew_out, done_out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_replay_gather_u8(const uint8_t* obs, const uint8_t* next_obs, const float* actions, const float* rewards, const float* dones,
+                         const int64_t* idx, int B, int O, int A, float* obs_out, float* next_obs_out, float* act_out, float* rew_out,
+                         float* done_out, void* stream) {
+    AID_REQUIRE(obs && next_obs && actions && rewards && dones && idx && obs_out && next_obs_out && act_out && rew_out && done_out, AID_E_NULL,
+                "aid_replay_gather_u8: null tensor");
+    const size_t n = (size_t)B * ((size_t)2 * O + A + 2);
+    if (n == 0) return AID_OK;
+    hipLaunchKernelGGL(replay_gather_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, obs, next_obs, actions, rewards,
+                       dones, idx, B, O, A, obs_out, next_obs_out, act_out, rew_out, done_out);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 

@@ -399,6 +399,11 @@ int aid_replay_gather(const float* obs, const float* next_obs, const float* acti
                       const int64_t* idx, int B, int O, int A, float* obs_out, float* next_obs_out, float* act_out,
                       float* rew_out, float* done_out, void* stream);
 
+/* Same with uint8 frame storage (obs / next_obs rows are bytes; outputs are float32 with the same values 0..255). */
+int aid_replay_gather_u8(const uint8_t* obs, const uint8_t* next_obs, const float* actions, const float* rewards, const float* dones,
+                         const int64_t* idx, int B, int O, int A, float* obs_out, float* next_obs_out, float* act_out,
+                         float* rew_out, float* done_out, void* stream);
+
 /* ---- A14: Fokker-Planck belief step, diagonal covariance, fp64 (aid/core/belief_dynamics.py:97-172) ---
  * Batched over n beliefs of dimension L (double pointers): mean/var updated in place; entropy_out [n] optional.
  * xi: [n,L] N(0,1) draws (double).  Closed form documented in oracle.aid_oracle.fokker_planck_step. */

@@ -217,3 +217,28 @@ def test_gemm_every_kernel_variant(nat, code, layout):
     ref = A.astype(np.float64) @ Bm.astype(np.float64).T + bias
     scale = np.abs(A).astype(np.float64) @ np.abs(Bm).astype(np.float64).T + 1.0
     assert np.max(np.abs(out.cpu().numpy() - ref) / scale) < 2e-6
+
+
+def test_replay_buffer_uint8_frames(nat):
+    """optimize_memory=True + uint8 frames: the ring arrays stay bytes in HBM; sample() returns the same float values a float32 store
+    would (the reference's arrays hold float32(frame)); bit-exact."""
+    from aid_amd.utils.buffers import ReplayBuffer
+    rng = np.random.default_rng(3)
+    cap, shape, A, B = 32, (3, 3, 84, 84), 4, 16
+    frames = rng.integers(0, 256, (cap, *shape), dtype=np.uint8); nxt = rng.integers(0, 256, (cap, *shape), dtype=np.uint8)
+    act = rng.uniform(-1, 1, (cap, A)).astype(np.float32); rew = rng.standard_normal(cap).astype(np.float32)
+    rb8 = ReplayBuffer(cap, shape, A, "cuda", optimize_memory=True); rbf = ReplayBuffer(cap, shape, A, "cuda", optimize_memory=False)
+    for i in range(cap):
+        rb8.add(frames[i], act[i], float(rew[i]), nxt[i], i % 7 == 0); rbf.add(frames[i], act[i], float(rew[i]), nxt[i], i % 7 == 0)
+    assert rb8.observations.dtype == torch.uint8 and rbf.observations.dtype == torch.float32
+    assert rb8.observations.element_size() * rb8.observations.numel() * 4 == rbf.observations.element_size() * rbf.observations.numel()
+
+    class Fixed:
+        def replay_indices(self, size, batch): return np.arange(batch)[::-1] % size
+    rb8.index_source = rbf.index_source = Fixed()
+    a, b = rb8.sample(B), rbf.sample(B)
+    for k in a:
+        assert a[k].dtype == torch.float32 and torch.equal(a[k], b[k]), k
+    assert torch.equal(a["observations"][0].cpu(), torch.from_numpy(frames[B - 1].astype(np.float32)))
+    with pytest.raises(TypeError):
+        rb8.add(frames[0].astype(np.float32), act[0], 0.0, nxt[0], False)

@@ -585,6 +585,12 @@ def reward_normalize_global(stats_src, rewards, state):
     return out
 
 
+def gemm_low_lds_hint(on: bool):
+    """Host-side dispatch hint for the launches enqueued while it is set: small GEMMs use the 35 KB-LDS panel variant so that they can
+    share CUs with a large GEMM running on another stream (speed only)."""
+    check(lib().aid_gemm_force_kernel(512 if on else 0), "aid_gemm_force_kernel")
+
+
 def gemm_force_kernel(k: int):
     """0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk (benches/tests only)."""
     check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")

@@ -114,6 +114,8 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             if self.overlap_streams:
                 self.score_optimizer.step()            # data parallel: the 109 MB RCCL all-reduce runs here, off the critical path
             ws = self._side_workspace() if self.overlap_streams else None
+            if self.overlap_streams:
+                nat.gemm_low_lds_hint(True)      # 35 KB panel variant: these launches must co-reside with the EFE's 25 600-row GEMMs
             if self._want_prefetch():
                 N, train = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
                 hook = lambda: ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
@@ -125,6 +127,8 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                                   "params": (self.score_optimizer.arena.step_count, ai.param_version), "B": B, "train": train}
             else:
                 next_latents = ai.denoise_only(next_obs, ws=ws)
+            if self.overlap_streams:
+                nat.gemm_low_lds_hint(False)
         if self.overlap_streams:
             next_latents.record_stream(main)
             if self._prefetch is not None:

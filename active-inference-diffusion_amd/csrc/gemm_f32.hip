@@ -765,12 +765,11 @@ __global__ void __launch_bounds__(256) gemm_ring_kernel(GemmArgs g, int tiles_n)
 // (67 KB), so TWO workgroups share a CU.  Used when a small-M layer has more 32x32 tiles than the chip has CUs (the 768-row
 // reverse loop: 384 tiles): with the 133 KB variant the second half of the grid waits for the first to retire.
 // ------------------------------------------------------------------------------------------------
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int KST>
 __global__ void __launch_bounds__(256) gemm_panel128_kernel(GemmArgs g, int tiles_n) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    constexpr int KST = 128;
     using RA = Ring<32, KST, AKM>; using RB = Ring<32, KST, BKM>;
-    static_assert((RA::INSTR + RB::INSTR) / 4 == 8, "vmcnt(8) below assumes 8 DMA instructions per wave per stage");
+    static_assert((RA::INSTR + RB::INSTR) / 4 == KST / 16, "counted vmcnt below assumes KST/16 DMA instructions per wave per stage");
     float* As = smem; float* Bs = smem + 2 * RA::FLOATS;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -789,7 +788,7 @@ __global__ void __launch_bounds__(256) gemm_panel128_kernel(GemmArgs g, int tile
     }
     for (int st = 0; st < ns; ++st) {
         const int cur = st & 1;
-        if (st + 1 < ns) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (st + 1 < ns) { if (KST == 128) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -826,16 +825,16 @@ __global__ void __launch_bounds__(256) gemm_panel128_kernel(GemmArgs g, int tile
         }
     }
 }
-template <bool AKM, bool BKM>
+template <bool AKM, bool BKM, int KST = 128>
 static int launch_panel128(const GemmArgs& g, hipStream_t s) {
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
-    const size_t lds = sizeof(float) * 2 * (Ring<32, 128, AKM>::FLOATS + Ring<32, 128, BKM>::FLOATS);
+    const size_t lds = sizeof(float) * 2 * (Ring<32, KST, AKM>::FLOATS + Ring<32, KST, BKM>::FLOATS);
     static bool done = false;
-    if (!done) {
-        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_panel128_kernel<AKM, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!done && lds > 65536) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_panel128_kernel<AKM, BKM, KST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         done = true;
     }
-    hipLaunchKernelGGL((gemm_panel128_kernel<AKM, BKM>), dim3(tm * tn), dim3(256), lds, s, g, tn);
+    hipLaunchKernelGGL((gemm_panel128_kernel<AKM, BKM, KST>), dim3(tm * tn), dim3(256), lds, s, g, tn);
     return AID_OK;
 }
 
@@ -910,6 +909,7 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     return AID_OK;
 }
 
+static int g_low_lds = 0;        // aid_gemm_force_kernel bit 9: prefer the 35 KB panel variant for small problems (launches meant to overlap another stream)
 static int g_force_kernel = 0;   // aid_gemm_force_kernel: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
 
 template <bool AKM, bool BKM>
@@ -926,6 +926,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
         case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
         case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM, 1>(g, s); break;
         case 14: if (p32_ok) return launch_panel128<AKM, BKM>(g, s); break;
+        case 15: if (p32_ok) return launch_panel128<AKM, BKM, 64>(g, s); break;
         default: break;
     }
     // Automatic selection, set by measurement on MI355X (profiles/gemm_*_r01.txt, tools/perf/cold_chain.py).
@@ -943,6 +944,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     if (t64 >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);        // unaligned operands / K < 64
     // < 160 tiles: the grid cannot fill the chip with 64x64 tiles; the 32x32 LDS-DMA panel kernel (whole K in flight, 4-way
     // in-workgroup split-K) has the shortest critical path.
+    if (p32_ok && t32 <= 1536 && g_low_lds) return launch_panel128<AKM, BKM, 64>(g, s);      // side-stream launches: co-reside with the big GEMM
     if (p32_ok && t32 <= 1536) {
         // more tiles than CUs and >= 16 row tiles (the 768-row reverse loop, 1024-row batches): two 67 KB workgroups per CU beat two
         // rounds of the 133 KB kernel by 12-18 us per launch in situ; a 256-row x 2048-column layer is the exception
@@ -959,7 +961,7 @@ static inline bool routes_to_tile(const GemmArgs& g) {
     return g_force_kernel == 0 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 160;
 }
 
-void gemm_force_kernel(int k) { g_force_kernel = k & 0xff; g_big_map = (k >> 8) & 0xff; }
+void gemm_force_kernel(int k) { g_force_kernel = k & 0xff; g_big_map = (k >> 8) & 1; g_low_lds = (k >> 9) & 1; }
 
 __global__ void slab_fold_kernel(const float* __restrict__ slab, int nslab, GemmArgs g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

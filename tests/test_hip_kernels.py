@@ -197,7 +197,7 @@ def test_gemm_small_k_route(nat, M, N, K):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
 
 
-@pytest.mark.parametrize("code", [1, 2, 4, 6, 9, 9 + 256, 11, 11 + 256, 14])
+@pytest.mark.parametrize("code", [1, 2, 4, 6, 9, 9 + 256, 11, 11 + 256, 14, 15, 512])
 @pytest.mark.parametrize("layout", ["nt", "nn", "tn"])
 def test_gemm_every_kernel_variant(nat, code, layout):
     """Each kernel of the family (forced through aid_gemm_force_kernel) on a shape all of them accept, incl. a ragged row count for the

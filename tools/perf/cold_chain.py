@@ -27,12 +27,12 @@ def run(force, steps=10):
         for _ in range(5): g.replay()
         torch.cuda.synchronize()
     return (time.perf_counter() - t0) / 5 / steps * 1e6
-NAMES = {0: "auto", 1: "panel32", 2: "ring64", 4: "tile64", 6: "splitk", 9: "b64x32p2", 7: "b64x16p2", 10: "b64x16", 13: "b64x128x16", 14: "panel128"}
+NAMES = {0: "auto", 1: "panel32", 2: "ring64", 4: "tile64", 6: "splitk", 9: "b64x32p2", 7: "b64x16p2", 10: "b64x16", 13: "b64x128x16", 14: "panel128", 15: "panel64"}
 base = run({})
 print(f"M={M}: auto chain {base:.1f} us per step ({base/18:.1f} us/GEMM)", flush=True)
 for kind in kinds:
     row = []
-    for code in (1, 14, 2, 9, 4):
+    for code in (1, 14, 15, 2):
         try:
             t = run({kind: code})
             row.append(f"{NAMES[code]}={t - base:+.1f}")

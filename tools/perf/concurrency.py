@@ -32,8 +32,20 @@ def both_rev(force=0):
     efe()
     main.wait_stream(side)
 print(f"efe alone {t(efe):.2f} ms   denoise alone {t(dn):.2f} ms   denoise(tile64) alone {t(lambda: dn(4)):.2f} ms")
-print(f"both (efe first)      {t(both):.2f} ms   with side tile64 {t(lambda: both(4)):.2f} ms   with side splitk {t(lambda: both(6)):.2f} ms")
-print(f"denoise(splitk) alone {t(lambda: dn(6)):.2f} ms")
+print(f"both (efe first)      {t(both):.2f} ms   with side splitk {t(lambda: both(6)):.2f} ms   with side low-LDS panel {t(lambda: both(512)):.2f} ms")
+print(f"denoise(splitk) alone {t(lambda: dn(6)):.2f} ms   denoise(low-LDS panel) alone {t(lambda: dn(512)):.2f} ms")
+R3 = torch.cat([next_obs, obs, next_obs])
+def dn3(force=0):
+    if force: nat.gemm_force_kernel(force)
+    ai.denoise_many([next_obs, obs, next_obs], ws=ws2)
+    if force: nat.gemm_force_kernel(0)
+def both3(force=0):
+    ev = torch.cuda.Event(); ev.record(main)
+    efe()
+    side.wait_event(ev)
+    with torch.cuda.stream(side): dn3(force)
+    main.wait_stream(side)
+print(f"768-row loop alone {t(dn3):.2f} ms (low-LDS {t(lambda: dn3(512)):.2f} ms)   with efe {t(both3):.2f} ms   low-LDS with efe {t(lambda: both3(512)):.2f} ms")
 # host-side enqueue cost
 t0 = time.perf_counter(); efe(); te = time.perf_counter() - t0; torch.cuda.synchronize()
 t0 = time.perf_counter(); dn(); td = time.perf_counter() - t0; torch.cuda.synchronize()

@@ -204,22 +204,24 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents)
         d_next = torch.zeros_like(enc_next)
         contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
-        self.encoder.backward(ai._last_d_obs, ctx_a)
-        self.encoder.backward(d_next, ctx_b)
-        if dp:
-            comm = self._comm_stream()
-            comm.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(comm):
-                self.score_optimizer.allreduce_grads(async_op=True)
-        else:
+        # The two encoder backward passes (36 ms at B=256) and the score / encoder / feature-decoder optimiser step depend only on the
+        # feature gradients produced above; the policy, value and dynamics phases read none of those parameters.  They run on a side
+        # stream underneath those phases (in data-parallel runs the gradient all-reduces ride on that stream too).
+        main = torch.cuda.current_stream()
+        side = self._comm_stream() if self.overlap_streams else main
+        if self.overlap_streams:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            self.encoder.backward(ai._last_d_obs, ctx_a)
+            self.encoder.backward(d_next, ctx_b)
             self.score_optimizer.step()
+        if self.overlap_streams:
+            for t_ in (ai._last_d_obs, d_next, enc_obs, enc_next):
+                t_.record_stream(side)
         # policy
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
-        if dp:
-            torch.cuda.current_stream().wait_stream(self._comm_stream())
-            self.score_optimizer.step()
         # value (the pixel agent reuses next_latents, pixel_agent.py:364-371) and dynamics
         self.value_optimizer.zero_grad()
         value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
@@ -228,6 +230,8 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         self.dynamics_optimizer.zero_grad()
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
         self.dynamics_optimizer.step()
+        if self.overlap_streams:
+            main.wait_stream(side)        # the next encoder forward needs the updated encoder
         self.total_steps += 1
         keys, vals = [], []
         for k, v in {**elbo_info, "contrastive_loss": contrastive, "policy_loss": efe_info.pop("policy_loss"), **efe_info, "value_loss": value_loss,
@@ -238,6 +242,8 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         metrics.update({"num_trajectories": efe_info["num_trajectories"], "horizon": efe_info["horizon"]})
         self._last = {"latents": latents, "next_latents": next_latents, "encoded_obs": enc_obs, "encoded_next_obs": enc_next}
         return metrics
+
+    overlap_streams = True    # False: every phase on the current stream, in order
 
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:

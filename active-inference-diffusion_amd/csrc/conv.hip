@@ -366,6 +366,7 @@ static EncGeom enc_geom(const AidEncoderNet& e) {
 struct EncSaved {
     float* x0;                                   // augmented input, CNHW
     float* conv_out[ENC_LAYERS]; float* act[ENC_LAYERS]; float* gn_stats[ENC_LAYERS]; float* w_eff[ENC_LAYERS]; float* sn[ENC_LAYERS];
+    float* col[ENC_LAYERS];                      // im2col of every layer's input: re-used by the weight-gradient GEMM (3.8 GB at B=256; HBM is 288 GB)
     float *pool, *apre, *att; int32_t* amax;
     float *xf, *ln_stats, *xln;
     LlaSave s0; float* o4; float* st5; float* feat;
@@ -377,6 +378,7 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
         const size_t n = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i];
         sv.conv_out[i] = ws.f32(n); sv.act[i] = ws.f32(n); sv.gn_stats[i] = ws.f32((size_t)B * g.G[i] * 2);
         sv.w_eff[i] = ws.f32((size_t)g.cout[i] * g.Kp[i]); sv.sn[i] = ws.f32(g.cout[i] + g.K[i] + 4);
+        sv.col[i] = ws.f32((size_t)g.Kp[i] * B * g.ho[i] * g.ho[i]);
     }
     sv.pool = ws.f32((size_t)B * 2 * g.HW); sv.apre = ws.f32((size_t)B * g.HW); sv.att = ws.f32((size_t)B * g.HW);
     sv.amax = (int32_t*)ws.raw(sizeof(int32_t) * (size_t)B * g.HW);
@@ -537,7 +539,7 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     for (int i = 0; i < ENC_LAYERS; ++i) {
         const size_t N = (size_t)B * g.ho[i] * g.ho[i];
         const size_t mark = ws.mark();
-        float* col = ws.f32((size_t)g.Kp[i] * N); AID_WS_OK(ws);
+        float* col = sv.col[i];
         hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, s, e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], train,
                            train, sv.w_eff[i], sv.sn[i]);
         AID_LAUNCH_CHECK();
@@ -629,10 +631,8 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
                            g.cout[i], B, hw, g.G[i]);
         hipLaunchKernelGGL(gn_param_grad_kernel, dim3(g.cout[i]), dim3(1024), 0, s, dcur, sv.conv_out[i], sv.gn_stats[i], gr.gn_g[i], gr.gn_b[i], g.cout[i], B, hw, g.G[i]);
         AID_LAUNCH_CHECK();
-        const float* xin = i == 0 ? sv.x0 : sv.act[i - 1];
-        L1D(im2col3_kernel, (size_t)g.Kp[i] * N, s, xin, col, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], g.K[i], (size_t)g.Kp[i] * N);
-        {   // dW_eff[Cout][Kp] = dconv[Cout][N] x col[Kp][N]^T  (both k-contiguous along N; huge reduction -> slabs)
-            GemmArgs ga = gemm_args(dconv, (int)N, col, (int)N, dweff, g.Kp[i], g.cout[i], g.Kp[i], (int)N);
+        {   // dW_eff[Cout][Kp] = dconv[Cout][N] x col[Kp][N]^T  (both k-contiguous along N; huge reduction -> slabs); col: the forward's im2col
+            GemmArgs ga = gemm_args(dconv, (int)N, sv.col[i], (int)N, dweff, g.Kp[i], g.cout[i], g.Kp[i], (int)N);
             ga.slab = slab; ga.nslab = S;
             AID_TRY(gemm_f32(ga, s));
         }

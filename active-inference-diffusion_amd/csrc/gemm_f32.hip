@@ -369,7 +369,12 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int nk = (g.K + BKT - 1) / BKT;
+    // slab mode (deterministic split-K): blockIdx.y owns a contiguous range of K tiles and writes its partial tile to slab[y]
+    const int nk_all = (g.K + BKT - 1) / BKT;
+    const int per = (nk_all + gridDim.y - 1) / gridDim.y;
+    const int ktb = blockIdx.y * per;                                  // first K tile of this slice
+    const int nk = max(0, min(per, nk_all - ktb));
+    const int kend = min(g.K, (ktb + nk) * BKT);                       // loads beyond this slice's K range come back as zeros
     auto contract = [&](int cur) {
         const float* a_s = As + cur * TA::FLOATS;
         const float* b_s = Bs + cur * TB::FLOATS;
@@ -391,21 +396,21 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
     };
     if constexpr (PD == 1) {
         f32x4 ra[PA], rb[PB];
-        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra);
-        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb);
-        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, 0, g.M, g.K, tid, ra);
-        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, 0, g.N, g.K, tid, rb);
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, ktb * BKT, g.M, kend, tid, ra);
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, ktb * BKT, g.N, kend, tid, rb);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, ktb * BKT, g.M, kend, tid, ra);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, ktb * BKT, g.N, kend, tid, rb);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
             const int cur = kt & 1;
             if (kt + 1 < nk) {
-                load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 1) * BKT, g.M, g.K, tid, ra);
-                load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 1) * BKT, g.N, g.K, tid, rb);
+                load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (ktb + kt + 1) * BKT, g.M, kend, tid, ra);
+                load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (ktb + kt + 1) * BKT, g.N, kend, tid, rb);
             }
             contract(cur);
             if (kt + 1 < nk) {
-                store_tile_k<BM, AKM, BKT, NT, PA>(As + (cur ^ 1) * TA::FLOATS, m0, (kt + 1) * BKT, g.M, g.K, tid, ra);
-                store_tile_k<BN, BKM, BKT, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, n0, (kt + 1) * BKT, g.N, g.K, tid, rb);
+                store_tile_k<BM, AKM, BKT, NT, PA>(As + (cur ^ 1) * TA::FLOATS, m0, (ktb + kt + 1) * BKT, g.M, kend, tid, ra);
+                store_tile_k<BN, BKM, BKT, NT, PB>(Bs + (cur ^ 1) * TB::FLOATS, n0, (ktb + kt + 1) * BKT, g.N, kend, tid, rb);
             }
             __syncthreads();
         }
@@ -414,32 +419,32 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
         // that tile kt+1 does not use, so a load has two contraction periods to arrive (Infinity-Cache / HBM latency is longer
         // than one 32-deep stage of fp32 MFMAs).  The loop is unrolled by two so both register sets are named statically.
         f32x4 ra0[PA], rb0[PB], ra1[PA], rb1[PB];
-        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, 0, g.M, g.K, tid, ra0);
-        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, 0, g.N, g.K, tid, rb0);
-        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, BKT, g.M, g.K, tid, ra1);     // rows beyond K come back as zeros
-        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, BKT, g.N, g.K, tid, rb1);
-        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, 0, g.M, g.K, tid, ra0);
-        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, 0, g.N, g.K, tid, rb0);
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, ktb * BKT, g.M, kend, tid, ra0);
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, ktb * BKT, g.N, kend, tid, rb0);
+        load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (ktb + 1) * BKT, g.M, kend, tid, ra1);     // rows beyond K come back as zeros
+        load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (ktb + 1) * BKT, g.N, kend, tid, rb1);
+        store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, ktb * BKT, g.M, kend, tid, ra0);
+        store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, ktb * BKT, g.N, kend, tid, rb0);
         __syncthreads();
         // An odd tile count runs one extra all-zero tile (loads beyond K come back as zeros) instead of leaving the loop half way:
         // an exit between the two halves makes the compiler shuttle the accumulators between two register banks every iteration.
         const int nk2 = (nk + 1) & ~1;
         for (int kt = 0; kt < nk2; kt += 2) {
             // even step: LDS[0] holds tile kt, set 1 holds tile kt+1 (in flight), set 0 is free
-            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 2) * BKT, g.M, g.K, tid, ra0);
-            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 2) * BKT, g.N, g.K, tid, rb0);
+            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (ktb + kt + 2) * BKT, g.M, kend, tid, ra0);
+            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (ktb + kt + 2) * BKT, g.N, kend, tid, rb0);
             __builtin_amdgcn_sched_barrier(0);     // keep the prefetch ahead of the MFMA block (the scheduler otherwise sinks it to the store)
             contract(0);
-            store_tile_k<BM, AKM, BKT, NT, PA>(As + TA::FLOATS, m0, (kt + 1) * BKT, g.M, g.K, tid, ra1);
-            store_tile_k<BN, BKM, BKT, NT, PB>(Bs + TB::FLOATS, n0, (kt + 1) * BKT, g.N, g.K, tid, rb1);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As + TA::FLOATS, m0, (ktb + kt + 1) * BKT, g.M, kend, tid, ra1);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs + TB::FLOATS, n0, (ktb + kt + 1) * BKT, g.N, kend, tid, rb1);
             __syncthreads();
             // odd step: LDS[1] holds tile kt+1, set 0 holds tile kt+2 (in flight), set 1 is free
-            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (kt + 3) * BKT, g.M, g.K, tid, ra1);
-            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (kt + 3) * BKT, g.N, g.K, tid, rb1);
+            load_tile_k<BM, AKM, BKT, NT, PA>(g.A, g.lda, m0, (ktb + kt + 3) * BKT, g.M, kend, tid, ra1);
+            load_tile_k<BN, BKM, BKT, NT, PB>(g.B, g.ldb, n0, (ktb + kt + 3) * BKT, g.N, kend, tid, rb1);
             __builtin_amdgcn_sched_barrier(0);
             contract(1);
-            store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, (kt + 2) * BKT, g.M, g.K, tid, ra0);
-            store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, (kt + 2) * BKT, g.N, g.K, tid, rb0);
+            store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, (ktb + kt + 2) * BKT, g.M, kend, tid, ra0);
+            store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, (ktb + kt + 2) * BKT, g.N, kend, tid, rb0);
             __syncthreads();
         }
     }
@@ -449,7 +454,11 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
         for (int j = 0; j < TN; ++j)
 #pragma clang loop unroll(full)
             for (int r = 0; r < 16; ++r)
-                epilogue_store(g, m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + wn + 32 * j + li, acc[i][j][r]);
+            {
+                const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, col = n0 + wn + 32 * j + li;
+                if (g.slab) { if (row < g.M && col < g.N) g.slab[((size_t)blockIdx.y * g.M + row) * g.N + col] = acc[i][j][r]; }
+                else epilogue_store(g, row, col, acc[i][j][r]);
+            }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,7 +906,7 @@ static int launch_big(const GemmArgs& g, hipStream_t s, int map = -1) {
         AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn), dim3(256), lds, s, g, tn, map);
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn, g.slab ? g.nslab : 1), dim3(256), lds, s, g, tn, map);
     return AID_OK;
 }
 template <bool AKM, bool BKM>
@@ -992,7 +1001,8 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         ProfScope prof(PROF_GEMM_TILE, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
         prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor + 4;
         int r;
-        if (!g.a_kmajor && !g.b_kmajor) r = launch_tile<64, 64, false, false>(g, vec, s);
+        if (vec && !g.a_kmajor && !g.b_kmajor) r = launch_big<64, 64, 32, false, false, 2>(g, s, 0);      // branch-free, two tiles of prefetch
+        else if (!g.a_kmajor && !g.b_kmajor) r = launch_tile<64, 64, false, false>(g, vec, s);
         else if (!g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, false, true>(g, vec, s);
         else if (g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, true, true>(g, vec, s);
         else r = launch_tile<64, 64, true, false>(g, vec, s);

@@ -210,3 +210,18 @@ def test_graphed_small_batch_denoise_matches_eager():
             else:
                 assert not torch.equal(first, z_graph)
     assert len(ai._denoise_graphs) == 2
+
+
+@pytest.mark.parametrize("O,A,B,D,N,H", [(11, 3, 100, 128, 5, 3), (23, 7, 36, 64, 4, 1)])
+def test_ragged_sizes_train_and_act(O, A, B, D, N, H):
+    """Batch sizes / dims that are not multiples of any tile (100 rows -> 300-row merged loop, latent 11 or 23): three train_steps
+    (device Philox, prefetch + side stream on) stay finite and act() works."""
+    agent = _agent(O, A, D, N, H, B, cap=4 * B)
+    rng = np.random.default_rng(O)
+    agent.replay_buffer.add_batch(rng.standard_normal((4 * B, O)), rng.uniform(-1, 1, (4 * B, A)), rng.standard_normal(4 * B),
+                                  rng.standard_normal((4 * B, O)), rng.random(4 * B) < 0.05)
+    for _ in range(3):
+        m = agent.train_step()
+        assert all(np.isfinite(v) for v in m.values()), m
+    a, info = agent.act(rng.standard_normal(O).astype(np.float32))
+    assert a.shape == (A,) and np.all(np.isfinite(a))

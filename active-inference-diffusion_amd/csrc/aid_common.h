@@ -112,7 +112,7 @@ inline int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx,
 // ---- profiling hooks (bench.py reads them through aid_prof_*) ---------------------------------
 enum ProfKernel : int { PROF_GEMM = 0, PROF_ROWWISE = 1, PROF_OPTIM = 2, PROF_GEMM_TILE = 3, PROF_COUNT = 4 };
 struct ProfScope {
-    int id; hipStream_t s; bool on; hipEvent_t e0, e1; double flops, bytes; int m = 0, n = 0, k = 0, layout = 0;
+    int id; hipStream_t s; bool on; hipEvent_t e0, e1; double flops, bytes; int m = 0, n = 0, k = 0, layout = 0, variant = 0;
     ProfScope(int id, hipStream_t s, double flops, double bytes);
     ~ProfScope();
 };

@@ -266,7 +266,9 @@ __global__ void __launch_bounds__(256) gemm_smallk_kernel(GemmArgs g, int tiles_
 #pragma unroll
         for (int j = 0; j < 4; ++j) epilogue_store(g, m0 + tr + 16 * i, c0 + j, acc[i][j]);
 }
+static thread_local int t_variant = 0;    // code of the kernel the last launch_* call used (profiling label: aid_prof_dump's `variant` column)
 static int launch_smallk(const GemmArgs& g, hipStream_t s) {
+    t_variant = 3;
     const int tm = (g.M + 63) / 64, tn = (g.N + 63) / 64;
     hipLaunchKernelGGL(gemm_smallk_kernel, dim3(tm * tn), dim3(256), 0, s, g, tn);
     return AID_OK;
@@ -517,6 +519,54 @@ __global__ void __launch_bounds__(256) gemm_splitk_kernel(GemmArgs g, int tiles_
             float v = acc[r] + red[(0 * 16 + r) * 64 + lane] + red[(1 * 16 + r) * 64 + lane] + red[(2 * 16 + r) * 64 + lane];
             const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
             epilogue_store(g, row, n0 + li, v);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Thin weight-gradient kernel: C[M,N] (+)= A^T B with both operands k-major ([K][M], [K][N]), a handful of 32x32 output tiles and a long K
+// (dW of a 6- or 17-wide layer over 2 560 rows).  One 1024-thread workgroup per tile: each of the 16 waves contracts its own K/16 slice
+// straight from global memory (k-major operands are lane-contiguous along m / n, so a fragment is one coalesced dword load) and the
+// slices are folded through LDS in wave order — a 16x shorter serial chain than one wave walking all of K, no workspace, reproducible.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) gemm_thin_tn_kernel(GemmArgs g, int tiles_n) {
+    constexpr int NW = 16;
+    __shared__ float red[(NW - 1) * 16 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int m0 = (blockIdx.x / tiles_n) * 32, n0 = (blockIdx.x % tiles_n) * 32;
+    int kper = (g.K + NW - 1) / NW; kper += kper & 1;
+    const int kb = wave * kper, ke = min(g.K, kb + kper);
+    const bool mok = m0 + li < g.M, nok = n0 + li < g.N;
+    const float* pa = g.A + (mok ? m0 + li : 0);
+    const float* pb = g.B + (nok ? n0 + li : 0);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = kb; k0 < ke; k0 += 16) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = min(k0 + 2 * j + h, g.K - 1);
+            av[j] = pa[(size_t)k * g.lda]; bv[j] = pb[(size_t)k * g.ldb];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = k0 + 2 * j + h < ke;
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ok && mok ? av[j] : 0.f, ok && nok ? bv[j] : 0.f, acc, 0, 0, 0);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            for (int w = 0; w < NW - 1; ++w) v += red[(w * 16 + r) * 64 + lane];
+            epilogue_store(g, m0 + (r & 3) + 8 * (r >> 2) + 4 * h, n0 + li, v);
         }
     }
 }
@@ -836,6 +886,7 @@ __global__ void __launch_bounds__(256) gemm_panel128_kernel(GemmArgs g, int tile
 }
 template <bool AKM, bool BKM, int KST = 128>
 static int launch_panel128(const GemmArgs& g, hipStream_t s) {
+    t_variant = KST == 64 ? 15 : 14;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     const size_t lds = sizeof(float) * 2 * (Ring<32, KST, AKM>::FLOATS + Ring<32, KST, BKM>::FLOATS);
     static bool done = false;
@@ -849,6 +900,7 @@ static int launch_panel128(const GemmArgs& g, hipStream_t s) {
 
 template <int BM, int BN, int KSTAGE, bool AKM, bool BKM>
 static int launch_ring(const GemmArgs& g, hipStream_t s) {
+    t_variant = 2;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const size_t lds = sizeof(float) * 2 * (Ring<BM, KSTAGE, AKM>::FLOATS + Ring<BN, KSTAGE, BKM>::FLOATS);
     static bool done = false;
@@ -862,6 +914,7 @@ static int launch_ring(const GemmArgs& g, hipStream_t s) {
 
 template <bool AKM, bool BKM>
 static int launch_panel(const GemmArgs& g, hipStream_t s) {
+    t_variant = 1;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     const size_t lds = sizeof(float) * 2 * (Panel<AKM>::FLOATS + Panel<BKM>::FLOATS);
     static bool done = false;
@@ -878,6 +931,7 @@ static int launch_panel(const GemmArgs& g, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, bool AKM, bool BKM>
 static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
+    t_variant = vec ? 4 : 5;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const size_t lds = sizeof(float) * 2 * (Tile<BM, AKM>::FLOATS + Tile<BN, BKM>::FLOATS);
     if (lds > 65536) {  // opt in to >64 KiB dynamic LDS once per instantiation
@@ -898,6 +952,7 @@ static int launch_tile(const GemmArgs& g, bool vec, hipStream_t s) {
 static int g_big_map = 0;     // benches only (aid_gemm_force_kernel bits 8+); the automatic dispatcher passes the map explicitly
 template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD = 1>
 static int launch_big(const GemmArgs& g, hipStream_t s, int map = -1) {
+    t_variant = PD == 2 ? 9 : 11;
     if (map < 0) map = g_big_map;
     const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
     const size_t lds = sizeof(float) * 2 * (TileK<BM, AKM, BKT>::FLOATS + TileK<BN, BKM, BKT>::FLOATS);
@@ -911,6 +966,7 @@ static int launch_big(const GemmArgs& g, hipStream_t s, int map = -1) {
 }
 template <bool AKM, bool BKM>
 static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
+    t_variant = vec ? 6 : 7;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
     const size_t lds = sizeof(float) * (2 * (Tile<32, AKM>::FLOATS + Tile<32, BKM>::FLOATS) + 3 * 16 * 64);
     if (vec) hipLaunchKernelGGL((gemm_splitk_kernel<AKM, BKM, true>), dim3(tm * tn), dim3(256), lds, s, g, tn);
@@ -918,6 +974,12 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     return AID_OK;
 }
 
+static int launch_thin_tn(const GemmArgs& g, hipStream_t s) {
+    t_variant = 8;
+    const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
+    hipLaunchKernelGGL(gemm_thin_tn_kernel, dim3(tm * tn), dim3(1024), 0, s, g, tn);
+    return AID_OK;
+}
 static int g_low_lds = 0;        // aid_gemm_force_kernel bit 9: prefer the 35 KB panel variant for small problems (launches meant to overlap another stream)
 static int g_force_kernel = 0;   // aid_gemm_force_kernel: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
 
@@ -932,6 +994,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
         case 2: if (r64_ok) return launch_ring<64, 64, 128, AKM, BKM>(g, s); break;
         case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
         case 6: return launch_splitk<AKM, BKM>(g, vec, s);
+        case 8: if (AKM && BKM) return launch_thin_tn(g, s); break;
         case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
         case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM, 1>(g, s); break;
         case 14: if (p32_ok) return launch_panel128<AKM, BKM>(g, s); break;
@@ -961,6 +1024,8 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
         return launch_panel<AKM, BKM>(g, s);
     }
     if (g.K <= 64) return launch_tile<64, 64, AKM, BKM>(g, vec, s);
+    // a few output tiles under a long K (weight gradients of 6- / 17-wide layers): 16 waves split K inside one workgroup
+    if (AKM && BKM && t32 <= 64 && g.K >= 512) return launch_thin_tn(g, s);
     return launch_splitk<AKM, BKM>(g, vec, s);
 }
 
@@ -1006,6 +1071,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         else if (!g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, false, true>(g, vec, s);
         else if (g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, true, true>(g, vec, s);
         else r = launch_tile<64, 64, true, false>(g, vec, s);
+        prof.variant = t_variant;
         if (r != AID_OK) return r;
         const size_t mn = (size_t)g.M * g.N;
         hipLaunchKernelGGL(slab_fold_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, s, g.slab, g.nslab, g);
@@ -1020,6 +1086,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     else if (!g.a_kmajor && g.b_kmajor) r = dispatch<false, true>(g, vec, s);
     else if (g.a_kmajor && g.b_kmajor) r = dispatch<true, true>(g, vec, s);
     else r = dispatch<true, false>(g, vec, s);
+    prof.variant = t_variant;
     if (r != AID_OK) return r;
     AID_LAUNCH_CHECK();
     return AID_OK;

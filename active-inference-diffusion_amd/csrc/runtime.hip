@@ -11,7 +11,7 @@ void set_error(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
 }
 
-struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int id, m, n, k, layout; };
+struct ProfRec { hipEvent_t e0, e1; double flops, bytes; int id, m, n, k, layout, variant; };
 struct ProfState {
     bool on = false;
     std::mutex mu;
@@ -28,7 +28,7 @@ ProfScope::~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, s);
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    g_prof.recs[id].push_back({e0, e1, flops, bytes, id, m, n, k, layout});
+    g_prof.recs[id].push_back({e0, e1, flops, bytes, id, m, n, k, layout, variant});
 }
 
 }  // namespace aid
@@ -52,12 +52,12 @@ int aid_prof_dump(const char* path) {
     FILE* f = fopen(path, "w");
     AID_REQUIRE(f, AID_E_SHAPE, "aid_prof_dump: cannot open %s", path);
     std::lock_guard<std::mutex> lk(g_prof.mu);
-    fprintf(f, "kernel_id,M,N,K,layout,ms\n");
+    fprintf(f, "kernel_id,M,N,K,layout,ms,variant\n");
     for (int k = 0; k < PROF_COUNT; ++k)
         for (auto& r : g_prof.recs[k]) {
             float t = 0.f;
             if (hipEventSynchronize(r.e1) != hipSuccess || hipEventElapsedTime(&t, r.e0, r.e1) != hipSuccess) t = -1.f;
-            fprintf(f, "%d,%d,%d,%d,%d,%.6f\n", r.id, r.m, r.n, r.k, r.layout, t);
+            fprintf(f, "%d,%d,%d,%d,%d,%.6f,%d\n", r.id, r.m, r.n, r.k, r.layout, t, r.variant);
         }
     fclose(f);
     return AID_OK;

@@ -105,6 +105,30 @@ def cpu_baseline(max_seconds=120.0):
             "sample": f"1 full cfg-2 train_step of the oracle (B=256,H=5,K=10,S=10,N=50,D=512), {dt:.1f} s, torch CPU fp32"}
 
 
+def kernel_name(variant, layout):
+    """The template instantiation a (variant, layout) pair of aid_prof_dump names, spelled as rocprofv3 prints it (minus `void aid::` and
+    the argument list)."""
+    b = lambda x: "true" if x else "false"
+    a, k = b((layout & 3) >> 1), b(layout & 1)
+    return {1: f"gemm_panel_kernel<{a}, {k}>", 2: f"gemm_ring_kernel<64, 64, 128, {a}, {k}>", 3: "gemm_smallk_kernel",
+            4: f"gemm_tile_kernel<64, 64, {a}, {k}, true>", 5: f"gemm_tile_kernel<64, 64, {a}, {k}, false>",
+            6: f"gemm_splitk_kernel<{a}, {k}, true>", 7: f"gemm_splitk_kernel<{a}, {k}, false>", 8: "gemm_thin_tn_kernel", 9: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 2>",
+            11: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 1>", 14: f"gemm_panel128_kernel<{a}, {k}, 128>",
+            15: f"gemm_panel128_kernel<{a}, {k}, 64>"}.get(variant, f"variant{variant}<{a}, {k}>")
+
+
+def per_kernel_table(path):
+    """Group the per-launch HIP-event timings of the profiled step by kernel instantiation: name -> launches, ms, flop."""
+    import csv
+    agg = {}
+    for r in csv.DictReader(open(path)):
+        if int(r["kernel_id"]) not in (0, 3) or float(r["ms"]) < 0:
+            continue
+        e = agg.setdefault(kernel_name(int(r["variant"]), int(r["layout"])), {"launches": 0, "ms": 0.0, "flops": 0.0})
+        e["launches"] += 1; e["ms"] += float(r["ms"]); e["flops"] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"])
+    return agg
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -166,8 +190,12 @@ def main():
     nat.prof_enable(True); nat.prof_reset()
     agent.train_step(); torch.cuda.synchronize()
     gt = nat.prof_read(nat.PROF_GEMM_TILE); gs = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
-    if args.dump_launches:
-        nat.prof_dump(args.dump_launches)
+    import tempfile
+    dump = args.dump_launches or os.path.join(tempfile.gettempdir(), f"aid_launches_{os.getpid()}.csv")
+    nat.prof_dump(dump)
+    per_kernel = per_kernel_table(dump)
+    if not args.dump_launches:
+        os.remove(dump)
     nat.prof_enable(False); nat.prof_reset()
     agent.overlap_streams = not args.no_overlap
     if rank != 0:
@@ -185,17 +213,20 @@ def main():
             if k.startswith(prefix) and "fetch_bytes_per_launch_corrected" in v:
                 return v["fetch_bytes_per_launch_corrected"] + v.get("write_bytes_per_launch", 0.0)
         return None
-    # The kernel with the largest share of GPU time (profiles/r01_train_step_kernel_stats.csv) is the small-problem GEMM kernel of the
-    # reverse-diffusion loops (gemm_panel_kernel + its split-K / ring siblings: every GEMM launch with < 160 64x64 tiles).
-    small = {"bound": "mfma", "kernel": "aid::gemm_panel_kernel family (fp32 MFMA, batch-256/512 layers of the reverse loops, ELBO and BPTT)",
-             "achieved": tf(gs), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tf(gs) * 1e12 / PEAK_F32_MFMA,
-             "traffic": traffic("gemm_panel_kernel<false, false>"), "launches_per_step": gs["launches"], "ms_per_step": gs["ms"],
-             "flop_per_launch": gs["flops"] / max(gs["launches"], 1), "us_per_launch": 1e3 * gs["ms"] / max(gs["launches"], 1),
-             "note": "per-CU ingest/latency-bound at M<=512 (DESIGN.md section 4); achieved = sum(2MNK)/sum(HIP-event durations) of these launches"}
-    big = {"bound": "mfma", "kernel": "aid::gemm_big_kernel / gemm_tile_kernel (fp32 MFMA, >= 160 tiles: MINE, hoisted conditioning, rollout)",
-           "achieved": tf(gt), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": tf(gt) * 1e12 / PEAK_F32_MFMA,
-           "traffic": traffic("gemm_big_kernel"), "launches_per_step": gt["launches"], "ms_per_step": gt["ms"],
-           "flop_per_launch": gt["flops"] / max(gt["launches"], 1), "us_per_launch": 1e3 * gt["ms"] / max(gt["launches"], 1)}
+    # One entry per kernel instantiation (= one row of the rocprofv3 --stats summary), ordered by its share of the profiled step.
+    def entry(name, d):
+        e = {"bound": "mfma", "kernel": "aid::" + name, "achieved": tf(d), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
+             "frac": tf(d) * 1e12 / PEAK_F32_MFMA, "traffic": traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name),
+             "launches_per_step": d["launches"], "ms_per_step": d["ms"], "flop_per_launch": d["flops"] / max(d["launches"], 1),
+             "us_per_launch": 1e3 * d["ms"] / max(d["launches"], 1)}
+        if name == "gemm_smallk_kernel":     # K <= 32: a VALU kernel bound by writing its output
+            e["bound"] = "hbm"; e["note"] = "VALU kernel (K <= 32), output-write bound; listed for completeness, no MFMA"
+        return e
+    ranked = sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])
+    mfma_ranked = [kv for kv in ranked if kv[0] != "gemm_smallk_kernel"]
+    dominant = entry(*mfma_ranked[0]); second = entry(*mfma_ranked[1]) if len(mfma_ranked) > 1 else None
+    dominant["note"] = ("the kernel instantiation with the largest share of GPU time; achieved = sum(2MNK) / sum(HIP-event durations) of its launches in "
+                        "one single-stream train_step (compare us_per_launch with AverageNs of the same name in profiles/*_kernel_stats_no_overlap.csv)")
     out = {
         "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
@@ -207,8 +238,14 @@ def main():
         "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
         "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * steps_per_s / 1e12,
         "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
-        "roofline": small if gs["ms"] >= gt["ms"] else big,
-        "roofline_second_kernel": big if gs["ms"] >= gt["ms"] else small,
+        "roofline": dominant,
+        "roofline_second_kernel": second,
+        "roofline_kernels": [entry(n, d) for n, d in ranked[:8]],
+        "roofline_big_family": {"kernel": "GEMM launches with >= 160 64x64 tiles (MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
+                                "frac": tf(gt) * 1e12 / PEAK_F32_MFMA, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"]},
+        "roofline_small_family": {"kernel": "GEMM launches with < 160 64x64 tiles (batch-256..768 layers of the reverse loops, ELBO, BPTT); per-CU "
+                                            "ingest / latency-bound (DESIGN.md section 5)", "achieved": tf(gs), "frac": tf(gs) * 1e12 / PEAK_F32_MFMA,
+                                  "launches_per_step": gs["launches"], "ms_per_step": gs["ms"]},
         "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step", "achieved": tf(g), "frac": tf(g) * 1e12 / PEAK_F32_MFMA,
                                  "launches_per_step": g["launches"], "ms_per_step": g["ms"], "flop_per_step": g["flops"]},
         "roofline_hbm": {"bound": "hbm", "kernel": "aid::adamw_kernel (clip + AdamW + EMA over the score arena)",

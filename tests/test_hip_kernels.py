@@ -219,6 +219,28 @@ def test_gemm_every_kernel_variant(nat, code, layout):
     assert np.max(np.abs(out.cpu().numpy() - ref) / scale) < 2e-6
 
 
+@pytest.mark.parametrize("M,N,K,acc", [(6, 256, 2560, 1), (512, 17, 2560, 1), (17, 23, 1001, 0), (3, 1, 513, 1)])
+def test_gemm_thin_weight_gradient(nat, M, N, K, acc):
+    """dW[M,N] (+)= dY^T X over K rows with a 6- / 17-wide side: the automatic dispatcher's thin TN kernel (16 waves split K inside one
+    workgroup, ordered fold) and the same kernel forced (code 8); ragged M, N and K; fp64 reference; two launches are bit-identical."""
+    rng = np.random.default_rng(M * 7 + N)
+    A = rng.standard_normal((K, M)).astype(np.float32); Bm = rng.standard_normal((K, N)).astype(np.float32)
+    C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64).T @ Bm.astype(np.float64) + (C0 if acc else 0.0)
+    scale = np.abs(A).astype(np.float64).T @ np.abs(Bm).astype(np.float64) + 1.0
+    outs = []
+    for code in (0, 8, 8):
+        out = dev(C0.copy())
+        nat.gemm_force_kernel(code)
+        try:
+            nat.gemm(dev(A), dev(Bm), out, M, N, K, M, N, N, 1, 1, accumulate=acc)
+        finally:
+            nat.gemm_force_kernel(0)
+        outs.append(out.cpu().numpy())
+        assert np.max(np.abs(outs[-1] - ref) / scale) < 2e-6, code
+    assert np.array_equal(outs[1], outs[2])
+
+
 def test_replay_buffer_uint8_frames(nat):
     """optimize_memory=True + uint8 frames: the ring arrays stay bytes in HBM; sample() returns the same float values a float32 store
     would (the reference's arrays hold float32(frame)); bit-exact."""

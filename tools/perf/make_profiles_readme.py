@@ -19,6 +19,7 @@ w("Regenerate this file with `python tools/perf/make_profiles_readme.py`; collec
 w("| file | what |\n|---|---|\n"
   "| `r01_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags) |\n"
   "| `r01_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` |\n"
+  "| `r01_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (side stream off): the per-kernel averages that bench.py's single-stream live measurement is comparable with |\n"
   "| `r01_pmc_summary.json` | per-kernel averages of the PMC passes over ONE train_step (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) |\n"
   "| `gemm_big_r01.txt`, `gemm_shapes_r01.txt` | microbenchmarks of the GEMM kernel variants per shape (`tools/perf/big_gemm.py`, `gemm_shapes.py`); the dispatcher in `csrc/gemm_f32.hip` is set from them and from the in-situ chain `tools/perf/cold_chain.py` |\n"
   "| `r01_other_configs.jsonl` | cfg 3 (Hopper, B=1024) and cfg 4 (pixels, B=256) train_step timings (`tools/perf/other_configs.py`) |\n")
@@ -27,9 +28,12 @@ w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/ste
   f"= {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
 for key in ("roofline", "roofline_second_kernel"):
     r = bench[key]
-    w(f"* `{key}`: {r['kernel']} — {r['achieved']:.1f} TFLOP/s = **{100*r['frac']:.1f} %** of peak over {r['launches_per_step']} launches "
+    w(f"* `{key}`: `{r['kernel']}` — {r['achieved']:.1f} TFLOP/s = **{100*r['frac']:.1f} %** of peak over {r['launches_per_step']} launches "
       f"({r['ms_per_step']:.1f} ms of the profiled step, {r['us_per_launch']:.1f} µs and {r['flop_per_launch']/1e9:.2f} GFLOP per launch"
       + (f", PMC traffic {r['traffic']/1e6:.1f} MB per launch" if r.get("traffic") else "") + ").")
+for key in ("roofline_big_family", "roofline_small_family"):
+    r = bench[key]
+    w(f"* `{key}`: {r['kernel']} — {r['achieved']:.1f} TFLOP/s = {100*r['frac']:.1f} % over {r['launches_per_step']} launches, {r['ms_per_step']:.1f} ms.")
 f = bench["roofline_gemm_family"]; h = bench["roofline_hbm"]
 w(f"* every GEMM launch: {f['achieved']:.1f} TFLOP/s = {100*f['frac']:.1f} % ({f['launches_per_step']} launches, {f['flop_per_step']/1e12:.2f} TFLOP per step).")
 w(f"* HBM-bound kernel (`adamw_kernel`, 1.09 GB of algorithmic traffic per launch over the 27.15 M-parameter score arena): {h['achieved']:.0f} GB/s = {100*h['frac']:.0f} % of the 8 TB/s peak "
@@ -38,6 +42,18 @@ if "cpu_baseline" in bench:
     c = bench["cpu_baseline"]
     w(f"* CPU baseline (oracle port, {c['cores']} host cores): {c['value']:.3f} steps/s ({c['sample']}) → GPU/CPU = {bench['speedup_vs_cpu_baseline']:.0f}×.")
 w("")
+noov = os.path.join(P, "r01_train_step_kernel_stats_no_overlap.csv")
+if os.path.exists(noov):
+    nrows = {r["Name"]: r for r in csv.DictReader(open(noov))}
+    w("## Live HIP-event measurement (bench.py, one single-stream step) vs rocprofv3 (`bench.py --no-overlap`, whole process)\n")
+    w("| kernel instantiation | launches/step | bench µs/launch | bench TFLOP/s | rocprofv3 avg µs | rocprofv3 calls |\n|---|---|---|---|---|---|")
+    for r in bench.get("roofline_kernels", []):
+        short = r["kernel"].replace("aid::", "")
+        m = [v for k, v in nrows.items() if ("aid::" + short + "(") in k or ("aid::" + short.rsplit(",", 1)[0]) in k]
+        ra = f"{float(m[0]['AverageNs'])/1e3:.1f}" if m else "—"; rc = m[0]["Calls"] if m else "—"
+        w(f"| `{short}` | {r['launches_per_step']} | {r['us_per_launch']:.1f} | {r['achieved']:.1f} | {ra} | {rc} |")
+    w("\nThe rocprofv3 column averages over every call of the process (warm-up, timed steps, the denoise-only loop, the profiled step), so the shape\n"
+      "mix differs slightly from one train_step; the two columns agree to within that mix.\n")
 w(f"## Kernel time under rocprofv3 (sum of kernel durations {tot/1e6:.0f} ms over the whole bench process; two streams overlap, so the sum exceeds wall time)\n")
 w("| kernel | calls | avg µs | total ms | % |\n|---|---|---|---|---|")
 for r in rows[:16]:

@@ -8,6 +8,9 @@ OUT=gpurun_out/prof_r01; rm -rf $OUT; mkdir -p $OUT
 B="tools/perf/pmc_probe2.py step_noov"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/stats.log 2>&1
 echo stats done
+# the same command with the side stream off: per-kernel averages comparable with bench.py's single-stream live measurement (roofline.us_per_launch)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_noov -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-overlap > $OUT/stats_noov.log 2>&1
+echo stats_noov done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $B > $OUT/fetch.log 2>&1
 echo fetch done
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $B > $OUT/write.log 2>&1

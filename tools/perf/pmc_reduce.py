@@ -40,3 +40,6 @@ for k, s in summary.items():
 st = glob.glob(os.path.join(out, "stats", "**", "*kernel_stats.csv"), recursive=True)
 if st:
     os.system(f"cp {st[0]} {out}/kernel_stats.csv")
+st = glob.glob(os.path.join(out, "stats_noov", "**", "*kernel_stats.csv"), recursive=True)
+if st:
+    os.system(f"cp {st[0]} {out}/kernel_stats_no_overlap.csv")

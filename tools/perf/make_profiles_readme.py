@@ -49,7 +49,7 @@ if os.path.exists(noov):
     w("| kernel instantiation | launches/step | bench µs/launch | bench TFLOP/s | rocprofv3 avg µs | rocprofv3 calls |\n|---|---|---|---|---|---|")
     for r in bench.get("roofline_kernels", []):
         short = r["kernel"].replace("aid::", "")
-        m = [v for k, v in nrows.items() if ("aid::" + short + "(") in k or ("aid::" + short.rsplit(",", 1)[0]) in k]
+        m = [v for k, v in nrows.items() if ("aid::" + short + "(") in k]
         ra = f"{float(m[0]['AverageNs'])/1e3:.1f}" if m else "—"; rc = m[0]["Calls"] if m else "—"
         w(f"| `{short}` | {r['launches_per_step']} | {r['us_per_launch']:.1f} | {r['achieved']:.1f} | {ra} | {rc} |")
     w("\nThe rocprofv3 column averages over every call of the process (warm-up, timed steps, the denoise-only loop, the profiled step), so the shape\n"

@@ -537,6 +537,34 @@ def replay_gather(obs, next_obs, actions, rewards, dones, idx):
     return o, n, a, r, d
 
 
+def sym_eig(A):
+    """Symmetric eigen-decomposition in fp64 on the device (parallel cyclic Jacobi): A [n,n] -> (w [n] unsorted, V [n,n] columns)."""
+    assert A.is_cuda and A.dtype == torch.float64 and A.dim() == 2 and A.shape[0] == A.shape[1]
+    n = A.shape[0]
+    work = A.contiguous().clone()
+    w = torch.empty(n, device=A.device, dtype=torch.float64); V = torch.empty(n, n, device=A.device, dtype=torch.float64)
+    check(lib().aid_sym_eig_f64(C.c_void_p(work.data_ptr()), C.c_void_p(w.data_ptr()), C.c_void_p(V.data_ptr()), n, _stream()), "aid_sym_eig_f64")
+    return w, V
+
+
+def fokker_planck_full_step(mean, lam, V, obs=None, score=None, xi=None, dt=0.01, D=0.1, lr=0.1, noise_scale=0.01, min_var=1e-6, advance=True):
+    """Full-covariance belief step on (mean [n,L], lam [n,L], V [n,L,L]) in place; returns (cov [n,L,L], precision [n,L,L], entropy [n],
+    condition number [n])."""
+    ts = (mean, lam, V) + ((obs, score, xi) if advance else ())
+    for t in ts:
+        assert t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()
+    n, L = mean.shape
+    assert lam.shape == (n, L) and V.shape == (n, L, L)
+    cov = torch.empty(n, L, L, device=mean.device, dtype=torch.float64); prec = torch.empty_like(cov)
+    ent = torch.empty(n, device=mean.device, dtype=torch.float64); cond = torch.empty_like(ent)
+    vp = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    check(lib().aid_fokker_planck_full_step(vp(mean), vp(lam), vp(V), vp(obs if advance else None), vp(score if advance else None),
+                                            vp(xi if advance else None), n, L, C.c_double(dt), C.c_double(D), C.c_double(lr), C.c_double(noise_scale),
+                                            C.c_double(min_var), int(bool(advance)), vp(cov), vp(prec), vp(ent), vp(cond), _stream()),
+          "aid_fokker_planck_full_step")
+    return cov, prec, ent, cond
+
+
 def fokker_planck_step(mean, var, obs, score, xi, dt=0.01, D=0.1, lr=0.1, noise_scale=0.01, min_var=1e-6, max_var=10.0, want_entropy=True):
     """In-place fp64 diagonal belief step over [n, L] tensors; returns entropy [n] (or None)."""
     for t in (mean, var, obs, score, xi):

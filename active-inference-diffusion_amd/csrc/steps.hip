@@ -129,6 +129,128 @@ __global__ void fokker_planck_kernel(double* __restrict__ mean, double* __restri
     if (ent) ent[b] = e;
 }
 
+// ---- full-covariance Fokker-Planck (belief_dynamics.py:141-152, 268-342) --------------------------------------------------------------
+// With the Gaussian observation model the Hessian is h I, so E = expm((-H - H^T + 2 D I) dt) = e^{(-2h+2D) dt} I and every later operation
+// (eigen-clamp, condition-number regularisation, (cov + eps I)^-1, logdet) is a spectral function of the covariance: its eigenvectors never
+// change.  The state is therefore kept as (lam, V) — one symmetric eigen-decomposition at reset (sym_eig_jacobi_kernel), then per step a
+// diagonal update of lam and the two rebuilds  cov = V diag(lam) V^T,  precision = V diag(1 / (lam + eps)) V^T.
+
+// Parallel cyclic Jacobi, fp64, one workgroup: A [n,n] symmetric (destroyed) -> eigenvalues w [n] (unsorted) and eigenvectors V (columns).
+// Each round rotates n/2 disjoint (p, q) pairs of a round-robin tournament: rows first (A <- J^T A), then columns (A <- A J, V <- V J).
+__global__ void __launch_bounds__(256) sym_eig_jacobi_kernel(double* __restrict__ A, double* __restrict__ w, double* __restrict__ V, int n) {
+    __shared__ double cs[128][2];
+    __shared__ int pq[128][2];
+    __shared__ double red[256];
+    __shared__ int done;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    for (int i = tid; i < n * n; i += NT) V[i] = (i / n == i % n) ? 1.0 : 0.0;
+    const int m = n + (n & 1), half = m / 2;
+    __syncthreads();
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0.0, dg = 0.0;
+        for (int i = tid; i < n * n; i += NT) { const double a = A[i]; if (i / n == i % n) dg += a * a; else off += a * a; }
+        red[tid] = off; __syncthreads();
+        for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        off = red[0]; __syncthreads();
+        red[tid] = dg; __syncthreads();
+        for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        dg = red[0];
+        if (tid == 0) done = !(off > 1e-30 * dg) || !(off == off);      // relative off-diagonal mass below 1e-15^2, or NaN input
+        __syncthreads();
+        if (done) break;
+        for (int round = 0; round < m - 1; ++round) {
+            if (tid < half) {
+                const int a = tid == 0 ? m - 1 : (round + tid) % (m - 1);
+                const int b = (round + m - 1 - tid) % (m - 1);
+                const int p = min(a, b), q = max(a, b);
+                double c = 1.0, sn = 0.0;
+                if (q < n) {
+                    const double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        const double tau = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                        const double t = (tau >= 0.0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                        c = 1.0 / sqrt(1.0 + t * t); sn = t * c;
+                    }
+                }
+                cs[tid][0] = c; cs[tid][1] = sn; pq[tid][0] = p; pq[tid][1] = q;
+            }
+            __syncthreads();
+            for (int e = tid; e < half * n; e += NT) {            // rows p, q of A
+                const int k = e / n, j = e % n, p = pq[k][0], q = pq[k][1];
+                if (q < n) {
+                    const double c = cs[k][0], sn = cs[k][1], x = A[p * n + j], y = A[q * n + j];
+                    A[p * n + j] = c * x - sn * y; A[q * n + j] = sn * x + c * y;
+                }
+            }
+            __syncthreads();
+            for (int e = tid; e < half * n; e += NT) {            // columns p, q of A and of V
+                const int k = e / n, i = e % n, p = pq[k][0], q = pq[k][1];
+                if (q < n) {
+                    const double c = cs[k][0], sn = cs[k][1];
+                    double x = A[i * n + p], y = A[i * n + q];
+                    A[i * n + p] = c * x - sn * y; A[i * n + q] = sn * x + c * y;
+                    x = V[i * n + p]; y = V[i * n + q];
+                    V[i * n + p] = c * x - sn * y; V[i * n + q] = sn * x + c * y;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < n; i += NT) w[i] = A[i * n + i];
+}
+
+// One workgroup per belief.  advance = 1: mean step (as the diagonal kernel) and lam *= e^{2 (-2h+2D) dt};  advance = 0: only the
+// stabilisation of `reset(initial_cov=...)`.  Then clamp / regularise lam (:296-332) and rebuild cov, precision (:334-342), entropy (:368-383).
+__global__ void __launch_bounds__(256) fokker_planck_full_kernel(double* __restrict__ mean, double* __restrict__ lam, const double* __restrict__ V,
+                                                                 const double* __restrict__ obs, const double* __restrict__ score,
+                                                                 const double* __restrict__ xi, int L, double dt, double D, double lr, double ns,
+                                                                 double min_eig, int advance, double* __restrict__ cov, double* __restrict__ prec,
+                                                                 double* __restrict__ ent, double* __restrict__ cond_out) {
+    __shared__ double red[256];
+    __shared__ double sl[128], sinv[128];
+    const int b = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    mean += (size_t)b * L; lam += (size_t)b * L; V += (size_t)b * L * L; cov += (size_t)b * L * L; prec += (size_t)b * L * L;
+    const double ns2 = ns * ns;
+    if (advance) {
+        obs += (size_t)b * L; score += (size_t)b * L; xi += (size_t)b * L;
+        double g = 0.0;
+        if (tid < L) { const double m = mean[tid]; g = -(m - obs[tid]) / ns2 - m + score[tid]; }
+        red[tid] = g * g; __syncthreads();
+        for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+        const double adt = dt / (1.0 + 0.1 * sqrt(red[0]));
+        __syncthreads();
+        if (tid < L) mean[tid] = mean[tid] + (-lr * g) * adt + sqrt(2.0 * D * dt) * ns * xi[tid];
+    }
+    const double h = -(1.0 / ns2 + 1.0);
+    const double fac = advance ? exp(2.0 * (-2.0 * h + 2.0 * D) * dt) : 1.0;
+    double l = tid < L ? fmax(lam[tid] * fac, min_eig) : 0.0;
+    // max, min, mean of the clamped eigenvalues
+    red[tid] = tid < L ? l : -1.0; __syncthreads();
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] = fmax(red[tid], red[tid + st]); __syncthreads(); }
+    const double lmax = red[0]; __syncthreads();
+    red[tid] = tid < L ? l : 1.7976931348623157e308; __syncthreads();
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] = fmin(red[tid], red[tid + st]); __syncthreads(); }
+    const double lmin = red[0]; __syncthreads();
+    red[tid] = l; __syncthreads();
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    const double lmean = red[0] / L; __syncthreads();
+    const double cond = lmax / lmin;
+    if (cond > 1e6) l += lmean * 1e-6;
+    if (tid < L) { lam[tid] = l; sl[tid] = l; sinv[tid] = 1.0 / (l + min_eig); }
+    red[tid] = tid < L ? log(l) : 0.0; __syncthreads();
+    for (int st = NT / 2; st > 0; st >>= 1) { if (tid < st) red[tid] += red[tid + st]; __syncthreads(); }
+    if (tid == 0) {
+        if (ent) ent[b] = 0.5 * (L * log(2.0 * 3.14159265358979323846 * 2.718281828459045) + red[0]);
+        if (cond_out) cond_out[b] = cond;
+    }
+    for (int e = tid; e < L * L; e += NT) {
+        const int i = e / L, j = e % L;
+        double c = 0.0, p = 0.0;
+        for (int k = 0; k < L; ++k) { const double vv = V[i * L + k] * V[j * L + k]; c += vv * sl[k]; p += vv * sinv[k]; }
+        cov[e] = c; prec[e] = p;
+    }
+}
+
 // p_sample with a given score (diffusion.py:208-255): z0 = (z + c0 s) c1 ; mean = c2 z0 + c3 z ; + c4 eps for t > 0
 __global__ void p_sample_kernel(const float* __restrict__ z, const float* __restrict__ score, const float* __restrict__ eps,
                                 const float* __restrict__ coef, int step, float* __restrict__ out, int n) {
@@ -329,6 +451,24 @@ int aid_fokker_planck_step(double* mean, double* var, const double* obs, const d
     AID_REQUIRE(n > 0 && L > 0, AID_E_SHAPE, "aid_fokker_planck_step: n=%d L=%d", n, L);
     hipLaunchKernelGGL(fokker_planck_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, mean, var, obs, score, xi, n, L, dt, D, lr,
                        noise_scale, min_var, max_var, entropy_out);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_sym_eig_f64(double* A, double* w, double* V, int n, void* stream) {
+    AID_REQUIRE(A && w && V, AID_E_NULL, "aid_sym_eig_f64: null tensor");
+    AID_REQUIRE(n >= 1 && n <= 256, AID_E_SHAPE, "aid_sym_eig_f64: n=%d (1..256)", n);
+    hipLaunchKernelGGL(sym_eig_jacobi_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, A, w, V, n);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_fokker_planck_full_step(double* mean, double* lam, const double* V, const double* obs, const double* score, const double* xi, int n, int L,
+                                double dt, double D, double lr, double noise_scale, double min_var, int advance, double* cov_out,
+                                double* prec_out, double* entropy_out, double* cond_out, void* stream) {
+    AID_REQUIRE(mean && lam && V && cov_out && prec_out, AID_E_NULL, "aid_fokker_planck_full_step: null tensor");
+    AID_REQUIRE(!advance || (obs && score && xi), AID_E_NULL, "aid_fokker_planck_full_step: advance needs obs, score, xi");
+    AID_REQUIRE(n > 0 && L > 0 && L <= 128, AID_E_SHAPE, "aid_fokker_planck_full_step: n=%d L=%d (L <= 128)", n, L);
+    hipLaunchKernelGGL(fokker_planck_full_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, mean, lam, V, obs, score, xi, L, dt, D, lr, noise_scale,
+                       fmax(min_var, 1e-8), advance, cov_out, prec_out, entropy_out, cond_out);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 

@@ -415,6 +415,20 @@ int aid_fokker_planck_step(double* mean, double* var, const double* obs, const d
                            double dt, double D, double lr, double noise_scale, double min_var, double max_var,
                            double* entropy_out, void* stream);
 
+/* ---- A14, full covariance (aid/core/belief_dynamics.py:141-152, 268-342, 368-383) ---------------------
+ * With the Gaussian observation model the Hessian is a multiple of I, so the matrix exponential is a scalar and the eigen-clamp,
+ * condition-number regularisation, (cov + eps I)^-1 and logdet are spectral functions of the covariance: the belief is carried as
+ * eigenvalues lam [n,L] + eigenvectors V [n,L,L] (columns), decomposed once at reset.
+ * aid_sym_eig_f64: symmetric eigen-decomposition (parallel cyclic Jacobi, fp64, one workgroup): A [n,n] is destroyed, w [n] unsorted,
+ *   V [n,n] eigenvectors in columns (replaces torch.linalg.eigh of `_ensure_numerical_stability` :303).
+ * aid_fokker_planck_full_step: advance=1: mean step as the diagonal entry point, lam *= exp(2 (-2h + 2D) dt) (`_matrix_exponential_update`);
+ *   advance=0: the stabilisation of reset(initial_cov) only.  Then lam = max(lam, eps), + mean(lam) 1e-6 if max/min > 1e6, and
+ *   cov_out = V diag(lam) V^T, prec_out = V diag(1/(lam+eps)) V^T  [n,L,L]; entropy_out / cond_out [n] optional.  L <= 128. */
+int aid_sym_eig_f64(double* A, double* w, double* V, int n, void* stream);
+int aid_fokker_planck_full_step(double* mean, double* lam, const double* V, const double* obs, const double* score, const double* xi, int n, int L,
+                                double dt, double D, double lr, double noise_scale, double min_var, int advance, double* cov_out,
+                                double* prec_out, double* entropy_out, double* cond_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

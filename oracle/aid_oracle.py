@@ -722,6 +722,51 @@ def fokker_planck_step(mean: np.ndarray, var: np.ndarray, obs: np.ndarray, score
     return new_mean, new_var
 
 
+def fp_matrix_exponential_update(cov: np.ndarray, H: np.ndarray, dt: float, D: float) -> np.ndarray:
+    """BeliefDynamics._matrix_exponential_update, belief_dynamics.py:268-294:  E = expm((-H - H^T + 2 D I) dt),  cov <- E cov E^T."""
+    from scipy.linalg import expm
+    n = H.shape[0]
+    E = expm((-H - H.T + 2 * D * np.eye(n)) * dt)
+    return E @ cov @ E.T
+
+
+def fp_ensure_numerical_stability(mat: np.ndarray, min_eig: float, max_cond: float = 1e6):
+    """BeliefDynamics._ensure_numerical_stability, belief_dynamics.py:296-332: eigh, clamp the eigenvalues from below, add
+    mean(eig) * 1e-6 to all of them when max/min exceeds 1e6, rebuild.  Returns (matrix, condition number before regularisation)."""
+    w, V = np.linalg.eigh(mat)
+    w = np.maximum(w, min_eig)
+    cond = w.max() / w.min()
+    if cond > max_cond:
+        w = w + w.mean() * 1e-6
+    return V @ np.diag(w) @ V.T, cond
+
+
+def fp_safe_inverse(mat: np.ndarray, min_eig: float) -> np.ndarray:
+    """BeliefDynamics._safe_inverse, belief_dynamics.py:334-342."""
+    return np.linalg.inv(mat + min_eig * np.eye(mat.shape[0]))
+
+
+def fokker_planck_full_step(mean, cov, obs, score, xi, dt=0.01, D=0.1, lr=0.1, noise_scale=0.01, min_var=1e-6):
+    """Full-covariance step in fp64 for ONE belief (belief_dynamics.py:110-152).  Like the diagonal step it is PARITY UNPINNED as a
+    whole (update() raises) and pinned at sub-function level: the mean update is the diagonal path's; the Hessian is the
+    analytic one of the log-density the gradient comes from, H = -(1/ns^2 + 1) I; `_matrix_exponential_update`,
+    `_ensure_numerical_stability`, `_safe_inverse` and `entropy` are restated above and checked against the reference's own functions
+    (tests/golden/fp_full.npz).  Returns (mean, covariance, precision, condition_number)."""
+    mean = np.asarray(mean, np.float64); cov = np.asarray(cov, np.float64)
+    L = mean.shape[-1]
+    new_mean, _ = fokker_planck_step(mean, np.ones(L), obs, score, xi, dt=dt, D=D, lr=lr, noise_scale=noise_scale)
+    H = -(1.0 / noise_scale ** 2 + 1.0) * np.eye(L)
+    min_eig = max(min_var, 1e-8)
+    new_cov, cond = fp_ensure_numerical_stability(fp_matrix_exponential_update(cov, H, dt, D), min_eig)
+    return new_mean, new_cov, fp_safe_inverse(new_cov, min_eig), cond
+
+
+def gaussian_entropy_full(cov: np.ndarray) -> float:
+    """BeliefDynamics.entropy (full covariance), belief_dynamics.py:368-383: 0.5 (k log 2 pi e + logdet cov)."""
+    sign, logdet = np.linalg.slogdet(np.asarray(cov, np.float64))
+    return 0.5 * (cov.shape[0] * np.log(2 * np.pi * np.e) + logdet)
+
+
 def gaussian_entropy_diag(var: np.ndarray) -> np.ndarray:
     """BeliefDynamics.entropy (diag), belief_dynamics.py:368-389."""
     var = np.asarray(var, np.float64)

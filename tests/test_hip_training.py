@@ -338,6 +338,67 @@ def test_fokker_planck_fp64(nat, golden_dir):
     np.testing.assert_allclose(md.cpu().numpy()[0], expect, rtol=1e-12)
 
 
+@pytest.mark.parametrize("n", [1, 2, 17, 33, 128])
+def test_sym_eig_jacobi_fp64(nat, n):
+    """On-device symmetric eigen-decomposition (parallel cyclic Jacobi, fp64) against numpy.linalg.eigh: eigenvalues to 1e-12 of the
+    spectral radius, A V = V diag(w) and V^T V = I to 1e-12; a wide spectrum (1e-8 .. 1e3) so small eigenvalues are resolved relatively."""
+    rng = np.random.default_rng(n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    wtrue = np.exp(rng.uniform(np.log(1e-8), np.log(1e3), n))
+    A = (Q * wtrue) @ Q.T; A = 0.5 * (A + A.T)
+    w, V = nat.sym_eig(torch.from_numpy(A).cuda())
+    w, V = w.cpu().numpy(), V.cpu().numpy()
+    np.testing.assert_allclose(np.sort(w), np.linalg.eigvalsh(A), rtol=0, atol=1e-12 * np.abs(wtrue).max())
+    assert np.max(np.abs(A @ V - V * w)) < 1e-12 * np.abs(wtrue).max()
+    assert np.max(np.abs(V.T @ V - np.eye(n))) < 1e-12
+
+
+def test_fokker_planck_full_covariance_reference_golden(nat, golden_dir):
+    """BeliefDynamics(use_full_covariance=True) on the HIP kernels against the reference's own sub-functions (tests/golden/fp_full.npz):
+    reset(initial_cov) stabilisation, then mean / covariance / precision / entropy / condition number of every step.  fp64; the tolerances
+    are those the oracle holds against the same vectors (the precision of an ill-conditioned matrix is the loosest: 1e-6)."""
+    import aid_amd
+    g = np.load(os.path.join(golden_dir, "fp_full.npz"))
+    for name in ("sane", "illcond", "default"):
+        L, steps = (int(x) for x in g[f"{name}_dims"])
+        dt, D, lr, ns, mv = (float(x) for x in g[f"{name}_cfg"])
+        cfg = aid_amd.BeliefDynamicsConfig(use_full_covariance=True, dt=dt, diffusion_coefficient=D, learning_rate=lr, noise_scale=ns, min_variance=mv)
+        bd = aid_amd.BeliefDynamics(L, cfg).cuda()
+        bd.reset(torch.from_numpy(g[f"{name}_mean_init"]), torch.from_numpy(g[f"{name}_cov_init"]))
+        ref = g[f"{name}_cov_reset"]
+        np.testing.assert_allclose(bd.covariance.cpu().numpy(), ref, rtol=1e-8, atol=1e-10 * np.abs(ref).max())
+        for t in range(steps):
+            m32, c32 = bd.update(torch.from_numpy(g[f"{name}_obs{t}"]), torch.from_numpy(g[f"{name}_score{t}"]), xi=torch.from_numpy(g[f"{name}_xi{t}"]))
+            cov, prec = g[f"{name}_cov{t}"], g[f"{name}_prec{t}"]
+            np.testing.assert_allclose(bd.mean.cpu().numpy()[0], g[f"{name}_mean{t}"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(bd.covariance.cpu().numpy(), cov, rtol=1e-8, atol=1e-10 * np.abs(cov).max())
+            np.testing.assert_allclose(bd.precision.cpu().numpy(), prec, rtol=1e-6, atol=1e-9 * np.abs(prec).max())
+            np.testing.assert_allclose(float(bd.entropy()), float(g[f"{name}_entropy{t}"]), rtol=1e-9)
+            np.testing.assert_allclose(float(bd._last_cond[0]), float(g[f"{name}_cond{t}"]), rtol=1e-6)
+            assert m32.dtype == torch.float32 and c32.shape == (L, L)
+
+
+def test_fokker_planck_full_covariance_batched_vs_oracle(nat):
+    """Three beliefs in one launch (L = 24), two steps, against the oracle's per-belief full-matrix restatement (scipy expm + numpy eigh)."""
+    import aid_amd
+    n, L = 3, 24
+    rng = np.random.default_rng(11)
+    cfg = aid_amd.BeliefDynamicsConfig(use_full_covariance=True, noise_scale=1.5, dt=0.02)
+    bd = aid_amd.BeliefDynamics(L, cfg, n_beliefs=n).cuda()
+    m0 = rng.standard_normal((n, L)); c0 = np.stack([(lambda Q: (Q * np.exp(rng.uniform(-9, 3, L))) @ Q.T)(np.linalg.qr(rng.standard_normal((L, L)))[0]) for _ in range(n)])
+    bd.reset(torch.from_numpy(m0), torch.from_numpy(c0))
+    mean = m0.copy(); cov = [orc.fp_ensure_numerical_stability(c0[b], 1e-6)[0] for b in range(n)]
+    for t in range(2):
+        obs, sc, xi = rng.standard_normal((n, L)), rng.standard_normal((n, L)), rng.standard_normal((n, L))
+        bd.update(torch.from_numpy(obs), torch.from_numpy(sc), xi=torch.from_numpy(xi))
+        for b in range(n):
+            mean[b], cov[b], prec, cond = orc.fokker_planck_full_step(mean[b], cov[b], obs[b], sc[b], xi[b], dt=0.02, noise_scale=1.5)
+            np.testing.assert_allclose(bd.mean.cpu().numpy()[b], mean[b], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(bd.covariance.cpu().numpy()[b], cov[b], rtol=1e-8, atol=1e-10 * np.abs(cov[b]).max())
+            np.testing.assert_allclose(bd.precision.cpu().numpy()[b], prec, rtol=1e-6, atol=1e-9 * np.abs(prec).max())
+            np.testing.assert_allclose(float(bd.entropy()[b]), orc.gaussian_entropy_full(cov[b]), rtol=1e-9)
+
+
 def test_train_epistemic_estimator_reference_golden(golden_dir):
     """DiffusionActiveInference.train_epistemic_estimator x3 against a run of the REFERENCE (tests/golden/mine_train.npz; the harness
     attached the optimiser base_agent.py:134-139 defines): steps 1-2 have a positive bound (live gradient through both MINE passes, the

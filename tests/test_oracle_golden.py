@@ -211,3 +211,24 @@ def test_train_epistemic_estimator_golden(golden_dir):
         cs = np.array([float(st.p[n].detach().double().sum()) for n in names])
         assert np.all(np.abs(cs - g[f"s{step}_checksum"]) <= 2e-6 * g[f"s{step}_abssum"] + 2e-6)
     assert float(g["s1_mi"]) > 0 and float(g["s3_mi"]) == 0.0     # both branches of the clamp are covered
+
+
+def test_fokker_planck_full_covariance_golden(golden_dir):
+    """Full-covariance belief step: the oracle's restatement against the reference's own sub-functions chained by the harness of
+    oracle/gen_golden_fp_full.py (three configurations: a well-conditioned one, one whose eigenvalues hit the clamp and the condition-number
+    regularisation, and the defaults with their exp(400) growth per step)."""
+    g = np.load(os.path.join(golden_dir, "fp_full.npz"))
+    for name in ("sane", "illcond", "default"):
+        L, steps = (int(x) for x in g[f"{name}_dims"])
+        dt, D, lr, ns, mv = (float(x) for x in g[f"{name}_cfg"])
+        cov, _ = orc.fp_ensure_numerical_stability(g[f"{name}_cov_init"], max(mv, 1e-8))
+        np.testing.assert_allclose(cov, g[f"{name}_cov_reset"], rtol=1e-9, atol=1e-12 * np.abs(cov).max())
+        mean = g[f"{name}_mean_init"]
+        for t in range(steps):
+            mean, cov, prec, cond = orc.fokker_planck_full_step(mean, cov, g[f"{name}_obs{t}"], g[f"{name}_score{t}"], g[f"{name}_xi{t}"],
+                                                               dt=dt, D=D, lr=lr, noise_scale=ns, min_var=mv)
+            np.testing.assert_allclose(mean, g[f"{name}_mean{t}"], rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(cov, g[f"{name}_cov{t}"], rtol=1e-8, atol=1e-10 * np.abs(cov).max())
+            np.testing.assert_allclose(prec, g[f"{name}_prec{t}"], rtol=1e-6, atol=1e-9 * np.abs(prec).max())
+            np.testing.assert_allclose(orc.gaussian_entropy_full(cov), float(g[f"{name}_entropy{t}"]), rtol=1e-9)
+            np.testing.assert_allclose(cond, float(g[f"{name}_cond{t}"]), rtol=1e-6)

@@ -192,7 +192,11 @@ constexpr int OPT_BLOCKS = 1024;
 __global__ void sumsq_partial_kernel(const float* __restrict__ g, size_t n, float* __restrict__ partial) {
     __shared__ float sh[16];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { const float v = g[i]; acc += v * v; }
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = ((((uintptr_t)g) & 15) == 0) ? n / 4 : 0;       // 16-B loads when the arena is aligned; fixed order either way
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    for (size_t i = tid; i < n4; i += nthr) { const f4 v = reinterpret_cast<const f4*>(g)[i]; acc += v[0] * v[0]; acc += v[1] * v[1]; acc += v[2] * v[2]; acc += v[3] * v[3]; }
+    for (size_t i = n4 * 4 + tid; i < n; i += nthr) { const float v = g[i]; acc += v * v; }
     const float s = blk_sum(acc, sh);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
@@ -208,23 +212,51 @@ __global__ void finalize_norm_kernel(const float* __restrict__ partial, int nb, 
         out[1] = clip > 0.f ? fminf(clip / (nrm + 1e-6f), 1.0f) : 1.0f;   // torch clip_grad_norm_
     }
 }
-// torch.optim.AdamW single-tensor update + EMAModel.update, one pass: 5 reads + 4 writes per parameter
+// torch.optim.AdamW single-tensor update + EMAModel.update, one pass: 5 reads + 4 writes per parameter (36 B).  16-B accesses; the moments,
+// the EMA copy and the gradient are touched once per step, so they go through non-temporal loads / stores and leave the Infinity Cache
+// to the parameters the next forward pass re-reads.
+__device__ __forceinline__ void adamw_one(float& pi, float gi, float& mi, float& vi, float* emai, float c, float lr, float wd, float b1, float b2,
+                                          float eps, float step_size, float sqrt_bc2, float ema_decay, int coupled_l2) {
+    gi *= c;
+    if (coupled_l2) gi += wd * pi;            // torch.optim.Adam(weight_decay=wd): L2 term folded into the gradient
+    else pi *= (1.f - lr * wd);                // torch.optim.AdamW: decoupled decay
+    mi = mi + (gi - mi) * (1.f - b1);
+    vi = vi * b2 + (1.f - b2) * gi * gi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    pi = pi - step_size * (mi / denom);
+    if (emai) *emai = ema_decay * *emai + (1.f - ema_decay) * pi;
+}
+typedef float opt_f4 __attribute__((ext_vector_type(4)));
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                              float* __restrict__ ema, size_t n, float lr, float wd, float b1, float b2, float eps, float bc1,
-                             float sqrt_bc2, const float* __restrict__ coef, float ema_decay, int coupled_l2) {
+                             float sqrt_bc2, const float* __restrict__ coef, float ema_decay, int coupled_l2, int vec) {
     const float c = coef[1];
     const float step_size = lr / bc1;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        float gi = g[i] * c;
-        float pi = p[i];
-        if (coupled_l2) gi += wd * pi;            // torch.optim.Adam(weight_decay=wd): L2 term folded into the gradient
-        else pi *= (1.f - lr * wd);                // torch.optim.AdamW: decoupled decay
-        const float mi = m[i] + (gi - m[i]) * (1.f - b1);
-        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
-        const float denom = sqrtf(vi) / sqrt_bc2 + eps;
-        pi = pi - step_size * (mi / denom);
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (size_t)gridDim.x * blockDim.x;
+    const size_t n4 = vec ? n / 4 : 0;
+    for (size_t i = tid; i < n4; i += nthr) {
+        opt_f4 pv = reinterpret_cast<opt_f4*>(p)[i];
+        const opt_f4 gv = __builtin_nontemporal_load(reinterpret_cast<const opt_f4*>(g) + i);
+        opt_f4 mv = __builtin_nontemporal_load(reinterpret_cast<const opt_f4*>(m) + i);
+        opt_f4 vv = __builtin_nontemporal_load(reinterpret_cast<const opt_f4*>(v) + i);
+        opt_f4 ev = {0.f, 0.f, 0.f, 0.f};
+        if (ema) ev = __builtin_nontemporal_load(reinterpret_cast<const opt_f4*>(ema) + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float pj = pv[j], mj = mv[j], vj = vv[j], ej = ev[j];
+            adamw_one(pj, gv[j], mj, vj, ema ? &ej : nullptr, c, lr, wd, b1, b2, eps, step_size, sqrt_bc2, ema_decay, coupled_l2);
+            pv[j] = pj; mv[j] = mj; vv[j] = vj; ev[j] = ej;
+        }
+        reinterpret_cast<opt_f4*>(p)[i] = pv;
+        __builtin_nontemporal_store(mv, reinterpret_cast<opt_f4*>(m) + i);
+        __builtin_nontemporal_store(vv, reinterpret_cast<opt_f4*>(v) + i);
+        if (ema) __builtin_nontemporal_store(ev, reinterpret_cast<opt_f4*>(ema) + i);
+    }
+    for (size_t i = n4 * 4 + tid; i < n; i += nthr) {
+        float pi = p[i], mi = m[i], vi = v[i], ei = ema ? ema[i] : 0.f;
+        adamw_one(pi, g[i], mi, vi, ema ? &ei : nullptr, c, lr, wd, b1, b2, eps, step_size, sqrt_bc2, ema_decay, coupled_l2);
         p[i] = pi; m[i] = mi; v[i] = vi;
-        if (ema) ema[i] = ema_decay * ema[i] + (1.f - ema_decay) * pi;
+        if (ema) ema[i] = ei;
     }
 }
 
@@ -277,9 +309,11 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, float* e
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, s, g, n, scratch + 8);
     hipLaunchKernelGGL(finalize_norm_kernel, dim3(1), dim3(1024), 0, s, scratch + 8, nb, clip_norm, scratch, ext_sumsq);
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    const int ub = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+    const int vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)ema) & 15) == 0) ? 1 : 0;
+    const size_t work = vec ? (n + 3) / 4 : n;
+    const int ub = (int)((work + 255) / 256 > 4096 ? 4096 : (work + 255) / 256);
     hipLaunchKernelGGL(adamw_kernel, dim3(ub), dim3(256), 0, s, p, g, m, v, ema, n, lr, weight_decay, beta1, beta2, eps, (float)bc1,
-                       (float)sqrt(bc2), scratch, ema_decay, coupled_l2);
+                       (float)sqrt(bc2), scratch, ema_decay, coupled_l2, vec);
     AID_LAUNCH_CHECK();
     return AID_OK;
 }

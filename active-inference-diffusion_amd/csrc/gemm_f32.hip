@@ -524,6 +524,69 @@ __global__ void __launch_bounds__(256) gemm_splitk_kernel(GemmArgs g, int tiles_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Skinny kernel (act() / collector batches, M <= 32 rows): y = x W^T is a weight-streaming problem — N*K*4 bytes of W against a few KB of
+// x — so every wave owns ONE output column: its W row sits in registers (KV float4 per lane, K <= 256 KV), the x rows come through L1 in
+// 8-row chunks, each lane keeps 8 partial dots and the wave folds them with a fixed xor butterfly.  N waves fill the chip where the MFMA
+// panel kernel has N/32 workgroups walking K serially (K = 2048: 14 us -> 3.5 us at M = 1).  VALU fp32 FMA, fixed summation order.
+// ------------------------------------------------------------------------------------------------
+template <int KV>
+__global__ void __launch_bounds__(256) gemm_skinny_kernel(GemmArgs g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n = blockIdx.x * 4 + wave;
+    if (n >= g.N) return;                       // no barrier below
+    f32x4 w[KV];
+    int koff[KV];
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+        const int k = (j * 64 + lane) * 4;
+        koff[j] = min(k, g.K - 4);              // clamped address, value zeroed below: the loads stay unconditional
+        w[j] = *reinterpret_cast<const f32x4*>(g.B + (size_t)n * g.ldb + koff[j]);
+        if (k >= g.K) w[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    constexpr int RB = KV >= 16 ? 1 : (16 / KV > 8 ? 8 : 16 / KV);      // rows whose x fragments are loaded together (<= 16 float4 in flight)
+    for (int m0 = 0; m0 < g.M; m0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int r0 = 0; r0 < 8; r0 += RB) {
+            f32x4 x[RB][KV];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const float* xr = g.A + (size_t)min(m0 + r0 + r, g.M - 1) * g.lda;
+#pragma unroll
+                for (int j = 0; j < KV; ++j) x[r][j] = *reinterpret_cast<const f32x4*>(xr + koff[j]);
+            }
+            __builtin_amdgcn_sched_barrier(0);           // all loads of the batch issued before the first FMA waits
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < KV; ++j) {
+                    a = fmaf(x[r][j][0], w[j][0], a); a = fmaf(x[r][j][1], w[j][1], a); a = fmaf(x[r][j][2], w[j][2], a); a = fmaf(x[r][j][3], w[j][3], a);
+                }
+                acc[r0 + r] = a;
+            }
+        }
+        // transpose-reduce: each butterfly stage halves the values a lane carries (4 + 2 + 1 + 3 = 10 cross-lane moves for 8 row sums);
+        // afterwards lane 8 c (c = 0..7) holds the sum of row  4*(c>>2) + 2*((c>>1)&1) + (c&1)  =  c
+        float a4[4], a2[2], a1;
+        const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const float recv = __shfl_xor(h32 ? acc[i] : acc[i + 4], 32, 64); a4[i] = (h32 ? acc[i + 4] : acc[i]) + recv; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const float recv = __shfl_xor(h16 ? a4[i] : a4[i + 2], 16, 64); a2[i] = (h16 ? a4[i + 2] : a4[i]) + recv; }
+        { const float recv = __shfl_xor(h8 ? a2[0] : a2[1], 8, 64); a1 = (h8 ? a2[1] : a2[0]) + recv; }
+        a1 += __shfl_xor(a1, 4, 64); a1 += __shfl_xor(a1, 2, 64); a1 += __shfl_xor(a1, 1, 64);
+        const int row = m0 + (lane >> 3);
+        if ((lane & 7) == 0 && row < g.M) epilogue_store(g, row, n, a1);
+    }
+}
+template <int KV>
+static int launch_skinny_kv(const GemmArgs& g, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_skinny_kernel<KV>), dim3((g.N + 3) / 4), dim3(256), 0, s, g);
+    return AID_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Thin weight-gradient kernel: C[M,N] (+)= A^T B with both operands k-major ([K][M], [K][N]), a handful of 32x32 output tiles and a long K
 // (dW of a 6- or 17-wide layer over 2 560 rows).  One 1024-thread workgroup per tile: each of the 16 waves contracts its own K/16 slice
 // straight from global memory (k-major operands are lane-contiguous along m / n, so a fragment is one coalesced dword load) and the
@@ -974,6 +1037,15 @@ static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     return AID_OK;
 }
 
+static int launch_skinny(const GemmArgs& g, hipStream_t s) {
+    t_variant = 10;
+    const int kv = (g.K + 255) / 256;
+    if (kv <= 1) return launch_skinny_kv<1>(g, s);
+    if (kv <= 2) return launch_skinny_kv<2>(g, s);
+    if (kv <= 4) return launch_skinny_kv<4>(g, s);
+    if (kv <= 8) return launch_skinny_kv<8>(g, s);
+    return launch_skinny_kv<16>(g, s);
+}
 static int launch_thin_tn(const GemmArgs& g, hipStream_t s) {
     t_variant = 8;
     const int tm = (g.M + 31) / 32, tn = (g.N + 31) / 32;
@@ -995,6 +1067,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
         case 4: return launch_tile<64, 64, AKM, BKM>(g, vec, s);
         case 6: return launch_splitk<AKM, BKM>(g, vec, s);
         case 8: if (AKM && BKM) return launch_thin_tn(g, s); break;
+        case 10: if (!AKM && !BKM && vec && g.K >= 4 && g.K <= 4096) return launch_skinny(g, s); break;
         case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
         case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM, 1>(g, s); break;
         case 14: if (p32_ok) return launch_panel128<AKM, BKM>(g, s); break;
@@ -1004,6 +1077,8 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     // Automatic selection, set by measurement on MI355X (profiles/gemm_*_r01.txt, tools/perf/cold_chain.py).
     // K <= 32 (first layer of every network, K = latent / observation dim): VALU kernel, output-write bound.
     if (!AKM && !BKM && g.K >= 1 && g.K <= 32) return launch_smallk(g, s);
+    // act() / collector batches: one wave per output column, W row in registers (weight-streaming, not MFMA-shaped)
+    if (!AKM && !BKM && vec && g.M <= 32 && g.K >= 64 && g.K <= 4096 && g.ksplit <= 1) return launch_skinny(g, s);
     if (vec && g.K >= 64) {
         // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): 64x64x32 tile at 4 workgroups/CU, branch-free loads, two
         // tiles of prefetch, XCD-grouped tile map (+3..20 % on these shapes); 160..2047 tiles: the same kernel, plain tile map.

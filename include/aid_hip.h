@@ -47,7 +47,7 @@ int aid_prof_reset(void);
 int aid_prof_read(int kernel_id, double out[4]);
 /* One CSV line per recorded launch (kernel_id,M,N,K,layout,milliseconds,variant): the in-situ per-shape timing the GEMM dispatcher is tuned
  * from.  layout = 2*a_kmajor + b_kmajor (+4 in slab split-K mode); variant = the aid_gemm_force_kernel code of the kernel that ran
- * (1 panel, 2 ring, 3 small-K, 4/5 tile (vector / scalar loads), 6/7 split-K (vector / scalar loads), 8 thin TN, 9/11 big, 14 panel128, 15 panel64): with the layout it
+ * (1 panel, 2 ring, 3 small-K, 4/5 tile (vector / scalar loads), 6/7 split-K (vector / scalar loads), 8 thin TN, 10 skinny (M <= 32), 9/11 big, 14 panel128, 15 panel64): with the layout it
  * names one template instantiation, i.e. one row of a rocprofv3 --stats summary. */
 int aid_prof_dump(const char* path);
 #define AID_PROF_GEMM 0        /* fp32-MFMA GEMM launches routed to the small-problem kernels (panel / split-K / ring) */

@@ -241,6 +241,29 @@ def test_gemm_thin_weight_gradient(nat, M, N, K, acc):
     assert np.array_equal(outs[1], outs[2])
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 512, 512), (8, 2048, 512), (32, 512, 2048), (5, 17, 64), (27, 130, 1000), (3, 6, 4096)])
+def test_gemm_skinny_rows(nat, M, N, K):
+    """act() / collector batches (M <= 32): the wave-per-column weight-streaming kernel the dispatcher picks, and the same kernel forced
+    (code 10), with bias + SiLU + residual; ragged M, N, K; fp64 reference; two launches bit-identical."""
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((M, K)).astype(np.float32); W = rng.standard_normal((N, K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32); res = rng.standard_normal((M, N)).astype(np.float32)
+    pre = A.astype(np.float64) @ W.astype(np.float64).T + bias
+    ref = pre / (1 + np.exp(-pre)) + res
+    scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1.0
+    outs = []
+    for code in (0, 10, 10):
+        out = torch.zeros(M, N, device="cuda")
+        nat.gemm_force_kernel(code)
+        try:
+            nat.gemm(dev(A), dev(W), out, M, N, K, K, K, N, bias=dev(bias), act="silu", residual=dev(res), ldr=N)
+        finally:
+            nat.gemm_force_kernel(0)
+        outs.append(out.cpu().numpy())
+        assert np.max(np.abs(outs[-1] - ref) / scale) < 2e-6, code
+    assert np.array_equal(outs[1], outs[2]) and np.array_equal(outs[0], outs[1])
+
+
 def test_replay_buffer_uint8_frames(nat):
     """optimize_memory=True + uint8 frames: the ring arrays stay bytes in HBM; sample() returns the same float values a float32 store
     would (the reference's arrays hold float32(frame)); bit-exact."""

@@ -432,9 +432,12 @@ def test_train_epistemic_estimator_reference_golden(golden_dir):
             for n in names:
                 ref = g[f"s1_grad/{n}"]; got = gv[n].reshape(-1)
                 got = (got if got.numel() <= 4096 else got[::97]).cpu().numpy() * coef
-                # mine_network.6.bias is -1 + mean(exp(t_marg)) / running_mean = 0 up to rounding on the first call: absolute floor
-                scale = max(float(np.abs(ref).max()), 1e-3 * gmax)
-                assert np.abs(got - ref).max() / scale < 3e-3, (n, np.abs(got - ref).max(), scale)
+                # bias gradients of the MINE network are sums that cancel (mine_network.6.bias is -1 + mean(exp(t_marg)) / running_mean
+                # = 0 up to rounding on the first call), and a pre-activation within rounding of 0 flips its ReLU gate for one row (one element
+                # of mine_network.0.bias moves by 5e-3 of the tensor's scale while the rest agree to 1e-5): 1e-2 of the tensor's own scale
+                # plus a norm-wise floor of 1e-5 of the largest gradient
+                tol = 1e-2 * float(np.abs(ref).max()) + 1e-5 * gmax
+                assert np.abs(got - ref).max() < tol, (n, np.abs(got - ref).max(), tol)
                 np.testing.assert_allclose(float(gv[n].double().abs().sum()) * coef, g[f"s1_gradsum/{n}"][1], rtol=2e-3, atol=1e-4 * gmax)
         sd = ai.state_dict()
         cs = np.array([float(sd[n].double().sum()) for n in names])
@@ -443,8 +446,9 @@ def test_train_epistemic_estimator_reference_golden(golden_dir):
         for n in names:
             t = sd[n].reshape(-1)
             # Adam's normalised update is +-lr (5e-6) per step wherever |g| >> eps and anything in between where the gradient is
-            # rounding noise (|g| ~ 1e-8): absolute tolerance = a fraction of the accumulated step size
-            np.testing.assert_allclose((t if t.numel() <= 4096 else t[::97]).cpu().numpy(), g[f"s{step}_param/{n}"], rtol=1e-4, atol=3e-6 * step, err_msg=f"step {step} {n}")
+            # rounding noise (|g| ~ 1e-8, e.g. a bias whose row contributions cancel): there the sign of g, hence the direction of the
+            # lr-sized step, is not determined in fp32 -> absolute tolerance 2 * lr (lr = 5e-6) per accumulated step
+            np.testing.assert_allclose((t if t.numel() <= 4096 else t[::97]).cpu().numpy(), g[f"s{step}_param/{n}"], rtol=1e-4, atol=1.1e-5 * step, err_msg=f"step {step} {n}")
     # nothing outside the estimator moved
     for n in ("observation_decoder.3.weight", "latent_dynamics.network.0.weight"):
         assert torch.equal(ai.state_dict()[n].cpu(), p[n])

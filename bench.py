@@ -124,8 +124,9 @@ def per_kernel_table(path):
     for r in csv.DictReader(open(path)):
         if int(r["kernel_id"]) not in (0, 3) or float(r["ms"]) < 0:
             continue
-        e = agg.setdefault(kernel_name(int(r["variant"]), int(r["layout"])), {"launches": 0, "ms": 0.0, "flops": 0.0})
-        e["launches"] += 1; e["ms"] += float(r["ms"]); e["flops"] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"])
+        e = agg.setdefault(kernel_name(int(r["variant"]), int(r["layout"])), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
+        e["launches"] += 1; e["ms"] += float(r["ms"]); e["flops"] += 2.0 * M * N * K; e["bytes"] += 4.0 * (M * K + N * K + M * N)
     return agg
 
 
@@ -218,6 +219,7 @@ def main():
         e = {"bound": "mfma", "kernel": "aid::" + name, "achieved": tf(d), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
              "frac": tf(d) * 1e12 / PEAK_F32_MFMA, "traffic": traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name),
              "launches_per_step": d["launches"], "ms_per_step": d["ms"], "flop_per_launch": d["flops"] / max(d["launches"], 1),
+             "algorithmic_bytes_per_launch": d["bytes"] / max(d["launches"], 1),
              "us_per_launch": 1e3 * d["ms"] / max(d["launches"], 1)}
         if name == "gemm_smallk_kernel":     # K <= 32: a VALU kernel bound by writing its output
             e["bound"] = "hbm"; e["note"] = "VALU kernel (K <= 32), output-write bound; listed for completeness, no MFMA"

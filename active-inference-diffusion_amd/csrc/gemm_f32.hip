@@ -1079,6 +1079,9 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     if (!AKM && !BKM && g.K >= 1 && g.K <= 32) return launch_smallk(g, s);
     // act() / collector batches: one wave per output column, W row in registers (weight-streaming, not MFMA-shaped)
     if (!AKM && !BKM && vec && g.M <= 32 && g.K >= 64 && g.K <= 4096 && g.ksplit <= 1) return launch_skinny(g, s);
+    // one column tile under many row tiles (N = 17 / 6 / 1 heads over 25 600 rows): an A-streaming problem; the 35 KB panel variant keeps
+    // 4 workgroups x 64-deep stages per CU in flight (18.9 vs 27.7 us on 25 600 x 17 x 512)
+    if (p32_ok && g.N <= 32 && t64 >= 160 && g.ksplit <= 1) return launch_panel128<AKM, BKM, 64>(g, s);
     if (vec && g.K >= 64) {
         // >= 2048 tiles (the 25 600-row MINE / hoisted-conditioning GEMMs): 64x64x32 tile at 4 workgroups/CU, branch-free loads, two
         // tiles of prefetch, XCD-grouped tile map (+3..20 % on these shapes); 160..2047 tiles: the same kernel, plain tile map.

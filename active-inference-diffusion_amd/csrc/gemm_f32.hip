@@ -1165,6 +1165,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     else if (g.a_kmajor && g.b_kmajor) r = dispatch<true, true>(g, vec, s);
     else r = dispatch<true, false>(g, vec, s);
     prof.variant = t_variant;
+    prof.id = (t_variant == 9 || t_variant == 11 || t_variant == 4 || t_variant == 5) ? PROF_GEMM_TILE : PROF_GEMM;   // family = the kernel that ran
     if (r != AID_OK) return r;
     AID_LAUNCH_CHECK();
     return AID_OK;

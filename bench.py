@@ -243,9 +243,9 @@ def main():
         "roofline": dominant,
         "roofline_second_kernel": second,
         "roofline_kernels": [entry(n, d) for n, d in ranked[:8]],
-        "roofline_big_family": {"kernel": "GEMM launches with >= 160 64x64 tiles (MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
+        "roofline_big_family": {"kernel": "GEMM launches that ran a 64x64-tile kernel (>= 160 tiles: MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
                                 "frac": tf(gt) * 1e12 / PEAK_F32_MFMA, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"]},
-        "roofline_small_family": {"kernel": "GEMM launches with < 160 64x64 tiles (batch-256..768 layers of the reverse loops, ELBO, BPTT); per-CU "
+        "roofline_small_family": {"kernel": "GEMM launches that ran a small-problem kernel (batch-256..768 layers of the reverse loops, ELBO, BPTT, thin heads); per-CU "
                                             "ingest / latency-bound (DESIGN.md section 5)", "achieved": tf(gs), "frac": tf(gs) * 1e12 / PEAK_F32_MFMA,
                                   "launches_per_step": gs["launches"], "ms_per_step": gs["ms"]},
         "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step", "achieved": tf(g), "frac": tf(g) * 1e12 / PEAK_F32_MFMA,

@@ -50,8 +50,8 @@ int aid_prof_read(int kernel_id, double out[4]);
  * (1 panel, 2 ring, 3 small-K, 4/5 tile (vector / scalar loads), 6/7 split-K (vector / scalar loads), 8 thin TN, 10 skinny (M <= 32), 9/11 big, 14 panel128, 15 panel64): with the layout it
  * names one template instantiation, i.e. one row of a rocprofv3 --stats summary. */
 int aid_prof_dump(const char* path);
-#define AID_PROF_GEMM 0        /* fp32-MFMA GEMM launches routed to the small-problem kernels (panel / split-K / ring) */
-#define AID_PROF_GEMM_TILE 3   /* fp32-MFMA GEMM launches routed to gemm_tile_kernel (the dominant kernel of a train_step) */
+#define AID_PROF_GEMM 0        /* GEMM launches that ran a small-problem kernel (panel / split-K / ring / skinny / thin / small-K) */
+#define AID_PROF_GEMM_TILE 3   /* GEMM launches that ran a 64x64-tile kernel (gemm_big_kernel, the dominant kernel of a train_step, or gemm_tile_kernel) */
 #define AID_PROF_ROWWISE 1
 #define AID_PROF_OPTIM 2
 

@@ -146,12 +146,20 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    # AID_BENCH_REHEARSAL=gloo: rehearse the multi-rank glue (rendezvous, sharded sampling, gradient / normaliser / time-importance
+    # collectives, barrier + max-over-ranks timing, rank-0 line) with several ranks sharing ONE GPU; the number it prints is not a result.
+    rehearsal = os.environ.get("AID_BENCH_REHEARSAL", "") == "gloo"
+    if rehearsal:
+        local %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
     from aid_amd import _native as nat
     agent = make_agent(device, seed=rank)
     if world > 1:
@@ -232,7 +240,7 @@ def main():
     out = {
         "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
         "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU over gloo; not a result)",
         "config": {"workload": "HalfCheetah-v4 state obs (O=17,A=6,L=17), batch=256/GPU, EFE horizon=5, K=10, S=10, 50 denoise steps, hidden=512 "
                                "(BASELINE configs[1]); full DiffusionStateAgent.train_step", "global_batch": BATCH * world,
                    "parallelism": f"dp{world}" if world > 1 else "single", "rng": "device Philox4x32-10"},

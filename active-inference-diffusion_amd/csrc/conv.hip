@@ -100,28 +100,49 @@ __global__ void spectral_norm_bwd_kernel(const float* __restrict__ dw_eff, const
 }
 
 // ---- im2col / col2im for 3x3, pad 1, stride s; x CNHW [Cin][B][Hi][Wi]; col [Kp][B*Ho*Wo], k = ci*9 + kh*3 + kw ------------------
+// grid (N/4/256, Kp): a block works on one row k of col (ci, kh, kw uniform), a thread on 4 consecutive columns -> one 16-B store; the
+// (b, ho, wo) decomposition is done once per thread in 32-bit arithmetic and advanced with carries.  Output-write bound (3.8 GB per
+// encoder forward at B = 256).
 __global__ void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int Cin, int B, int Hi, int Wi, int Ho, int Wo, int stride,
-                               int K, size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
-    const size_t N = (size_t)B * Ho * Wo;
-    const int k = i / N; const size_t n = i % N;
-    float v = 0.f;
+                               int K, int N) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int k = blockIdx.y;
+    const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n0 >= N) return;
+    f4 v = {0.f, 0.f, 0.f, 0.f};
     if (k < K) {
         const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
-        const int wo = n % Wo, ho = (n / Wo) % Ho, b = n / ((size_t)Wo * Ho);
-        const int hi = ho * stride + kh - 1, wi = wo * stride + kw - 1;
-        if (hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v = x[(((size_t)ci * B + b) * Hi + hi) * Wi + wi];
+        int wo = n0 % Wo, t = n0 / Wo;
+        int ho = t % Ho, b = t / Ho;
+        const float* xc = x + (size_t)ci * B * Hi * Wi;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int hi = ho * stride + kh - 1, wi = wo * stride + kw - 1;
+            if (n0 + j < N && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v[j] = xc[(b * Hi + hi) * Wi + wi];
+            if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++b; } }
+        }
     }
-    col[i] = v;
+    float* dst = col + (size_t)k * N + n0;
+    if ((N & 3) == 0) *reinterpret_cast<f4*>(dst) = v;
+    else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (n0 + j < N) dst[j] = v[j];
+    }
+}
+static int im2col3(const float* x, float* col, int Cin, int B, int Hi, int Ho, int stride, int K, int Kp, size_t N, hipStream_t s) {
+    AID_REQUIRE(N < ((size_t)1 << 31) && Kp <= 65535, AID_E_SHAPE, "im2col3: N=%zu Kp=%d", N, Kp);
+    if (N == 0) return AID_OK;
+    hipLaunchKernelGGL(im2col3_kernel, dim3((unsigned)((N + 1023) / 1024), Kp), dim3(256), 0, s, x, col, Cin, B, Hi, Hi, Ho, Ho, stride, K, (int)N);
+    AID_LAUNCH_CHECK(); return AID_OK;
 }
 // dx[ci][b][hi][wi] = sum_{kh,kw} dcol[(ci,kh,kw)][(b,ho,wo)] over valid (ho,wo) with ho*s+kh-1 = hi (gather form, no atomics)
-__global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int Cin, int B, int Hi, int Wi, int Ho, int Wo, int stride,
-                               size_t total) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= total) return;
+// grid (Hi*Wi/256, B, Cin): 32-bit index arithmetic inside one image plane
+__global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int stride) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= Hi * Wi) return;
+    const int hi = p / Wi, wi = p % Wi, b = blockIdx.y, ci = blockIdx.z;
     const size_t N = (size_t)B * Ho * Wo;
-    const int wi = i % Wi, hi = (i / Wi) % Hi, b = (i / ((size_t)Wi * Hi)) % B, ci = i / ((size_t)Wi * Hi * B);
+    const float* dc = dcol + (size_t)ci * 9 * N + (size_t)b * Ho * Wo;
     float s = 0.f;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
@@ -135,10 +156,10 @@ __global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict
             if (tw < 0 || tw % stride) continue;
             const int wo = tw / stride;
             if (wo >= Wo) continue;
-            s += dcol[(size_t)(ci * 9 + kh * 3 + kw) * N + ((size_t)b * Ho + ho) * Wo + wo];
+            s += dc[(size_t)(kh * 3 + kw) * N + ho * Wo + wo];
         }
     }
-    dx[i] = s;
+    dx[((size_t)ci * B + b) * Hi * Wi + p] = s;
 }
 
 // ---- GroupNorm + Mish + Dropout2d, one workgroup per (sample, group); x/y CNHW [C][B][HW] -----------------------------------------
@@ -475,7 +496,7 @@ struct ConvW { const float* w_eff; int cin, cout, Kp; };
 // out[Cout][R*H*W] = W_eff x im2col3(x)   (stride 1, pad 1);  col: scratch of Kp * R*H*W floats
 static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* col, float* out, hipStream_t s) {
     const size_t N = (size_t)R * H * H;
-    L1D(im2col3_kernel, (size_t)cw.Kp * N, s, x, col, cw.cin, R, H, H, H, H, 1, cw.cin * 9, (size_t)cw.Kp * N);
+    AID_TRY(im2col3(x, col, cw.cin, R, H, H, 1, cw.cin * 9, cw.Kp, N, s));
     GemmArgs ga = gemm_args(cw.w_eff, cw.Kp, col, (int)N, out, (int)N, cw.cout, (int)N, cw.Kp);
     ga.b_kmajor = 1;
     return gemm_f32(ga, s);
@@ -543,7 +564,7 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
         hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, s, e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], train,
                            train, sv.w_eff[i], sv.sn[i]);
         AID_LAUNCH_CHECK();
-        L1D(im2col3_kernel, (size_t)g.Kp[i] * N, s, cur, col, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], g.K[i], (size_t)g.Kp[i] * N);
+        AID_TRY(im2col3(cur, col, g.cin[i], B, g.hi[i], g.ho[i], g.stride[i], g.K[i], g.Kp[i], N, s));
         GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], col, (int)N, sv.conv_out[i], (int)N, g.cout[i], (int)N, g.Kp[i]);
         ga.b_kmajor = 1;
         AID_TRY(gemm_f32(ga, s));
@@ -642,11 +663,11 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
             GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], dconv, (int)N, col, (int)N, g.Kp[i], (int)N, g.cout[i]);
             ga.a_kmajor = 1; ga.b_kmajor = 1;
             AID_TRY(gemm_f32(ga, s));
-            const size_t nin = (size_t)g.cin[i] * B * g.hi[i] * g.hi[i];
-            float* dprev = dconv;   // reuse: dconv is dead after the two GEMMs; cin*hi*hi*B <= cout*ho*ho*B for layers 1..3
-            L1D(col2im3_kernel, nin, s, col, dprev, g.cin[i], B, g.hi[i], g.hi[i], g.ho[i], g.ho[i], g.stride[i], nin);
-            // keep dprev alive below the mark: copy into the persistent gradient buffer
-            AID_TRY(copy_f32(dprev, dact, nin, s));
+            // dact (gradient wrt act[i]) was consumed by the two GroupNorm kernels above: the gradient wrt act[i-1] goes straight into it
+            // (cin*hi*hi*B <= 256*HW*B for layers 1..3)
+            hipLaunchKernelGGL(col2im3_kernel, dim3((g.hi[i] * g.hi[i] + 255) / 256, B, g.cin[i]), dim3(256), 0, s, col, dact, B, g.hi[i], g.hi[i], g.ho[i],
+                               g.ho[i], g.stride[i]);
+            AID_LAUNCH_CHECK();
             dcur = dact;
         }
         ws.release(mark);

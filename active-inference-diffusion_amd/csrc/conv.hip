@@ -223,6 +223,120 @@ __global__ void gn_param_grad_kernel(const float* __restrict__ e, const float* _
     if (threadIdx.x == 0) { dgamma[c] += a0; dbeta[c] += a1; }
 }
 
+// Register-resident variants for HW % 4 == 0, HW / 4 <= 512 and CPG channels per group (the DrQ-v2 stack: 42x42 planes, 4 or 8 channels per
+// group): a (sample, group) slab is CPG contiguous planes of HW floats; every thread keeps its <= 2 float4 per plane in registers, so x (and
+// dy) is read once with 16-B accesses and no index division; the backward also emits the per-(sample, channel) parameter-gradient partials
+// that gn_param_fold_kernel sums over the batch in order (replaces a second full pass over e and x).
+typedef float gn_f4 __attribute__((ext_vector_type(4)));
+template <int CPG>
+__global__ void __launch_bounds__(256) gn_mish_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mask, float* __restrict__ stats, float* __restrict__ y, int C, int B,
+                                                          int HW, int G) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x, HW4 = HW >> 2;
+    const bool v0 = tid < HW4, v1 = tid + 256 < HW4;
+    gn_f4 v[CPG][2];
+    float s = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {
+        const gn_f4* xp = reinterpret_cast<const gn_f4*>(x + ((size_t)(g * CPG + cc) * B + b) * HW);
+        v[cc][0] = v0 ? xp[tid] : (gn_f4){0.f, 0.f, 0.f, 0.f};
+        v[cc][1] = v1 ? xp[tid + 256] : (gn_f4){0.f, 0.f, 0.f, 0.f};
+        s += ((v[cc][0][0] + v[cc][0][1]) + (v[cc][0][2] + v[cc][0][3])) + ((v[cc][1][0] + v[cc][1][1]) + (v[cc][1][2] + v[cc][1][3]));
+    }
+    const float n = (float)(CPG * HW);
+    const float mean = wg_sum256(s, sh) / n;
+    float q = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+            if (h == 0 ? v0 : v1)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[cc][h][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / n + 1e-5f);
+    if (tid == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {
+        const int c = g * CPG + cc;
+        const float ga = gamma[c], be = beta[c], mk = mask ? mask[(size_t)b * C + c] : 1.f;
+        gn_f4* yp = reinterpret_cast<gn_f4*>(y + ((size_t)c * B + b) * HW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!(h == 0 ? v0 : v1)) continue;
+            gn_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { float t = act_apply((v[cc][h][j] - mean) * rstd * ga + be, ACT_MISH); if (mask) t *= mk; o[j] = t; }
+            yp[tid + 256 * h] = o;
+        }
+    }
+}
+template <int CPG>
+__global__ void __launch_bounds__(256) gn_mish_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ mask, const float* __restrict__ stats, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, float* __restrict__ ppart /*[B][C][2]*/, int C, int B, int HW, int G) {
+    __shared__ float sh[16];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x, HW4 = HW >> 2;
+    const bool v0 = tid < HW4, v1 = tid + 256 < HW4;
+    const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
+    gn_f4 xh[CPG][2], e[CPG][2];
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {
+        const int c = g * CPG + cc;
+        const size_t base = ((size_t)c * B + b) * HW;
+        const gn_f4* xp = reinterpret_cast<const gn_f4*>(x + base);
+        const gn_f4* dp = reinterpret_cast<const gn_f4*>(dy + base);
+        const float ga = gamma[c], be = beta[c], mk = mask ? mask[(size_t)b * C + c] : 1.f;
+        float pe = 0.f, pex = 0.f;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = h == 0 ? v0 : v1;
+            const gn_f4 xv = ok ? xp[tid + 256 * h] : (gn_f4){0.f, 0.f, 0.f, 0.f};
+            const gn_f4 dv = ok ? dp[tid + 256 * h] : (gn_f4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xx = (xv[j] - mean) * rstd;
+                float ee = ok ? dv[j] * act_grad(xx * ga + be, ACT_MISH) : 0.f;
+                if (mask) ee *= mk;
+                xh[cc][h][j] = xx; e[cc][h][j] = ee;
+                pe += ee; pex += ee * xx;
+            }
+        }
+        sg += pe * ga; sgx += pex * ga;
+        const float te = wg_sum256(pe, sh), tex = wg_sum256(pex, sh);     // per-(sample, channel) partials of dbeta / dgamma
+        if (tid == 0) { ppart[((size_t)b * C + c) * 2] = tex; ppart[((size_t)b * C + c) * 2 + 1] = te; }
+    }
+    const float n = (float)(CPG * HW);
+    const float mg = wg_sum256(sg, sh) / n, mgx = wg_sum256(sgx, sh) / n;
+#pragma unroll
+    for (int cc = 0; cc < CPG; ++cc) {
+        const int c = g * CPG + cc;
+        const float ga = gamma[c];
+        gn_f4* op = reinterpret_cast<gn_f4*>(dx + ((size_t)c * B + b) * HW);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!(h == 0 ? v0 : v1)) continue;
+            gn_f4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rstd * (e[cc][h][j] * ga - mg - xh[cc][h][j] * mgx);
+            op[tid + 256 * h] = o;
+        }
+    }
+}
+// dgamma[c] += sum_b ppart[b][c][0], dbeta[c] += sum_b ppart[b][c][1], in batch order
+__global__ void gn_param_fold_kernel(const float* __restrict__ ppart, float* __restrict__ dgamma, float* __restrict__ dbeta, int C, int B) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a0 = 0.f, a1 = 0.f;
+    for (int b = 0; b < B; ++b) { a0 += ppart[((size_t)b * C + c) * 2]; a1 += ppart[((size_t)b * C + c) * 2 + 1]; }
+    dgamma[c] += a0; dbeta[c] += a1;
+}
+static inline bool gn_reg_ok(int C, int G, int HW, const void* a, const void* b2) {
+    const int cpg = C / G;
+    return (cpg == 4 || cpg == 8) && HW % 4 == 0 && HW / 4 <= 512 && ((((uintptr_t)a | (uintptr_t)b2) & 15) == 0);
+}
+
 // ---- SpatialAttention (visual_encoders.py:210-225) -------------------------------------------------------------------------------
 __global__ void attn_pool_kernel(const float* __restrict__ x /*CNHW*/, float* __restrict__ pool /*[B][2][HW]*/, int32_t* __restrict__ amax /*[B][HW]*/,
                                  int C, int B, int HW) {
@@ -568,8 +682,15 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
         GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], col, (int)N, sv.conv_out[i], (int)N, g.cout[i], (int)N, g.Kp[i]);
         ga.b_kmajor = 1;
         AID_TRY(gemm_f32(ga, s));
-        hipLaunchKernelGGL(gn_mish_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], sv.act[i],
-                           g.cout[i], B, g.ho[i] * g.ho[i], g.G[i]);
+        {
+            const int hw = g.ho[i] * g.ho[i], cpg = g.cout[i] / g.G[i];
+            if (gn_reg_ok(g.cout[i], g.G[i], hw, sv.conv_out[i], sv.act[i])) {
+                if (cpg == 4) hipLaunchKernelGGL(gn_mish_reg_kernel<4>, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], sv.act[i], g.cout[i], B, hw, g.G[i]);
+                else hipLaunchKernelGGL(gn_mish_reg_kernel<8>, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], sv.act[i], g.cout[i], B, hw, g.G[i]);
+            } else {
+                hipLaunchKernelGGL(gn_mish_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], sv.act[i], g.cout[i], B, hw, g.G[i]);
+            }
+        }
         AID_LAUNCH_CHECK();
         ws.release(mark);
         cur = sv.act[i];
@@ -647,10 +768,17 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         float* dweff = ws.f32((size_t)g.cout[i] * g.Kp[i]);
         const int S = conv_slabs(N);
         float* slab = ws.f32((size_t)S * g.cout[i] * g.Kp[i]);
+        float* ppart = ws.f32((size_t)B * g.cout[i] * 2);
         AID_WS_OK(ws);
-        hipLaunchKernelGGL(gn_mish_bwd_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv,
-                           g.cout[i], B, hw, g.G[i]);
-        hipLaunchKernelGGL(gn_param_grad_kernel, dim3(g.cout[i]), dim3(1024), 0, s, dcur, sv.conv_out[i], sv.gn_stats[i], gr.gn_g[i], gr.gn_b[i], g.cout[i], B, hw, g.G[i]);
+        if (gn_reg_ok(g.cout[i], g.G[i], hw, sv.conv_out[i], dcur) && ((((uintptr_t)dconv) & 15) == 0)) {
+            if (g.cout[i] / g.G[i] == 4) hipLaunchKernelGGL(gn_mish_bwd_reg_kernel<4>, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv, ppart, g.cout[i], B, hw, g.G[i]);
+            else hipLaunchKernelGGL(gn_mish_bwd_reg_kernel<8>, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv, ppart, g.cout[i], B, hw, g.G[i]);
+            hipLaunchKernelGGL(gn_param_fold_kernel, dim3((g.cout[i] + 63) / 64), dim3(64), 0, s, ppart, gr.gn_g[i], gr.gn_b[i], g.cout[i], B);
+        } else {
+            hipLaunchKernelGGL(gn_mish_bwd_kernel, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv,
+                               g.cout[i], B, hw, g.G[i]);
+            hipLaunchKernelGGL(gn_param_grad_kernel, dim3(g.cout[i]), dim3(1024), 0, s, dcur, sv.conv_out[i], sv.gn_stats[i], gr.gn_g[i], gr.gn_b[i], g.cout[i], B, hw, g.G[i]);
+        }
         AID_LAUNCH_CHECK();
         {   // dW_eff[Cout][Kp] = dconv[Cout][N] x col[Kp][N]^T  (both k-contiguous along N; huge reduction -> slabs); col: the forward's im2col
             GemmArgs ga = gemm_args(dconv, (int)N, sv.col[i], (int)N, dweff, g.Kp[i], g.cout[i], g.Kp[i], (int)N);

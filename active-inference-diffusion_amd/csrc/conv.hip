@@ -329,7 +329,15 @@ __global__ void gn_param_fold_kernel(const float* __restrict__ ppart, float* __r
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     float a0 = 0.f, a1 = 0.f;
-    for (int b = 0; b < B; ++b) { a0 += ppart[((size_t)b * C + c) * 2]; a1 += ppart[((size_t)b * C + c) * 2 + 1]; }
+    int b = 0;
+    for (; b + 8 <= B; b += 8) {          // 8 independent loads in flight, added in batch order
+        float2 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = *reinterpret_cast<const float2*>(ppart + ((size_t)(b + j) * C + c) * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a0 += t[j].x; a1 += t[j].y; }
+    }
+    for (; b < B; ++b) { a0 += ppart[((size_t)b * C + c) * 2]; a1 += ppart[((size_t)b * C + c) * 2 + 1]; }
     dgamma[c] += a0; dbeta[c] += a1;
 }
 static inline bool gn_reg_ok(int C, int G, int HW, const void* a, const void* b2) {

@@ -620,7 +620,8 @@ def gemm_low_lds_hint(on: bool):
 
 
 def gemm_force_kernel(k: int):
-    """0 auto, 1 panel32, 2 ring64, 3 ring128, 4 tile64, 5 tile128, 6 splitk (benches/tests only)."""
+    """Kernel override for benches / tests (codes: include/aid_hip.h, aid_gemm_force_kernel): 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 split-K,
+    8 thin TN, 9 / 11 big (prefetch 2 / 1), 10 skinny (M <= 32), 14 panel128, 15 panel64; +256 XCD-grouped tile map; 512 low-LDS hint."""
     check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")
 
 

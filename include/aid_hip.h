@@ -67,8 +67,8 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream);
-/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 / 11 gemm_big_kernel with prefetch
- * distance 2 / 1, 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel; bit 9 (value 512, with kernel code 0) is a
+/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 8 thin TN (weight gradients of narrow layers),
+ * 9 / 11 gemm_big_kernel with prefetch distance 2 / 1, 10 skinny (M <= 32 rows: act() / collector batches), 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel; bit 9 (value 512, with kernel code 0) is a
  * dispatch HINT, not an override: small problems use the 35 KB-LDS panel variant (launches meant to overlap a big GEMM on another stream) */
 int aid_gemm_force_kernel(int k);
 

@@ -14,7 +14,7 @@ def bench(fn, reps=50):
         t0=time.time()
         for _ in range(3): g.replay()
         torch.cuda.synchronize(); return (time.time()-t0)/3/reps
-names={1:"panel32",2:"ring64",3:"ring128",4:"tile64",5:"tile128"}
+names={1:"panel32",14:"panel128",15:"panel64",2:"ring64",4:"tile64",9:"big",6:"splitk"}   # aid_gemm_force_kernel codes (include/aid_hip.h)
 shapes=[(256,512,512,"nt"),(512,512,512,"nt"),(256,2048,512,"nt"),(512,2048,512,"nt"),(256,512,2048,"nt"),(512,512,2048,"nt"),(256,13312,512,"nt"),(512,13312,512,"nt"),
         (2560,512,512,"nt"),(2560,256,512,"nt"),(25600,1024,1024,"nt"),(25600,512,1024,"nt"),(25600,512,384,"nt"),(25600,256,128,"nt"),
         (256,512,2048,"nn"),(512,2048,256,"tn"),(13312,512,256,"tn"),(2560,512,512,"nn"),(512,512,2560,"tn")]
@@ -23,7 +23,7 @@ for (M,N,K,lay) in shapes:
     A=torch.randn((K,M) if akm else (M,K),device="cuda"); W=torch.randn((K,N) if bkm else (N,K),device="cuda"); C=torch.empty(M,N,device="cuda")
     ref = (A.t() if akm else A).double() @ (W if bkm else W.t()).double()
     row=[]
-    for k in (1,2,3,4,5):
+    for k in names:
         nat.gemm_force_kernel(k)
         try:
             C.zero_(); nat.gemm(A,W,C,M,N,K,A.shape[1],W.shape[1],N,akm,bkm); torch.cuda.synchronize()

@@ -231,11 +231,12 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("AID_HIP_LIB", LIB_PATH)     # another build of the same library (A/B measurements of kernel variants)
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"aid_amd: native library not found at {LIB_PATH}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"aid_amd: native library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C active-inference-diffusion_amd/csrc`. There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     L.aid_last_error.restype = C.c_char_p
     L.aid_version.restype = C.c_int
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",

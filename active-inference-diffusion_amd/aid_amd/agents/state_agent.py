@@ -91,29 +91,35 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         next_obs, dones = batch["next_observations"], batch["dones"]
         nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
         latents = both[:B]
-        # 2. score / diffusion group: ELBO forward + backward on the main stream
-        self.score_optimizer.zero_grad()
-        elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents)
+        # 2. score / diffusion group.  The policy phase reads no score-network parameter and no ELBO result, and the value phase needs a
+        # fresh belief over next_obs from the UPDATED score network (state_agent.py:194-205).  So the whole chain
+        #   ELBO forward + backward -> [gradient all-reduce ->] score step -> reverse loop
+        # is enqueued on a side stream and runs underneath the EFE/MINE phase: its batch-256 kernels are latency-bound and leave most CUs
+        # idle, the 25 600-row MINE GEMMs fill them.  Same arithmetic; the host enqueues ELBO, EFE, belief in the reference's order, so
+        # the Philox offsets (draw order) are unchanged.
+        side = self._comm_stream() if self.overlap_streams else main
+        ws = self._side_workspace() if self.overlap_streams else None
         if self.overlap_streams:
-            # The policy phase reads no score-network parameter, and the value phase needs a fresh belief over next_obs from
-            # the UPDATED score network (state_agent.py:194-205).  So: [gradient all-reduce ->] score step -> reverse loop run on a
-            # side stream underneath the EFE/MINE phase.  The loop's batch-256 kernels are latency-bound and leave most CUs idle;
-            # the 25 600-row MINE GEMMs fill them.  Same arithmetic, same draw order (EFE, then belief).
-            elbo_done = torch.cuda.Event(); elbo_done.record(main)
-        else:
-            self.score_optimizer.step()
+            side.wait_stream(main)
+            for t_ in (obs, nrew, latents, next_obs):
+                t_.record_stream(side)
+        with torch.cuda.stream(side):
+            if self.overlap_streams and self.elbo_low_lds:
+                nat.gemm_low_lds_hint(True)
+            self.score_optimizer.zero_grad()
+            elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
+            if self.overlap_streams:
+                nat.gemm_low_lds_hint(False)
+            else:
+                self.score_optimizer.step()
         # 3. policy
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
         # 4. value (targets from a re-sampled next-latent belief) [+ the two belief updates of the next step]
-        side = self._comm_stream() if self.overlap_streams else main
-        if self.overlap_streams:
-            side.wait_event(elbo_done)
         with torch.cuda.stream(side):
             if self.overlap_streams:
                 self.score_optimizer.step()            # data parallel: the 109 MB RCCL all-reduce runs here, off the critical path
-            ws = self._side_workspace() if self.overlap_streams else None
             if self.overlap_streams:
                 nat.gemm_low_lds_hint(True)      # 35 KB panel variant: these launches must co-reside with the EFE's 25 600-row GEMMs
             if self._want_prefetch():
@@ -131,6 +137,9 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                 nat.gemm_low_lds_hint(False)
         if self.overlap_streams:
             next_latents.record_stream(main)
+            for v in elbo_info.values():
+                if torch.is_tensor(v):
+                    v.record_stream(main)
             if self._prefetch is not None:
                 self._prefetch["latents"].record_stream(main)
                 for v in self._prefetch["batch"].values():
@@ -164,6 +173,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     # The reference trains the MINE estimator when `total_steps % 5 == 0` (state_agent.py:216-222) but its concrete agents never create
     # the optimiser that branch needs, so it raises there.  Opt in with 5 to get the behaviour the code intends.
     train_epistemic_every = 0
+    elbo_low_lds = True            # side-stream ELBO launches use the 35 KB panel variant too
 
     # -- cross-step prefetch of the next minibatch's belief latents ------------------------------------------------------------
     prefetch_next_batch = True     # False: never look ahead (every train_step samples and denoises its own minibatch)

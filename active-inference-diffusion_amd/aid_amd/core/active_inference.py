@@ -423,10 +423,12 @@ class DiffusionActiveInference(nn.Module):
 
     # ------------------------------------------------------------------------------------------ A5 / A7
     def compute_diffusion_elbo(self, observations: torch.Tensor, rewards: torch.Tensor, latents: Optional[torch.Tensor] = None,
-                               raw_observations: Optional[torch.Tensor] = None, noise: Optional[dict] = None
+                               raw_observations: Optional[torch.Tensor] = None, noise: Optional[dict] = None, ws=None
                                ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """Forward + backward of -ELBO in one native call; gradients are ACCUMULATED into the score arena
-        (`agent.score_optimizer.zero_grad()` first, as the reference does)."""
+        (`agent.score_optimizer.zero_grad()` first, as the reference does).  `ws`: workspace to use when the call is enqueued on a
+        stream other than the one the module's own workspace serves."""
+        ws = ws if ws is not None else self._ws
         observations = observations.to(self.device).contiguous().float()
         rewards = rewards.to(self.device).contiguous().float()
         if latents is None:
@@ -447,7 +449,7 @@ class DiffusionActiveInference(nn.Module):
                 fd_mask = torch.empty(B, c.hidden_dim, device=self.device)
                 nat.fill_dropout_mask(fd_mask, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(fd_mask.numel()))
             preset = nat.feature_decoder_step(self._fd_tab.get(self.feature_decoder), self._fd_gtab.get(self.feature_decoder), latents, observations,
-                                              fd_mask if self.feature_decoder.training else None, d_obs, self._ws)
+                                              fd_mask if self.feature_decoder.training else None, d_obs, ws)
             noise = dict(noise or {}); noise["d_obs_out"] = d_obs
         self._last_d_obs = d_obs
         metrics, t, per = nat.elbo_step(self.latent_score_network.table(), self.latent_score_network.grad_table(), self.latent_diffusion.table(),
@@ -455,7 +457,7 @@ class DiffusionActiveInference(nn.Module):
                                         self.reward_table(), observations, rewards, latents,
                                         self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training, recon_preset=preset,
                                         kl_weight=c.kl_weight, diffusion_weight=c.diffusion_weight, reward_weight=c.reward_weight, gp_weight=0.1,
-                                        seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws,
+                                        seed=self.noise.seed, offset=self.noise.next_offset(), ws=ws,
                                         defer_time_importance=parallel.is_dp())
         if parallel.is_dp():   # one global, rank-major order for the order-dependent EMA
             nat.time_importance_update(self.time_importance_weights, parallel.allgather_cat(t), parallel.allgather_cat(per), first)

@@ -31,6 +31,13 @@ for key in ("roofline", "roofline_second_kernel"):
     w(f"* `{key}`: `{r['kernel']}` — {r['achieved']:.1f} TFLOP/s = **{100*r['frac']:.1f} %** of peak over {r['launches_per_step']} launches "
       f"({r['ms_per_step']:.1f} ms of the profiled step, {r['us_per_launch']:.1f} µs and {r['flop_per_launch']/1e9:.2f} GFLOP per launch"
       + (f", PMC traffic {r['traffic']/1e6:.1f} MB per launch" if r.get("traffic") else "") + ").")
+r = bench["roofline"]
+if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
+    w(f"  PMC traffic vs algorithmic bytes of that kernel: {r['traffic']/1e6:.0f} MB against {r['algorithmic_bytes_per_launch']/1e6:.0f} MB per launch "
+      f"({r['traffic']/r['algorithmic_bytes_per_launch']:.1f}x).  `FETCH_SIZE` counts what the eight per-XCD L2s pull from the fabric (Infinity Cache or HBM): every XCD "
+      "fetches its own copy of the weight operand, and an activation row tile is fetched once per group of 8 column tiles.  At "
+      f"{r['traffic']/1e6/r['us_per_launch']*1e6/1e6:.1f} TB/s the kernel is nowhere near the 8 TB/s roof, and the tile map that removes the replicated weight fetch "
+      "(N-partitioned across XCDs) was measured in situ: no gain (DESIGN.md, tried and rejected).")
 for key in ("roofline_big_family", "roofline_small_family"):
     r = bench[key]
     w(f"* `{key}`: {r['kernel']} — {r['achieved']:.1f} TFLOP/s = {100*r['frac']:.1f} % over {r['launches_per_step']} launches, {r['ms_per_step']:.1f} ms.")

@@ -219,6 +219,26 @@ def test_gemm_every_kernel_variant(nat, code, layout):
     assert np.max(np.abs(out.cpu().numpy() - ref) / scale) < 2e-6
 
 
+@pytest.mark.parametrize("M,N", [(64 * 37, 64 * 8), (64 * 13 + 5, 64 * 24), (64 * 9, 64 * 3), (64 * 41 + 63, 64 * 16 + 1)])
+def test_gemm_big_kernel_xcd_grouped_map_any_grid(nat, M, N):
+    """The XCD-grouped tile map of gemm_big_kernel must be a bijection for every grid (row-tile counts that are not multiples of 8,
+    leftover tasks, column-tile counts below / not divisible by 8): forced kernel 9 with the map bit, against the fp64 reference."""
+    K = 96
+    rng = np.random.default_rng(M + N)
+    A = rng.standard_normal((M, K)).astype(np.float32); W = rng.standard_normal((N, K)).astype(np.float32)
+    out = torch.full((M, N), float("nan"), device="cuda")
+    nat.gemm_force_kernel(9 + 256)
+    try:
+        nat.gemm(dev(A), dev(W), out, M, N, K, K, K, N)
+    finally:
+        nat.gemm_force_kernel(0)
+    ref = A.astype(np.float64) @ W.astype(np.float64).T
+    scale = np.abs(A).astype(np.float64) @ np.abs(W).astype(np.float64).T + 1.0
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.max(np.abs(got - ref) / scale) < 2e-6
+
+
 @pytest.mark.parametrize("M,N,K,acc", [(6, 256, 2560, 1), (512, 17, 2560, 1), (17, 23, 1001, 0), (3, 1, 513, 1)])
 def test_gemm_thin_weight_gradient(nat, M, N, K, acc):
     """dW[M,N] (+)= dY^T X over K rows with a 6- / 17-wide side: the automatic dispatcher's thin TN kernel (16 waves split K inside one

@@ -24,9 +24,9 @@ class FakeEnv:
         self.observation_space, self.action_space = Box((O,)), Box((A,))
 
 
-def _agent(O, A, D, N, H, B, cap=64):
+def _agent(O, A, D, N, H, B, cap=64, L=None):
     import aid_amd
-    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=O, hidden_dim=D)
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=L or O, hidden_dim=D)
     cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
     return aid_amd.DiffusionStateAgent(FakeEnv(O, A), cfg, aid_amd.TrainingConfig(buffer_size=cap))
 
@@ -223,5 +223,23 @@ def test_ragged_sizes_train_and_act(O, A, B, D, N, H):
     for _ in range(3):
         m = agent.train_step()
         assert all(np.isfinite(v) for v in m.values()), m
+    a, info = agent.act(rng.standard_normal(O).astype(np.float32))
+    assert a.shape == (A,) and np.all(np.isfinite(a))
+
+
+def test_state_mode_latent_dim_differs_from_obs_dim():
+    """State mode with latent_dim != observation_dim (the config default is 128 on 17-d observations): the reference cannot run it
+    (its obs encoder is sized latent_dim but fed raw states), so there is no parity to pin; the build sizes the obs encoder
+    with the true observation dim.  Three train_steps stay finite, the decoder maps latents back to O dims, act() works."""
+    O, A, L, B = 17, 6, 32, 32
+    agent = _agent(O, A, 64, 4, 2, B, cap=4 * B, L=L)
+    rng = np.random.default_rng(5)
+    agent.replay_buffer.add_batch(rng.standard_normal((4 * B, O)), rng.uniform(-1, 1, (4 * B, A)), rng.standard_normal(4 * B),
+                                  rng.standard_normal((4 * B, O)), rng.random(4 * B) < 0.05)
+    for _ in range(3):
+        m = agent.train_step()
+        assert all(np.isfinite(v) for v in m.values()), m
+    assert agent._last["latents"].shape == (B, L)
+    assert agent.active_inference.decode_observation(agent._last["latents"]).shape == (B, O)
     a, info = agent.act(rng.standard_normal(O).astype(np.float32))
     assert a.shape == (A,) and np.all(np.isfinite(a))

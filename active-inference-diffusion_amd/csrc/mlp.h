@@ -14,7 +14,7 @@ int axpby_cols(const float* a, int lda, float alpha, const float* b, int ldb, fl
 struct LlaSave { float *lin, *stats, *y; };
 int lla_alloc(int M, int out, Workspace& ws, LlaSave& sv);
 int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, const float* x, int ldx, int M, LlaSave& sv, hipStream_t s,
-            const float* add = nullptr);
+            const float* add = nullptr, bool need_lin = true);
 // dy: gradient wrt sv.y [M,out].  Writes dx (optional, row stride lddx) ; accumulates parameter grads when gl/gln given.
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
             int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s);

@@ -16,6 +16,11 @@ int sinusoid_embed(const float* t, const float* freq_scale, float tmul, int mode
 int ln_act(const float* x, int ldx, const float* gamma, const float* beta, int act, const float* mask, float* y, int ldy,
            float* stats, int M, int D, hipStream_t s, const float* add = nullptr);
 
+// y = act(LN(x W^T + b)) * mask + add for K <= 32, D in {256, 512, 1024}, act in {ReLU, SiLU}: one pass (lin / stats optional outputs for a backward pass)
+bool lin_smallk_ln_act_ok(int K, int D, int act, const void* a, const void* b, const void* c, const void* d, int ldy);
+int lin_smallk_ln_act(const float* x, int ldx, int K, const float* W, const float* bias, const float* gamma, const float* beta, int act,
+                      const float* mask, const float* add, float* lin, float* y, int ldy, float* stats, int M, int D, hipStream_t s);
+
 // cond = LN(x)*gamma+beta + temb[row*ld_temb + c] ; sc = silu(cond).   (score_networks.py:145-153 + adaLN's SiLU)
 // x_mod > 0: row r reads x row (r % x_mod) (obs embedding shared by every step); temb_div > 0: row r adds temb row (r / temb_div)
 // (per-step time embedding), else temb row stride ld_temb (0 = one shared row).

@@ -117,12 +117,20 @@ struct ProfScope {
     ~ProfScope();
 };
 
+// tanh(softplus(x)) = n / (n + 2) with n = e^x (e^x + 2): the same function as tanhf(log1pf(expf(x))) with one exponential and one division
+// instead of three transcendental calls (the GroupNorm-Mish kernels of the pixel encoder are VALU-bound on them); tanh is 1 to fp32 precision
+// beyond x = 20 (F.softplus switches to the identity there too) and e^{2x} would overflow beyond x = 44.
+__device__ __forceinline__ float tanh_softplus(float x) {
+    if (x > 20.f) return 1.f;
+    const float e = expf(x), n = e * (e + 2.f);
+    return n / (n + 2.f);
+}
 __device__ __forceinline__ float act_apply(float x, int act) {
     switch (act) {
         case ACT_RELU: return x > 0.f ? x : 0.f;
         case ACT_SILU: return x / (1.f + expf(-x));
         case ACT_GELU: return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
-        case ACT_MISH: return x * tanhf(log1pf(expf(x)));      // F.mish
+        case ACT_MISH: return x * tanh_softplus(x);            // F.mish
         case ACT_TANH: return tanhf(x);
         default: return x;
     }
@@ -134,7 +142,7 @@ __device__ __forceinline__ float act_grad(float x, int act) {
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
         case ACT_SILU: { const float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
         case ACT_GELU: return 0.5f * (1.f + erff(x * 0.70710678118654752440f)) + x * expf(-0.5f * x * x) * 0.3989422804014327f;
-        case ACT_MISH: { const float t = tanhf(log1pf(expf(x))); return t + x * sigmoidf_(x) * (1.f - t * t); }
+        case ACT_MISH: { const float t = tanh_softplus(x); return t + x * sigmoidf_(x) * (1.f - t * t); }
         case ACT_TANH: { const float t = tanhf(x); return 1.f - t * t; }
         default: return 1.f;
     }

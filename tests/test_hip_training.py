@@ -441,7 +441,9 @@ def test_train_epistemic_estimator_reference_golden(golden_dir):
                 np.testing.assert_allclose(float(gv[n].double().abs().sum()) * coef, g[f"s1_gradsum/{n}"][1], rtol=2e-3, atol=1e-4 * gmax)
         sd = ai.state_dict()
         cs = np.array([float(sd[n].double().sum()) for n in names])
-        bad = np.abs(cs - g[f"s{step}_checksum"]) > 2e-6 * g[f"s{step}_abssum"] + 2e-6
+        # + 2 * lr per accumulated step: one element whose gradient is rounding noise (mine_network.6.bias on the first call: -1 + mean(exp(t)) /
+        # running_mean = 0) takes its lr-sized Adam step in the direction of the noise
+        bad = np.abs(cs - g[f"s{step}_checksum"]) > 2e-6 * g[f"s{step}_abssum"] + 2e-6 + 1.1e-5 * step
         assert not bad.any(), (step, [names[i] for i in np.nonzero(bad)[0]])
         for n in names:
             t = sd[n].reshape(-1)

@@ -33,7 +33,7 @@ for key in ("roofline", "roofline_second_kernel"):
       + (f", PMC traffic {r['traffic']/1e6:.1f} MB per launch" if r.get("traffic") else "") + ").")
 r = bench["roofline"]
 if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
-    w(f"  PMC traffic vs algorithmic bytes of that kernel: {r['traffic']/1e6:.0f} MB against {r['algorithmic_bytes_per_launch']/1e6:.0f} MB per launch "
+    w(f"  PMC traffic vs algorithmic bytes of the dominant kernel (`roofline`): {r['traffic']/1e6:.0f} MB against {r['algorithmic_bytes_per_launch']/1e6:.0f} MB per launch "
       f"({r['traffic']/r['algorithmic_bytes_per_launch']:.1f}x).  `FETCH_SIZE` counts what the eight per-XCD L2s pull from the fabric (Infinity Cache or HBM): every XCD "
       "fetches its own copy of the weight operand, and an activation row tile is fetched once per group of 8 column tiles.  At "
       f"{r['traffic']/1e6/r['us_per_launch']*1e6/1e6:.1f} TB/s the kernel is nowhere near the 8 TB/s roof, and the tile map that removes the replicated weight fetch "

@@ -159,6 +159,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// 8 per-lane partial sums -> 8 wave totals with 4 + 2 + 1 + 3 = 10 cross-lane moves (each butterfly stage halves the values a lane
+// carries); afterwards lane 8 c (c = 0..7) holds the total of value c.  Fixed order: reproducible.
+__device__ __forceinline__ float fold8(const float (&acc)[8], int lane) {
+    float a4[4], a2[2], a1;
+    const bool h32 = lane & 32, h16 = lane & 16, h8 = lane & 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const float recv = __shfl_xor(h32 ? acc[i] : acc[i + 4], 32, 64); a4[i] = (h32 ? acc[i + 4] : acc[i]) + recv; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float recv = __shfl_xor(h16 ? a4[i] : a4[i + 2], 16, 64); a2[i] = (h16 ? a4[i + 2] : a4[i]) + recv; }
+    { const float recv = __shfl_xor(h8 ? a2[0] : a2[1], 8, 64); a1 = (h8 ? a2[1] : a2[0]) + recv; }
+    a1 += __shfl_xor(a1, 4, 64); a1 += __shfl_xor(a1, 2, 64); a1 += __shfl_xor(a1, 1, 64);
+    return a1;
+}
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -138,10 +138,22 @@ class ArenaOptimizer:
         self.arena.step(self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"], self.clip_norm, self.ema_decay)
 
     def state_dict(self):
-        return self.arena.state_dict()
+        """torch.optim.AdamW's layout (per-parameter step / exp_avg / exp_avg_sq; one param group with its hyper-parameters), so a
+        checkpoint written by either side loads into the other (`utils/training.py:72-122` saves `*_optimizer.state_dict()`)."""
+        sd = self.arena.state_dict()
+        g = self.param_groups[0]
+        sd["param_groups"][0].update({"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
+                                      "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                                      "decoupled_weight_decay": True})
+        return sd
 
     def load_state_dict(self, sd):
         self.arena.load_state_dict(sd)
+        groups = sd.get("param_groups") or [{}]
+        for k in ("lr", "weight_decay", "betas", "eps"):
+            if k in groups[0]:
+                self.param_groups[0][k] = groups[0][k]
+        self.lr, self.weight_decay = self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"]
 
 
 class AdamL2Optimizer:

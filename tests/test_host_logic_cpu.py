@@ -79,6 +79,37 @@ def test_param_arena_flattens_in_place_and_keeps_adaLN_contiguous():
     assert st["param_groups"][0]["params"] == list(range(len(arena.names)))
 
 
+def test_optimizer_state_dict_interchanges_with_torch_adamw():
+    """`agent.*_optimizer.state_dict()` follows torch.optim.AdamW's layout (the reference's checkpoint writer saves exactly that,
+    utils/training.py:87-105): ours loads into a torch AdamW over same-shaped parameters, and a torch AdamW state loads into ours."""
+    from aid_amd.arena import ParamArena, ArenaOptimizer
+    from aid_amd.models import ValueNetwork
+    net = ValueNetwork(17, 64)
+    arena = ParamArena([(n, p) for n, p in net.named_parameters()], "cpu")
+    opt = ArenaOptimizer(arena, lr=5e-5, weight_decay=1e-2, clip_norm=0.5)
+    arena.exp_avg.uniform_(-1, 1); arena.exp_avg_sq.uniform_(0, 1); arena.step_count = 7
+    sd = opt.state_dict()
+    ref_params = [torch.nn.Parameter(p.detach().clone()) for p in net.parameters()]
+    ref = torch.optim.AdamW(ref_params, lr=1.0, weight_decay=0.0)
+    ref.load_state_dict(sd)                                                  # our checkpoint -> torch
+    g = ref.param_groups[0]
+    assert g["lr"] == 5e-5 and g["weight_decay"] == 1e-2 and tuple(g["betas"]) == (0.9, 0.999) and g["eps"] == 1e-8
+    for i, (n, p) in enumerate(net.named_parameters()):
+        o, shp = arena.offsets[n]
+        st = ref.state[ref_params[i]]
+        assert float(st["step"]) == 7.0 and torch.equal(st["exp_avg"], arena.exp_avg[o:o + p.numel()].view(shp))
+    for q in ref_params:
+        q.grad = torch.randn_like(q)
+    ref.step()                                                                # the loaded state is usable
+    arena2 = ParamArena([(n, p) for n, p in ValueNetwork(17, 64).named_parameters()], "cpu")
+    opt2 = ArenaOptimizer(arena2, lr=1.0, weight_decay=0.0, clip_norm=0.5)
+    opt2.load_state_dict(ref.state_dict())                                    # torch checkpoint -> ours
+    assert arena2.step_count == 8 and opt2.param_groups[0]["lr"] == 5e-5 and opt2.param_groups[0]["weight_decay"] == 1e-2
+    for i, (n, p) in enumerate(net.named_parameters()):
+        o, shp = arena2.offsets[n]
+        assert torch.equal(arena2.exp_avg_sq[o:o + p.numel()].view(shp), ref.state[ref_params[i]]["exp_avg_sq"])
+
+
 def test_noise_source_hands_out_disjoint_counter_ranges():
     from aid_amd.noise import NoiseSource, PhiloxNoise
     n = PhiloxNoise(seed=3)

@@ -74,14 +74,28 @@ class BaseActiveInferenceAgent(ABC):
         """Four AdamW groups (state_agent.py:245-274): lr = config.learning_rate; weight decay 1e-5 on the score and policy
         groups, torch's default 1e-2 on value and dynamics (the reference passes none); clip-by-global-norm = gradient_clip;
         score-net EMA 0.9999 fused into the score step."""
-        a, lr, clip = self.active_inference.arenas, self.config.learning_rate, self.config.gradient_clip
-        self.score_optimizer = ArenaOptimizer(a["score"], lr, 1e-5, clip, ema_decay=0.9999)
+        ai = self.active_inference
+        a, lr, clip = ai.arenas, self.config.learning_rate, self.config.gradient_clip
+        self.score_optimizer = ArenaOptimizer(a["score"], lr, 1e-5, clip, ema_decay=0.9999, layout=self._score_layout())
         self.policy_optimizer = ArenaOptimizer(a["policy"], lr, 1e-5, clip)
         self.value_optimizer = ArenaOptimizer(a["value"], lr, 1e-2, clip)
-        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip)
+        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip, layout=self._dynamics_layout())
         if "epistemic" in a:   # base_agent.py:134-139 (the reference's concrete agents forget to create it: SURVEY D3)
             self.epistemic_optimizer = AdamL2Optimizer(a["epistemic"], lr * 0.1, 1e-5, clip)
             self.active_inference.epistemic_optimizer = self.epistemic_optimizer
+
+    # Checkpoint layouts: the parameter lists the reference passes to torch.optim.AdamW, in its order (state_agent.py:245-274).  The score
+    # arena stores its tensors in another order (the 13 adaLN matrices back to back); the dynamics optimiser also lists the observation
+    # decoder and the reward predictor, which it never updates (SURVEY D11) - positions without state.
+    def _score_layout(self):
+        ai, sc = self.active_inference, self.active_inference.arenas["score"]
+        return ([(sc, "latent_score_network." + n) for n, _ in ai.latent_score_network.named_parameters()] +
+                [(sc, "latent_diffusion." + n) for n, _ in ai.latent_diffusion.named_parameters()])
+
+    def _dynamics_layout(self):
+        ai, dy = self.active_inference, self.active_inference.arenas["dynamics"]
+        n_frozen = sum(1 for _ in ai.observation_decoder.parameters()) + sum(1 for _ in ai.reward_predictor.parameters())
+        return [(dy, "latent_dynamics." + n) for n, _ in ai.latent_dynamics.named_parameters()] + [None] * n_frozen
 
     def act(self, observation: np.ndarray, deterministic: bool = False) -> Tuple[np.ndarray, Dict[str, Any]]:
         obs = self._process_observation(observation).to(self.device)

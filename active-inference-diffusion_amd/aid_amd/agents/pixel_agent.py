@@ -15,7 +15,7 @@ import torch
 
 from .. import _native as nat
 from .. import parallel
-from ..arena import ArenaOptimizer, ParamArena
+from ..arena import ArenaOptimizer, ParamArena, adamw_load_state_dict, adamw_state_dict
 from ..configs.config import PixelObservationConfig
 from ..core.active_inference import DiffusionActiveInference
 from ..encoder.visual_encoders import DrQV2Encoder, RandomShiftAugmentation
@@ -27,8 +27,9 @@ class _PixelScoreOptimizer:
     """The reference's single AdamW over score net + diffusion + encoder + feature decoder (pixel_agent.py:441-449) with
     its clip over the first three only (:325-331): three arenas, one shared squared-norm."""
 
-    def __init__(self, score: ParamArena, encoder: ParamArena, fdec: ParamArena, lr: float, clip: float):
+    def __init__(self, score: ParamArena, encoder: ParamArena, fdec: ParamArena, lr: float, clip: float, layout=None):
         self.score, self.encoder, self.fdec, self.clip = score, encoder, fdec, clip
+        self.layout = layout
         self.param_groups = [{"lr": lr, "weight_decay": 1e-5, "betas": (0.9, 0.999), "eps": 1e-8}]
         self._pending = None
 
@@ -55,10 +56,11 @@ class _PixelScoreOptimizer:
         self.fdec.step(g["lr"], g["weight_decay"], 3.0e38)       # in the optimiser, outside the clipped set
 
     def state_dict(self):
-        return {"score": self.score.state_dict(), "encoder": self.encoder.state_dict(), "feature_decoder": self.fdec.state_dict()}
+        """One torch.optim.AdamW state over score net + diffusion + encoder + feature decoder, by position in the reference's list."""
+        return adamw_state_dict(self.layout, self.param_groups[0])
 
     def load_state_dict(self, sd):
-        self.score.load_state_dict(sd["score"]); self.encoder.load_state_dict(sd["encoder"]); self.fdec.load_state_dict(sd["feature_decoder"])
+        adamw_load_state_dict(self.layout, self.param_groups[0], sd)
 
 
 class DiffusionPixelAgent(BaseActiveInferenceAgent):
@@ -96,10 +98,14 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
 
     def _setup_optimizers(self):
         a, lr, clip = self.active_inference.arenas, self.config.learning_rate, self.config.gradient_clip
-        self.score_optimizer = _PixelScoreOptimizer(a["score"], self.encoder_arena, a["feature_decoder"], lr, clip)
+        enc_layout = [(self.encoder_arena, "encoder." + n) if ("encoder." + n) in self.encoder_arena.offsets else None   # channel_reduce: listed, never stepped
+                      for n, _ in self.encoder.named_parameters()]
+        fd_layout = [(a["feature_decoder"], "feature_decoder." + n) for n, _ in self.active_inference.feature_decoder.named_parameters()]
+        self.score_optimizer = _PixelScoreOptimizer(a["score"], self.encoder_arena, a["feature_decoder"], lr, clip,
+                                                    layout=self._score_layout() + enc_layout + fd_layout)
         self.policy_optimizer = ArenaOptimizer(a["policy"], lr, 1e-5, clip)
         self.value_optimizer = ArenaOptimizer(a["value"], lr, 1e-2, clip)
-        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip)
+        self.dynamics_optimizer = ArenaOptimizer(a["dynamics"], lr, 1e-2, clip, layout=self._dynamics_layout())
 
     def _create_replay_buffer(self) -> ReplayBuffer:
         shape = (self.frame_stack, *self.obs_shape) if self.frame_stack > 1 else self.obs_shape

@@ -113,13 +113,50 @@ class ParamArena:
             self.step_count = int(float(st["step"]))
 
 
+def adamw_state_dict(layout, hyper) -> dict:
+    """torch.optim.AdamW.state_dict() for a parameter list laid out as `layout`: entry i is (arena, name) for a parameter this build steps,
+    or None for one the reference passes to its optimiser but never updates (it keeps no state for those either).  One param group."""
+    state = {}
+    for i, e in enumerate(layout):
+        if e is None or not e[0].step_count:
+            continue
+        a, n = e
+        o, shp = a.offsets[n]; k = int(torch.Size(shp).numel())
+        state[i] = {"step": torch.tensor(float(a.step_count)), "exp_avg": a.exp_avg[o:o + k].view(shp).clone(),
+                    "exp_avg_sq": a.exp_avg_sq[o:o + k].view(shp).clone()}
+    group = {"lr": hyper["lr"], "betas": tuple(hyper["betas"]), "eps": hyper["eps"], "weight_decay": hyper["weight_decay"], "amsgrad": False,
+             "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": True,
+             "params": list(range(len(layout)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def adamw_load_state_dict(layout, hyper, sd: dict):
+    arenas = []
+    for i, e in enumerate(layout):
+        st = sd.get("state", {}).get(i)
+        if st is None or e is None:
+            continue
+        a, n = e
+        o, shp = a.offsets[n]; k = int(torch.Size(shp).numel())
+        a.exp_avg[o:o + k].view(shp).copy_(st["exp_avg"]); a.exp_avg_sq[o:o + k].view(shp).copy_(st["exp_avg_sq"])
+        a.step_count = int(float(st["step"]))
+        if a not in arenas:
+            arenas.append(a)
+    groups = sd.get("param_groups") or [{}]
+    for k in ("lr", "weight_decay", "betas", "eps"):
+        if k in groups[0]:
+            hyper[k] = groups[0][k]
+
+
 class ArenaOptimizer:
     """What callers see as `agent.score_optimizer` etc.: zero_grad / step / state_dict over one arena
     (reference: torch.optim.AdamW groups of aid/agents/state_agent.py:245-274)."""
 
-    def __init__(self, arena: ParamArena, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999):
+    def __init__(self, arena: ParamArena, lr: float, weight_decay: float, clip_norm: float, ema_decay: float = 0.9999, layout=None):
         self.arena, self.lr, self.weight_decay, self.clip_norm, self.ema_decay = arena, lr, weight_decay, clip_norm, ema_decay
         self.param_groups = [{"lr": lr, "weight_decay": weight_decay, "betas": (0.9, 0.999), "eps": 1e-8}]
+        # checkpoint layout = the parameter list the reference hands to torch.optim.AdamW (order matters: torch indexes state by position)
+        self.layout = layout if layout is not None else [(arena, n) for n in arena.names]
 
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
@@ -138,21 +175,13 @@ class ArenaOptimizer:
         self.arena.step(self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"], self.clip_norm, self.ema_decay)
 
     def state_dict(self):
-        """torch.optim.AdamW's layout (per-parameter step / exp_avg / exp_avg_sq; one param group with its hyper-parameters), so a
-        checkpoint written by either side loads into the other (`utils/training.py:72-122` saves `*_optimizer.state_dict()`)."""
-        sd = self.arena.state_dict()
-        g = self.param_groups[0]
-        sd["param_groups"][0].update({"lr": g["lr"], "betas": tuple(g["betas"]), "eps": g["eps"], "weight_decay": g["weight_decay"], "amsgrad": False,
-                                      "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
-                                      "decoupled_weight_decay": True})
-        return sd
+        """torch.optim.AdamW's layout (per-parameter step / exp_avg / exp_avg_sq by position in the reference's parameter list; one param
+        group with its hyper-parameters), so a checkpoint written by either side loads into the other (`utils/training.py:72-172` saves and
+        restores `*_optimizer.state_dict()`)."""
+        return adamw_state_dict(self.layout, self.param_groups[0])
 
     def load_state_dict(self, sd):
-        self.arena.load_state_dict(sd)
-        groups = sd.get("param_groups") or [{}]
-        for k in ("lr", "weight_decay", "betas", "eps"):
-            if k in groups[0]:
-                self.param_groups[0][k] = groups[0][k]
+        adamw_load_state_dict(self.layout, self.param_groups[0], sd)
         self.lr, self.weight_decay = self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"]
 
 

@@ -243,3 +243,50 @@ def test_state_mode_latent_dim_differs_from_obs_dim():
     assert agent.active_inference.decode_observation(agent._last["latents"]).shape == (B, O)
     a, info = agent.act(rng.standard_normal(O).astype(np.float32))
     assert a.shape == (A,) and np.all(np.isfinite(a))
+
+
+def _layout_names(opt, agent):
+    """Our optimiser's checkpoint layout as the reference spells its parameters: 'active_inference.<name>' / 'encoder.<name>' or None."""
+    out = []
+    for e in opt.layout:
+        if e is None:
+            out.append(None)
+        else:
+            n = e[1]
+            out.append(n if n.startswith("encoder.") else "active_inference." + n)
+    return out
+
+
+@pytest.mark.parametrize("mode", ["state", "pixel"])
+def test_optimizer_checkpoint_layout_matches_reference(golden_dir, mode):
+    """torch.optim.AdamW indexes its state by position in the parameter list it was given, so `*_optimizer.state_dict()` exchanges
+    with the reference's checkpoints (utils/training.py:72-172) only if every optimiser lists the same parameters in the same order:
+    tests/golden/opt_layout.json holds the reference's four lists for both agents (names + shapes).  Positions the reference lists but
+    never updates (observation decoder, reward predictor, the encoder's dead channel_reduce conv) carry no state on either side."""
+    import json
+    import aid_amd
+    g = json.load(open(os.path.join(golden_dir, "opt_layout.json")))[mode]
+    d = g["dims"]
+    if mode == "state":
+        agent = _agent(d["O"], d["A"], d["D"], d["N"], 2, 8)
+    else:
+        cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=3, efe_horizon=1, latent_dim=d["L"], hidden_dim=d["D"], pixel_observation=True)
+        cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=d["N"])
+
+        class Env:
+            observation_space, action_space = Box((3, 3, 84, 84)), Box((d["A"],))
+        agent = aid_amd.DiffusionPixelAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=4), aid_amd.PixelObservationConfig())
+    for key in ("score_optimizer", "policy_optimizer", "value_optimizer", "dynamics_optimizer"):
+        opt, ref = getattr(agent, key), g[key]
+        ours = _layout_names(opt, agent)
+        assert len(ours) == len(ref), (key, len(ours), len(ref))
+        for i, (o, (rn, rshape)) in enumerate(zip(ours, ref)):
+            if o is None:        # listed by the reference, never stepped: no state on either side
+                assert rn.startswith(("active_inference.observation_decoder.", "active_inference.reward_predictor.", "encoder.attention.channel_reduce")), (key, i, rn)
+                continue
+            assert o == rn, (key, i, o, rn)
+            arena, name = opt.layout[i]
+            assert list(arena.offsets[name][1]) == rshape, (key, name)
+        sd = opt.state_dict()
+        assert sd["param_groups"][0]["params"] == list(range(len(ref))) and sd["state"] == {}        # nothing stepped yet
+    assert agent.value_optimizer.state_dict()["param_groups"][0]["weight_decay"] == 1e-2 and agent.score_optimizer.state_dict()["param_groups"][0]["weight_decay"] == 1e-5

@@ -1,5 +1,5 @@
 """Microbenchmark of the large-M GEMM kernel variants (force codes of aid_gemm_force_kernel; high byte = tile map)."""
-import sys, os, time
+import os, sys, os, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R + "/active-inference-diffusion_amd"); sys.path.insert(0, R)
 import torch
 from aid_amd import _native as nat
@@ -18,7 +18,7 @@ for (M, N, K) in shapes:
     # a chain of distinct activations (as in situ: every GEMM reads a freshly produced A), weights re-used
     As = [torch.randn(M, K, device="cuda") for _ in range(3)]; W = torch.randn(N, K, device="cuda"); C = torch.empty(M, N, device="cuda")
     ref = None; line = f"M={M:6d} N={N:6d} K={K:5d}: "
-    for code in (4, 11, 11 + 256, 9, 9 + 256, 2, 0):
+    for code in ([int(c) for c in os.environ["BIG_GEMM_CODES"].split(",")] if os.environ.get("BIG_GEMM_CODES") else (4, 11, 11 + 256, 9, 9 + 256, 2, 0)):
         nat.gemm_force_kernel(code)
         i = [0]
         def fn():

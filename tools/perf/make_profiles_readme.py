@@ -22,6 +22,7 @@ w("| file | what |\n|---|---|\n"
   "| `r01_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (side stream off): the per-kernel averages that bench.py's single-stream live measurement is comparable with |\n"
   "| `r01_pmc_summary.json` | per-kernel averages of the PMC passes over ONE train_step (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) |\n"
   "| `gemm_big_r01.txt`, `gemm_shapes_r01.txt` | microbenchmarks of the GEMM kernel variants per shape (`tools/perf/big_gemm.py`, `gemm_shapes.py`); the dispatcher in `csrc/gemm_f32.hip` is set from them and from the in-situ chain `tools/perf/cold_chain.py` |\n"
+  "| `r01_gemm_big_stall_breakdown.txt` | SQ wave-state, LDS, L1 and L2 counters of `gemm_big_kernel` on the 25 600 x 1024 x 1024 MINE shape (`tools/perf/pmc_stall.sh`) and what they say |\n"
   "| `r01_other_configs.jsonl` | cfg 3 (Hopper, B=1024) and cfg 4 (pixels, B=256) train_step timings (`tools/perf/other_configs.py`) |\n")
 w("## Bench line (cfg 2: B=256, H=5, K=10, S=10, N=50, D=512, fp32)\n")
 w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/step; whole-step algorithmic rate {bench['train_step_algorithmic_tflops']:.1f} TFLOP/s "

@@ -4,7 +4,7 @@ R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from aid_amd import _native as nat
 nat.lib()
-NAMES = {0: "auto", 4: "tile64", 9: "big_pd2", 11: "big_pd1", 2: "ring64"}
+NAMES = {0: "auto", 4: "tile64", 9: "big_pd2", 11: "big_pd1", 2: "ring64", 13: "big_bk64"}
 def timeit(fn, reps):
     fn(); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -28,6 +28,6 @@ for (M, N, K) in shapes:
         nat.gemm(As[0], W, C, M, N, K, K, K, N); torch.cuda.synchronize()
         if ref is None: ref = C.clone()
         err = float((C - ref).abs().max() / ref.abs().max())
-        line += f"{NAMES[code & 255]}{'/x' if code >> 8 else ''}={dt*1e6:7.1f}us({2.0*M*N*K/dt/1e12:5.1f}TF{'' if err < 1e-5 else ' ERR%.1e' % err}) "
+        line += f"{NAMES.get(code & 255, str(code & 255))}{'/x' if code >> 8 else ''}={dt*1e6:7.1f}us({2.0*M*N*K/dt/1e12:5.1f}TF{'' if err < 1e-5 else ' ERR%.1e' % err}) "
     nat.gemm_force_kernel(0)
     print(line, flush=True)

@@ -110,6 +110,11 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
             if self.overlap_streams:
                 nat.gemm_low_lds_hint(False)
+                if dp:
+                    # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
+                    # host order on one internal stream, so issued later it would queue behind the policy all-reduce (which waits for the
+                    # whole EFE phase) and the score step + reverse loop would lose their overlap with the EFE.
+                    self.score_optimizer.allreduce_grads(async_op=True)
             else:
                 self.score_optimizer.step()
         # 3. policy

@@ -161,17 +161,21 @@ class ArenaOptimizer:
     def zero_grad(self, set_to_none: bool = False):
         self.arena.zero_grad()
 
+    _pending, _reduced = None, False
+
     def allreduce_grads(self, async_op: bool = False):
-        """Data parallel: average this group's gradient arena over ranks (one RCCL all-reduce). No-op on one GPU."""
+        """Data parallel: average this group's gradient arena over ranks (one RCCL all-reduce). No-op on one GPU.
+        async_op: the collective is enqueued now and step() waits for it (on whatever stream step() is called from)."""
         self._pending = parallel.allreduce_mean_(self.arena.grad, async_op=async_op)
+        self._reduced = True
         return self._pending
 
     def step(self, reduce: bool = True):
-        pend = getattr(self, "_pending", None)
-        if pend is not None:
-            pend.wait(); self._pending = None
-        elif reduce:
+        if self._pending is not None:
+            self._pending.wait()
+        elif reduce and not self._reduced:
             parallel.allreduce_mean_(self.arena.grad)
+        self._pending, self._reduced = None, False
         self.arena.step(self.param_groups[0]["lr"], self.param_groups[0]["weight_decay"], self.clip_norm, self.ema_decay)
 
     def state_dict(self):

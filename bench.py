@@ -136,6 +136,77 @@ def per_kernel_table(path):
     return agg
 
 
+def self_launch(n: int) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks ourselves, one child process per GPU with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set (what torch.distributed.run would set), and return their worst exit code.  This
+    parent never initialises the GPU (no HIP call, no torch.cuda.is_available()); the children are fresh interpreters, not re-execs.
+    Rank 0's stdout is ours, so its single JSON line is this command's output."""
+    import signal
+    import socket
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    base = dict(os.environ)
+    base.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    base.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc, alive = 0, set(range(n))
+    try:
+        while alive:
+            for r in sorted(alive):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[bench] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr, flush=True)
+                    for o in alive:
+                        procs[o].send_signal(signal.SIGTERM)
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_rehearsal(args, world, rank):
+    """No GPU, no hot path: the ranks rendezvous over gloo, run the barrier / max-over-ranks timing protocol and the arena
+    all-reduce helper on host tensors, and rank 0 prints a line whose `value` is null.  Checks the launcher, nothing else."""
+    import torch.distributed as dist
+    from aid_amd import parallel
+    if world > 1:
+        dist.init_process_group("gloo")
+    g = torch.full((1024,), float(rank + 1))
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        parallel.allreduce_mean_(g)
+    if world > 1:
+        dist.barrier()
+    tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    ok = bool(torch.allclose(g, torch.full((1024,), (world + 1) / 2.0)))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"rank {rank}: all-reduce mean gave {float(g[0])}")
+    if os.environ.get("AID_BENCH_DRY_FAIL_RANK", "") == str(rank):
+        raise SystemExit(3)
+    if rank == 0:
+        print(json.dumps({"metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": None, "unit": "train steps/s (batch=256 each)",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (DRY launcher rehearsal over gloo on CPU; not a result)",
+                          "config": {"workload": "launcher rehearsal", "global_batch": BATCH * world, "parallelism": f"dp{world}"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,11 +220,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: become the launcher (before anything touches the GPU) and exit with the ranks' code
+        sys.exit(self_launch(args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # AID_BENCH_REHEARSAL=gloo: rehearse the multi-rank glue (rendezvous, sharded sampling, gradient / normaliser / time-importance
     # collectives, barrier + max-over-ranks timing, rank-0 line) with several ranks sharing ONE GPU; the number it prints is not a result.
+    # AID_BENCH_REHEARSAL=dry: the launcher + rendezvous + timing protocol alone on a box WITHOUT a GPU (tests/test_bench_launcher_cpu.py):
+    # no hot path runs, `value` is null.
+    if os.environ.get("AID_BENCH_REHEARSAL", "") == "dry":
+        return dry_rehearsal(args, world, rank)
     rehearsal = os.environ.get("AID_BENCH_REHEARSAL", "") == "gloo"
     if rehearsal:
         local %= max(torch.cuda.device_count(), 1)

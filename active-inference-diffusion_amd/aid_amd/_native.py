@@ -242,7 +242,7 @@ def lib() -> C.CDLL:
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
                  "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
-                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace"):
+                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -753,6 +753,27 @@ def mine_train_step(dyn: AidDynamicsNet, dec: AidDecoderNet, epi: AidEpistemicNe
     check(lib().aid_mine_train_step(C.byref(dyn), C.byref(dec), C.byref(epi), C.byref(egrads), B, num_samples, _ptr(latents), _ptr(actions), C.byref(nz),
                                     int(bool(train)), C.c_uint64(seed), C.c_uint64(offset), C.c_float(alpha), _ptr(running_mean), _ptr(out),
                                     C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_mine_train_step")
+    return out
+
+
+def epistemic_value(dec: AidDecoderNet, epi: AidEpistemicNet, next_mean, next_logvar, running_mean, num_samples=5, noise=None, train=True,
+                    seed=0, offset=0, alpha=0.01, ws: Workspace = None):
+    """compute_epistemic_value: one gradient-free estimator forward. -> out [4] = mi, joint, marginal term, -clamp(mi, 0)"""
+    B = next_mean.shape[0]
+    nz = AidEfeNoise(); noise = noise or {}
+    for k, _ in AidEfeNoise._fields_:
+        v = noise.get(k)
+        if k == "perms" and v is not None:
+            assert v.dtype == torch.int32 and v.is_cuda and v.is_contiguous()
+            setattr(nz, k, v.data_ptr())
+        else:
+            setattr(nz, k, _ptr(v).value)
+    out = torch.zeros(4, device=next_mean.device, dtype=torch.float32)
+    ws = ws or Workspace(next_mean.device)
+    buf = ws.get(lib().aid_epistemic_value_workspace(C.byref(dec), B, num_samples))
+    check(lib().aid_epistemic_value(C.byref(dec), C.byref(epi), B, num_samples, _ptr(next_mean), _ptr(next_logvar), C.byref(nz), int(bool(train)),
+                                    C.c_uint64(seed), C.c_uint64(offset), C.c_float(alpha), _ptr(running_mean), _ptr(out),
+                                    C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_epistemic_value")
     return out
 
 

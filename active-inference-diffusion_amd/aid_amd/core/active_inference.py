@@ -386,14 +386,47 @@ class DiffusionActiveInference(nn.Module):
                     "policy_loss": info[0]})
         return efe, out
 
-    def compute_epistemic_value(self, next_latent_mean, next_latent_logvar, num_samples: int = 5):
-        raise NotImplementedError("the MINE estimator is evaluated inside compute_expected_free_energy_diffusion (aid_efe_step)")
+    def compute_epistemic_value(self, next_latent_mean: torch.Tensor, next_latent_logvar: torch.Tensor, num_samples: int = 5,
+                                noise: Optional[dict] = None) -> Tuple[torch.Tensor, Dict[str, float]]:
+        """active_inference.py:398-418: one gradient-free forward of the epistemic estimator (MINE lower bound on I(o; theta | z)) on
+        `num_samples` draws of N(mean, exp(logvar)) per row.  -> (clamp(mi, 0) expanded to [B], metrics).  Mutates
+        `epistemic_estimator.running_mean` as the reference does under no_grad.  (Inside the EFE rollout the same estimator runs batched
+        over the K trajectories in aid_efe_step; this is the stand-alone public method.)"""
+        mean = next_latent_mean.to(self.device).contiguous().float()
+        logvar = next_latent_logvar.to(self.device).float().expand_as(mean).contiguous()
+        B = mean.shape[0]
+        if self.is_pixel_observation:
+            if not hasattr(self, "epistemic_estimator"):
+                raise RuntimeError("pixel-mode compute_epistemic_value needs the ConvDecoder estimator (construct with pixel_shape)")
+            if not bool(torch.allclose(logvar, torch.full_like(logvar, float(np.log(0.1))))):
+                raise NotImplementedError("the pixel estimator entry point samples with the dynamics model's fixed log-variance ln 0.1")
+            dec, epi = self.observation_decoder._tab.get(self.observation_decoder), self._pepi_tab.get(self.epistemic_estimator)
+            mine = nat.pixel_epistemic_value(dec, epi, mean, 1, num_samples, noise=noise, train=self.training, seed=self.noise.seed,
+                                             offset=self.noise.next_offset(), ws=self._ws)        # [1][4] = joint, marginal, t_exp, mi
+            joint, marg, texp, mi = mine[0].cpu().tolist()
+            rm = float(self._running_mean[0])
+            rm = texp if rm == 0.0 else 0.01 * texp + (1.0 - 0.01) * rm
+            self._running_mean.fill_(rm)
+        else:
+            if noise is None:
+                hook = getattr(self.noise, "mine_train", None)        # same draws, same order as one estimator forward
+                noise = hook(B, self.latent_dim, num_samples) if hook is not None else None
+            out = nat.epistemic_value(self.decoder_table(), self.epistemic_table(), mean, logvar, self._running_mean, num_samples=num_samples,
+                                      noise=noise, train=self.epistemic_estimator.training, seed=self.noise.seed, offset=self.noise.next_offset(),
+                                      alpha=self.epistemic_estimator.alpha, ws=self._ws)
+            mi, joint, marg, _ = out.cpu().tolist()
+            rm = float(self._running_mean[0])
+        value = torch.full((B,), max(mi, 0.0), device=self.device)
+        return value, {"epistemic/mi_estimate": mi, "epistemic/joint_term": joint, "epistemic/marginal_term": marg, "epistemic/running_mean": rm}
 
     def train_epistemic_estimator(self, latents: torch.Tensor, actions: torch.Tensor, next_latents: torch.Tensor = None, noise: Optional[dict] = None):
         """active_inference.py:420-445: one optimiser step of the MINE estimator on -clamp(MI lower bound, 0).  Needs
         `self.epistemic_optimizer` (the agents attach the one base_agent.py:134-139 defines).  -> (mi, metrics of floats)"""
         if self.is_pixel_observation:
-            raise NotImplementedError("pixel-mode epistemic estimator (ConvDecoder) is SURVEY 8(f) rank 1: not built")
+            # the pixel estimator is built for inference (aid_pixel_epistemic_value, what the reference's EFE runs under no_grad); its
+            # backward through the ConvDecoder features / attention aggregator is not, and the reference cannot train it either (SURVEY D3)
+            raise NotImplementedError("train_epistemic_estimator: the pixel-mode estimator is inference-only here (its training step raises "
+                                      "in the reference too, SURVEY D3); use compute_epistemic_value / ai.pixel_epistemic for its value")
         opt = getattr(self, "epistemic_optimizer", None)
         if opt is None:
             raise AttributeError("epistemic_optimizer is not set (the reference's concrete agents never create it, SURVEY D3); "

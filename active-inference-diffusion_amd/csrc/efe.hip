@@ -29,14 +29,16 @@ __global__ void reparam_kernel(const float* __restrict__ mean, const float* __re
     if (i < n) out[i] = mean[i] + eps[i] * sd;
 }
 // z_all[(k*S+s)*B + b] = next_mean[k*B + b] + eps * std          (active_inference.py:1009-1014)
-__global__ void mine_sample_kernel(const float* __restrict__ nm, const float* __restrict__ eps, float sd, float* __restrict__ z,
-                                   int K, int S, int B, int L) {
+// lv: per-element log-variance of the mean rows (compute_epistemic_value's next_latent_logvar), or null => the constant `sd`
+__global__ void mine_sample_kernel(const float* __restrict__ nm, const float* __restrict__ eps, float sd, const float* __restrict__ lv,
+                                   float* __restrict__ z, int K, int S, int B, int L) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t n = (size_t)K * S * B * L;
     if (i >= n) return;
     const int l = i % L; const size_t r = i / L;
     const int b = r % B; const int k = (r / B) / S;
-    z[i] = nm[((size_t)k * B + b) * L + l] + eps[i] * sd;
+    const size_t src = ((size_t)k * B + b) * L + l;
+    z[i] = nm[src] + eps[i] * (lv ? expf(0.5f * lv[src]) : sd);
 }
 // zp = z + normalize(delta) * eps_scale (F.normalize: / max(||d||, 1e-12))   (:962)
 __global__ void perturb_kernel(const float* __restrict__ z, const float* __restrict__ d, const float* __restrict__ scale,
@@ -177,7 +179,8 @@ __global__ void randperm_blocks_kernel(const float* __restrict__ keys, int32_t* 
 struct PixelBackend { const AidConvDecoder* dec; const AidPixelEpistemicNet* epi; const float* attn_mask; uint64_t seed, offset; };
 static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int K, int S, int B, const float* next_mean,
                         const float* z_eps, const float* delta, const float* proj_mask, const float* mine_mask, const int32_t* perms,
-                        bool train, float* mine_out, Workspace& ws, hipStream_t s, const PixelBackend* px = nullptr) {
+                        bool train, float* mine_out, Workspace& ws, hipStream_t s, const PixelBackend* px = nullptr,
+                        const float* next_logvar = nullptr) {
     const int L = e.L, O = px ? 1 : e.O;
     const size_t R = (size_t)K * S * B;
     const int Rm = (int)R;
@@ -191,7 +194,7 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     LlaSave pj; lla_alloc(Rm, e.jp0.out, ws, pj);
     AID_WS_OK(ws);
     const float sd = sqrtf(0.1f);   // exp(0.5 * ln 0.1)  (predict_next_latent :463)
-    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), z_all, K, S, B, L);
+    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), next_logvar, z_all, K, S, B, L);
     (void)sd;
     const int FE = e.fe4.out, CW = e.jp4.out + e.lp2.out;
     if (px) {   // pixel branch: ConvDecoder finite differences -> 5x5 convs -> attention aggregator (conv.hip)
@@ -448,7 +451,7 @@ int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, con
     la_alloc(Rm, MH, true, ws, mj0); la_alloc(Rm, e.mn3.out, true, ws, mj1); la_alloc(Rm, MH, true, ws, mm0); la_alloc(Rm, e.mn3.out, true, ws, mm1);
     float* tj = ws.f32(R); float* tm = ws.f32(R); float* red = ws.f32(8);
     AID_WS_OK(ws);
-    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), z_all, 1, S, B, L);
+    LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), (const float*)nullptr, z_all, 1, S, B, L);
     AID_TRY(decoder_fwd(*dec, Rm, z_all, L, nullptr, fz, O, ws, s));                     // decoder: eval mode, no gradient (:949-953)
     for (int j = 0; j < 4; ++j) {
         LAUNCH1D(perturb_kernel, R, s, z_all, delta + (size_t)j * R * L, e.perturbation_scale, zp, R, L);
@@ -531,6 +534,50 @@ int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, con
         hipLaunchKernelGGL(scale_out_kernel, dim3(1), dim3(64), 0, s, ge.perturbation_scale, acc, e.perturbation_scale);
         AID_LAUNCH_CHECK();
     }
+    return AID_OK;
+}
+
+size_t aid_epistemic_value_workspace(const AidDecoderNet* dec, int B, int S) {
+    if (!dec || B <= 0 || S <= 0) return 0;
+    const size_t R = (size_t)S * B;
+    return mine_ws_bytes(*dec, 1, S, B) + sizeof(float) * R * (size_t)(5 * dec->L + 5 * 512 + 1) + sizeof(int32_t) * R + (1 << 20);
+}
+
+int aid_epistemic_value(const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, int S, const float* next_mean, const float* next_logvar,
+                        const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset, float alpha, float* running_mean, float* out4,
+                        void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dec && epi && next_mean && next_logvar && noise && running_mean && out4, AID_E_NULL, "aid_epistemic_value: null argument");
+    AID_REQUIRE(B > 0 && S > 0 && B <= 2048, AID_E_SHAPE, "aid_epistemic_value: B=%d S=%d", B, S);
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const AidEpistemicNet& e = *epi;
+    const size_t R = (size_t)S * B; const int L = e.L;
+    uint64_t ctr = offset;
+    auto draw = [&](const float* given, size_t cnt, int kind, float p, const float** out) -> int {
+        if (given) { *out = given; return AID_OK; }
+        float* buf = ws.f32(cnt); AID_WS_OK(ws);
+        AID_TRY(philox_fill(buf, cnt, kind, p, seed, ctr, s)); ctr += (cnt + 3) / 4; *out = buf; return AID_OK;
+    };
+    const float *z_eps, *delta, *pmask = nullptr, *mmask = nullptr;
+    AID_TRY(draw(noise->mine_z_eps, R * L, 0, 0.f, &z_eps));
+    AID_TRY(draw(noise->mine_delta, 4 * R * L, 0, 0.f, &delta));
+    if (train) {
+        AID_TRY(draw(noise->proj_mask, R * e.jp0.out, 2, 0.1f, &pmask));
+        AID_TRY(draw(noise->mine_mask, 4 * R * e.mn0.out, 2, 0.1f, &mmask));
+    }
+    const int32_t* perms = noise->perms;
+    if (!perms) {
+        const float* keys; AID_TRY(draw(nullptr, R, 1, 0.f, &keys));
+        int32_t* pb = (int32_t*)ws.raw(sizeof(int32_t) * R); AID_WS_OK(ws);
+        int P2 = 1; while (P2 < B) P2 <<= 1;
+        hipLaunchKernelGGL(randperm_blocks_kernel, dim3((unsigned)S), dim3(256), (size_t)P2 * 8, s, keys, pb, B, P2);
+        AID_LAUNCH_CHECK(); perms = pb;
+    }
+    float* red = ws.f32(8); AID_WS_OK(ws);
+    AID_TRY(mine_forward(*dec, e, 1, S, B, next_mean, z_eps, delta, pmask, mmask, perms, train != 0, red, ws, s, nullptr, next_logvar));
+    // running-mean EMA of this one call, then out4 = {mi, joint, marginal term, -clamp(mi, 0)}: the caller negates slot 3
+    hipLaunchKernelGGL(mine_train_finish_kernel, dim3(1), dim3(64), 0, s, red, alpha, running_mean, out4);
+    AID_LAUNCH_CHECK();
     return AID_OK;
 }
 

@@ -279,6 +279,15 @@ size_t aid_mine_train_workspace(const AidDecoderNet* dec, const AidDynamicsNet* 
 int aid_mine_train_step(const AidDynamicsNet* dyn, const AidDecoderNet* dec, const AidEpistemicNet* epi, const AidEpistemicNet* grads, int B, int S,
                         const float* latents, const float* actions, const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset,
                         float alpha, float* running_mean, float* out4, void* ws, size_t ws_bytes, void* stream);
+/* DiffusionActiveInference.compute_epistemic_value (active_inference.py:398-418) = one gradient-free forward of the state-mode
+ * FunctionSpaceEpistemicEstimator (:995-1063): S samples of N(next_mean, exp(next_logvar)) per row, finite-difference decoder features,
+ * MINE statistics on joint / row-permuted marginal.  next_mean, next_logvar [B,L].  noise members as aid_mine_train_step (NULL => device
+ * Philox).  running_mean (device scalar) gets the EMA update the reference applies even under no_grad.
+ * out4 = {mi, joint term, marginal term, -clamp(mi, 0)}. */
+size_t aid_epistemic_value_workspace(const AidDecoderNet* dec, int B, int S);
+int aid_epistemic_value(const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, int S, const float* next_mean, const float* next_logvar,
+                        const AidEfeNoise* noise, int train, uint64_t seed, uint64_t offset, float alpha, float* running_mean, float* out4,
+                        void* ws, size_t ws_bytes, void* stream);
 /* Same as aid_efe_step with one more output: next_means_out [H][K*B][L] (or NULL), the dynamics means the estimator samples around. */
 int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const AidDynamicsNet* dyn, const AidRewardNet* rew,
                     const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,

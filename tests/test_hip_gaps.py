@@ -1,0 +1,115 @@
+"""GPU: rows of SURVEY 8(a) that round 1 covered only indirectly, each against the reference's own numbers (tests/golden) or the oracle:
+A15 FreeEnergyComputation.compute_loss, A0' RunningMeanStd (aid_reward_normalize), A10 compute_epistemic_value as a public method."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import aid_oracle as orc
+from oracle.noise import NoiseStream
+from oracle.weights import draw_params, param_specs
+from parity_noise import ParityNoise, dev
+
+
+def _golden(golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, f"state_{tag}.npz"))
+    O, A, L, D, N = (int(g[k]) for k in ("O", "A", "L", "D", "N"))
+    specs = param_specs(O, A, L, D, N)
+    return g, draw_params(specs, int(g["weights_key"]), orc.schedule_tables(N))
+
+
+@pytest.mark.parametrize("tag", ["hc", "hop"])
+def test_free_energy_compute_loss_golden(golden_dir, tag):
+    """core/free_energy.py:30-91 at current_time=0.5, score network in eval mode: the reference's value (golden `free_energy_t05`) and
+    every entry of the info dict against the oracle."""
+    from aid_amd.core.free_energy import FreeEnergyComputation
+    from aid_amd.models import LatentScoreNetwork
+    g, p = _golden(golden_dir, tag)
+    L, D = int(g["L"]), int(g["D"])
+    net = LatentScoreNetwork(latent_dim=L, observation_dim=L, hidden_dim=D).cuda()
+    pre = "latent_score_network."
+    net.load_state_dict({k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}, strict=True)
+    net.eval()
+    fe = FreeEnergyComputation().cuda()
+    z, obs = dev(g["z"]), dev(g["obs"])
+    loss, info = fe.compute_loss(z, obs, None, net, current_time=0.5)
+    np.testing.assert_allclose(float(loss), float(g["free_energy_t05"]), rtol=1e-4)      # losses rtol 1e-4
+    ref, rinfo = orc.free_energy_loss(p, torch.from_numpy(g["z"]), torch.from_numpy(g["obs"]), torch.zeros(()), 0.5)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=1e-4)
+    for k, v in rinfo.items():
+        if k in info:
+            np.testing.assert_allclose(float(info[k]), float(v), rtol=1e-4, atol=1e-7, err_msg=k)
+    # update_precision (:93-101): log-precision nudged by 0.01 * clamp(err, -1, 1), clamped to [-3, 3]
+    fe.update_precision(torch.tensor(5.0), torch.tensor(1.0)); np.testing.assert_allclose(float(fe.log_precision), 0.01, rtol=1e-6)
+    fe.update_precision(torch.tensor(0.25), torch.tensor(0.5)); np.testing.assert_allclose(float(fe.log_precision), 0.0075, rtol=1e-5)
+
+
+def test_reward_normalizer_golden_sequence(golden_dir):
+    """agents/base_agent.py:24-52: four update()s of the reference's RunningMeanStd (golden `rms_seq` = its mean, var, count after each) and
+    the normalised batch.  The reference takes the batch moments with numpy in float32 and merges in float64; the kernel takes them in
+    float64 throughout, hence 1e-6 rather than 1e-12 on mean / var (count is exact)."""
+    from aid_amd.agents.base_agent import RunningMeanStd
+    m = np.load(os.path.join(golden_dir, "misc.npz"))
+    rms = RunningMeanStd(shape=(), device="cuda")
+    ref = orc.RunningMeanStd()
+    for i in range(4):
+        x = NoiseStream(90 + i).randn(16) * (i + 1) + i
+        out = rms.update_and_normalize(dev(x))
+        ref.update(x)
+        mean, var, count = m["rms_seq"][i]
+        np.testing.assert_allclose(rms.mean, mean, rtol=1e-6, atol=1e-9)
+        np.testing.assert_allclose(rms.var, var, rtol=1e-6)
+        assert rms.count == count
+        np.testing.assert_allclose(out.cpu().numpy(), ref.normalize(x), rtol=1e-5, atol=1e-6)
+    # data parallel form: statistics from the gathered global batch, the local slice normalised
+    rms2 = RunningMeanStd(shape=(), device="cuda"); ref2 = orc.RunningMeanStd()
+    x = NoiseStream(99).randn(32)
+    out = rms2.update_and_normalize(dev(x[8:16]), dev(x)); ref2.update(x)
+    np.testing.assert_allclose([rms2.mean, rms2.var, rms2.count], [ref2.mean, ref2.var, ref2.count], rtol=1e-6)
+    np.testing.assert_allclose(out.cpu().numpy(), ref2.normalize(x[8:16]), rtol=1e-5, atol=1e-6)
+
+
+class _Box:
+    def __init__(self, shape):
+        self.shape = shape
+
+
+@pytest.mark.parametrize("B,S,D", [(8, 5, 64), (256, 10, 512)])
+def test_compute_epistemic_value_vs_oracle(B, S, D):
+    """core/active_inference.py:398-418 as a public method: MI lower bound, joint / marginal terms, the running-mean EMA over two
+    successive calls (it is mutated under no_grad), with a row- and column-dependent log-variance."""
+    import aid_amd
+    O, A, N = 17, 6, 4
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=2, latent_dim=O, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+
+    class Env:
+        observation_space, action_space = _Box((O,)), _Box((A,))
+    agent = aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=16))
+    ai = agent.active_inference
+    p = draw_params(param_specs(O, A, O, D, N), 19, orc.schedule_tables(N))
+    sd0 = ai.state_dict()
+    ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+    ns = NoiseStream(5)
+    mean = ns.randn(B, O); logvar = (np.log(0.1) + 0.3 * ns.randn(B, O)).astype(np.float32)
+    ai.noise = ParityNoise(321)
+    ref_noise = NoiseStream(321)
+    rm = float(p["epistemic_estimator.running_mean"])
+    for call in range(2):
+        val, met = ai.compute_epistemic_value(dev(mean), dev(logvar), num_samples=S)
+        clamped, mi, joint, tlog, rm = orc.epistemic_value(p, torch.from_numpy(mean), torch.from_numpy(logvar), rm, ref_noise, S, True)
+        assert val.shape == (B,) and float(val.min()) == float(val.max())
+        # the MI is a difference of two O(1) batch means: absolute tolerance on the terms, SURVEY's 1e-4 relative on each of them
+        np.testing.assert_allclose(met["epistemic/joint_term"], float(joint), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(met["epistemic/marginal_term"], float(tlog), rtol=1e-4, atol=2e-6)
+        np.testing.assert_allclose(met["epistemic/mi_estimate"], float(mi), rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(float(val[0]), float(clamped), rtol=1e-4, atol=5e-6)
+        np.testing.assert_allclose(met["epistemic/running_mean"], rm, rtol=1e-5)
+    np.testing.assert_allclose(float(ai.state_dict()["epistemic_estimator.running_mean"]), rm, rtol=1e-5)
+    # eval mode (no dropout draws) runs too and is deterministic given the noise
+    ai.eval(); ai.noise = ParityNoise(7)
+    v1, _ = ai.compute_epistemic_value(dev(mean), dev(logvar), num_samples=S)
+    assert np.isfinite(float(v1[0]))

@@ -129,3 +129,24 @@ def test_cpu_device_is_rejected_loudly():
     cfg = aid_amd.ActiveInferenceConfig(device="cpu", latent_dim=17, hidden_dim=64)
     with pytest.raises(RuntimeError, match="no CPU path"):
         aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=8))
+
+
+def test_make_schedule_matches_reference_tables(golden_dir):
+    """A2 (core/diffusion.py:106-144): the PRODUCT's schedule builder against the reference's buffers (misc.npz `sched_*`: cosine and
+    linear, N in {10, 25, 50, 100}), bit for bit, and the [N,5] p_sample coefficient table derived from them against the oracle's."""
+    import os
+    from aid_amd.core.diffusion import make_schedule
+    from oracle import aid_oracle as orc
+    m = np.load(os.path.join(golden_dir, "misc.npz"))
+    keys = [str(k) for k in m["sched_keys"]]
+    for N in (10, 25, 50, 100):
+        for kind in ("cosine", "linear"):
+            tab = make_schedule(N, kind)
+            assert sorted(tab) == keys
+            np.testing.assert_array_equal(torch.stack([tab[k] for k in keys]).numpy(), m[f"sched_{kind}_{N}"], err_msg=f"{kind} {N}")
+            c1 = tab["betas"] * torch.sqrt(tab["alphas_cumprod_prev"]) / (1.0 - tab["alphas_cumprod"])
+            c2 = (1.0 - tab["alphas_cumprod_prev"]) * torch.sqrt(tab["alphas"]) / (1.0 - tab["alphas_cumprod"])
+            coefs = torch.stack([tab["sqrt_one_minus_alphas_cumprod"], 1.0 / torch.sqrt(tab["alphas"]), c1, c2, torch.sqrt(tab["posterior_variance"])], dim=1)
+            np.testing.assert_array_equal(coefs.numpy(), orc.p_sample_coefs(orc.schedule_tables(N, kind)).numpy())
+    with pytest.raises(ValueError):
+        make_schedule(10, "sigmoid")

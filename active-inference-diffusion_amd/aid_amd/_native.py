@@ -114,7 +114,7 @@ class AidDiffusionParams(C.Structure):
 
 
 class AidElboNoise(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2", "d_obs_out")]
+    _fields_ = [(n, C.c_void_p) for n in ("t", "eps", "prior_eps", "score_mask", "gp_mask", "dec_mask0", "dec_mask1", "dec_mask2", "d_obs_out", "mean_t")]
 
 
 class AidSNConv(C.Structure):
@@ -460,15 +460,27 @@ def lambda_returns(rewards, next_values, dones, gamma=0.99, lam=0.95, n_steps=5)
 
 
 def value_step(val, vgrads, latents, next_latents, rewards, dones, gamma=0.99, lam=0.95, n_steps=5, ws: Workspace = None):
-    """-> (loss device scalar, targets [B]); gradients accumulate into vgrads."""
-    B = latents.shape[0]
+    """-> (loss device scalar, targets [B]); gradients accumulate into vgrads.  next_latents / rewards / dones may hold more rows than
+    latents: the extra rows are a lambda-return halo (aid_value_step_ex)."""
+    B, Bx = latents.shape[0], next_latents.shape[0]
+    assert rewards.shape[0] == Bx and dones.shape[0] == Bx and Bx >= B
     loss = torch.zeros(1, device=latents.device); targets = torch.empty(B, device=latents.device)
     ws = ws or Workspace(latents.device)
     buf = ws.get(lib().aid_value_step_workspace(C.byref(val), B))
-    check(lib().aid_value_step(C.byref(val), C.byref(vgrads), B, _ptr(latents), _ptr(next_latents), _ptr(rewards), _ptr(dones), C.c_float(gamma),
-                               C.c_float(lam), n_steps, _ptr(targets), _ptr(loss), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
-          "aid_value_step")
+    check(lib().aid_value_step_ex(C.byref(val), C.byref(vgrads), B, Bx, _ptr(latents), _ptr(next_latents), _ptr(rewards), _ptr(dones), C.c_float(gamma),
+                                  C.c_float(lam), n_steps, _ptr(targets), _ptr(loss), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_value_step_ex")
     return loss, targets
+
+
+def sample_time(time_importance, first_call: bool, B: int, seed=0, offset=0, ws: Workspace = None):
+    """_importance_sample_time alone (device Philox) -> t [B]"""
+    t = torch.empty(B, device=time_importance.device, dtype=torch.float32)
+    ws = ws or Workspace(time_importance.device)
+    buf = ws.get(8 * B + 256)
+    check(lib().aid_sample_time(_ptr(time_importance), int(bool(first_call)), B, C.c_uint64(seed), C.c_uint64(offset), _ptr(t),
+                                C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_sample_time")
+    return t
 
 
 def dynamics_step(dyn, dgrads, latents, actions, next_latents, ws: Workspace = None):
@@ -614,15 +626,15 @@ def reward_normalize_global(stats_src, rewards, state):
     return out
 
 
-def gemm_low_lds_hint(on: bool):
-    """Host-side dispatch hint for the launches enqueued while it is set: small GEMMs use the 35 KB-LDS panel variant so that they can
-    share CUs with a large GEMM running on another stream (speed only)."""
-    check(lib().aid_gemm_force_kernel(512 if on else 0), "aid_gemm_force_kernel")
+def stream_hint(stream: "torch.cuda.Stream", flags: int):
+    """Per-stream dispatch hint (aid_stream_hint): bit 0 = small GEMMs launched on `stream` use the 35 KB-LDS panel variant so that they
+    can share CUs with a large GEMM running on another stream (speed only).  State lives with the stream, not the process."""
+    check(lib().aid_stream_hint(C.c_void_p(stream.cuda_stream), int(flags)), "aid_stream_hint")
 
 
 def gemm_force_kernel(k: int):
     """Kernel override for benches / tests (codes: include/aid_hip.h, aid_gemm_force_kernel): 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 split-K,
-    8 thin TN, 9 / 11 big (prefetch 2 / 1), 10 skinny (M <= 32), 14 panel128, 15 panel64; +256 XCD-grouped tile map; 512 low-LDS hint."""
+    8 thin TN, 9 / 11 big (prefetch 2 / 1), 10 skinny (M <= 32), 14 panel128, 15 panel64; +256 XCD-grouped tile map.  Process-wide: tests only."""
     check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")
 
 

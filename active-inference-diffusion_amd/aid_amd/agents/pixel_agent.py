@@ -230,7 +230,8 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         self.policy_optimizer.step()
         # value (the pixel agent reuses next_latents, pixel_agent.py:364-371) and dynamics
         self.value_optimizer.zero_grad()
-        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
+        nl_x, nrew_x, dones_x = parallel.halo_from_next_rank(next_latents, nrew, dones, rows=5) if dp else (next_latents, nrew, dones)
+        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, nl_x, nrew_x, dones_x,
                                        cfg.discount_factor, 0.95, 5, ws=ai._ws)
         self.value_optimizer.step()
         self.dynamics_optimizer.zero_grad()

@@ -51,6 +51,9 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:
             self._comm = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its small dependent kernels get workgroup slots as the big GEMMs of the main stream retire (-1.5 % per step)
+            # everything this stream launches runs underneath the EFE's 25 600-row GEMMs: its small GEMMs take the 35 KB-LDS variant so
+            # that they co-reside (a property of the stream, aid_stream_hint - no process-wide dispatch state)
+            nat.stream_hint(self._comm, 1 if self.side_low_lds else 0)
         return self._comm
 
     def enable_data_parallel(self):
@@ -104,12 +107,9 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             for t_ in (obs, nrew, latents, next_obs):
                 t_.record_stream(side)
         with torch.cuda.stream(side):
-            if self.overlap_streams and self.elbo_low_lds:
-                nat.gemm_low_lds_hint(True)
             self.score_optimizer.zero_grad()
             elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
             if self.overlap_streams:
-                nat.gemm_low_lds_hint(False)
                 if dp:
                     # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
                     # host order on one internal stream, so issued later it would queue behind the policy all-reduce (which waits for the
@@ -125,8 +125,6 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         with torch.cuda.stream(side):
             if self.overlap_streams:
                 self.score_optimizer.step()            # data parallel: the 109 MB RCCL all-reduce runs here, off the critical path
-            if self.overlap_streams:
-                nat.gemm_low_lds_hint(True)      # 35 KB panel variant: these launches must co-reside with the EFE's 25 600-row GEMMs
             if self._want_prefetch():
                 N, train = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
                 hook = lambda: ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
@@ -138,8 +136,6 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                                   "params": (self.score_optimizer.arena.step_count, ai.param_version), "B": B, "train": train}
             else:
                 next_latents = ai.denoise_only(next_obs, ws=ws)
-            if self.overlap_streams:
-                nat.gemm_low_lds_hint(False)
         if self.overlap_streams:
             next_latents.record_stream(main)
             for v in elbo_info.values():
@@ -151,7 +147,8 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                     v.record_stream(main)
             main.wait_stream(side)
         self.value_optimizer.zero_grad()
-        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones,
+        nl_x, nrew_x, dones_x = parallel.halo_from_next_rank(next_latents, nrew, dones, rows=5) if dp else (next_latents, nrew, dones)
+        value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, nl_x, nrew_x, dones_x,
                                        cfg.discount_factor, 0.95, 5, ws=ai._ws)
         self.value_optimizer.step()
         epi_metrics = {}
@@ -178,7 +175,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     # The reference trains the MINE estimator when `total_steps % 5 == 0` (state_agent.py:216-222) but its concrete agents never create
     # the optimiser that branch needs, so it raises there.  Opt in with 5 to get the behaviour the code intends.
     train_epistemic_every = 0
-    elbo_low_lds = True            # side-stream ELBO launches use the 35 KB panel variant too
+    side_low_lds = True            # side-stream launches (ELBO, score step, reverse loop) use the 35 KB panel variant
 
     # -- cross-step prefetch of the next minibatch's belief latents ------------------------------------------------------------
     prefetch_next_batch = True     # False: never look ahead (every train_step samples and denoises its own minibatch)

@@ -485,15 +485,26 @@ class DiffusionActiveInference(nn.Module):
                                               fd_mask if self.feature_decoder.training else None, d_obs, ws)
             noise = dict(noise or {}); noise["d_obs_out"] = d_obs
         self._last_d_obs = d_obs
+        dp_run = parallel.is_dp()
+        t_all = None
+        if dp_run:
+            # Global-batch semantics for the two batch statistics of the ELBO: t is drawn first so that its all-gather
+            # yields (a) the global mean behind the KL annealing weight exp(-5 mean t) and (b) the t column of the rank-major
+            # time-importance replay below.
+            noise = dict(noise or {})
+            if noise.get("t") is None:
+                noise["t"] = nat.sample_time(self.time_importance_weights, first, B, self.noise.seed, self.noise.next_offset(4 * B), ws)
+            t_all = parallel.allgather_cat(noise["t"].contiguous())
+            noise["mean_t"] = t_all.mean().reshape(1)
         metrics, t, per = nat.elbo_step(self.latent_score_network.table(), self.latent_score_network.grad_table(), self.latent_diffusion.table(),
                                         self.latent_diffusion.grad_table(), None if self.is_pixel_observation else self.decoder_table(),
                                         self.reward_table(), observations, rewards, latents,
                                         self.time_importance_weights, first, noise=noise, train=self.latent_score_network.training, recon_preset=preset,
                                         kl_weight=c.kl_weight, diffusion_weight=c.diffusion_weight, reward_weight=c.reward_weight, gp_weight=0.1,
                                         seed=self.noise.seed, offset=self.noise.next_offset(), ws=ws,
-                                        defer_time_importance=parallel.is_dp())
-        if parallel.is_dp():   # one global, rank-major order for the order-dependent EMA
-            nat.time_importance_update(self.time_importance_weights, parallel.allgather_cat(t), parallel.allgather_cat(per), first)
+                                        defer_time_importance=dp_run)
+        if dp_run:   # one global, rank-major order for the order-dependent EMA
+            nat.time_importance_update(self.time_importance_weights, t_all, parallel.allgather_cat(per), first)
         info = {k: metrics[i] for i, k in enumerate(nat.ELBO_METRICS) if k != "loss"}
         self._last_elbo = {"t": t, "per_sample_losses": per}
         return metrics[8], info

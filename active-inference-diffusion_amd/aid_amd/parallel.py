@@ -6,8 +6,12 @@ contiguous arena (arena.py) that exchange is a single all-reduce per group (109 
 no bucketing or flatten/unflatten copies.  The three batch-coupled pieces get global semantics with tiny collectives:
   * reward normaliser: all-gather the B rewards of each rank, update the fp64 statistics from the global batch;
   * time-importance EMA: all-gather (t, per-sample loss) and replay the sequential EMA in global (rank-major) order;
-  * lambda-returns: per-rank windows (identical to the reference run on each shard; differs from one 8x-larger batch
-    only at the 7 shard seams) — stated choice, no halo exchange.
+  * lambda-returns (minibatch order is time, window 5): a 5-row halo — every rank appends the first n rows of the next rank's
+    (next_latents, normalised rewards, dones) to its own, so the windows of its last rows see the neighbours they would see in
+    one global batch (`halo_from_next_rank`); the last rank gets none.  N ranks x B rows then equal one N*B-row step
+    (tests/test_hip_dp_equiv.py).
+  * KL annealing weight exp(-5 mean t): mean over the all-gathered t (the same gather feeds the time-importance replay).
+  * MINE statistics stay per rank: gradient-free, they enter only the logged EFE value and the estimator's running mean.
 Nothing here is GPU-specific: the same code runs on CPU tensors under the gloo backend (tests/test_parallel_gloo.py).
 """
 from __future__ import annotations
@@ -66,3 +70,20 @@ def shard_indices(global_indices, rank_: Optional[int] = None, world_: Optional[
         raise ValueError(f"global batch {n} is not divisible by world size {w}")
     b = n // w
     return global_indices[r * b:(r + 1) * b]
+
+
+def halo_from_next_rank(*tensors: torch.Tensor, rows: int = 5):
+    """For each [B, ...] tensor: this rank's rows followed by the first `rows` rows of rank+1's (nothing appended on the last rank).
+    One small all-gather per tensor group: the heads of all ranks are gathered, each rank keeps its successor's."""
+    if not is_dp():
+        return tensors
+    w, r = dist.get_world_size(), dist.get_rank()
+    out = []
+    for x in tensors:
+        n = min(rows, x.shape[0])
+        heads = allgather_cat(x[:n].contiguous().reshape(1, n, -1))          # [W, n, F]
+        if r + 1 < w:
+            out.append(torch.cat([x, heads[r + 1].reshape((n,) + tuple(x.shape[1:]))], dim=0).contiguous())
+        else:
+            out.append(x)
+    return tuple(out)

@@ -85,7 +85,8 @@ inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
     return g;
 }
 int gemm_f32(const GemmArgs& g, hipStream_t s);
-void gemm_force_kernel(int k);   // benchmarking knob, 0 = automatic selection
+void gemm_force_kernel(int k);   // tests / benches only: process-wide kernel override, 0 = automatic selection
+int stream_hint_set(hipStream_t s, int flags);   // per-stream dispatch hints (bit 0: prefer low-LDS small-problem kernels)
 // y = x W^T + b with optional activation: the torch.nn.Linear forward.
 inline int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
                       int act, hipStream_t s, float* preact = nullptr, const float* residual = nullptr, int ldr = 0,

@@ -74,13 +74,15 @@ __global__ void elbo_lambda_grad_kernel(const float* __restrict__ dlamA, const f
 // KL-ish prior term (diffusion.py:146-152, active_inference.py:466-476,609-611) + gradients of the learnable prior
 __global__ void kl_prior_kernel(const float* __restrict__ z, const float* __restrict__ peps, const float* __restrict__ pm,
                                 const float* __restrict__ pls, const float* __restrict__ t, float kcfg, float* __restrict__ dpm,
-                                float* __restrict__ dpls, float* __restrict__ out /*kl, klw, mean_t*/, int B, int L) {
+                                float* __restrict__ dpls, float* __restrict__ out /*kl, klw, mean_t*/, int B, int L,
+                                const float* __restrict__ mean_t_global) {
     __shared__ float sh[16];
     __shared__ float s_klw;
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) acc += t[b];
     const float st = blk_sum(acc, sh);
-    if (threadIdx.x == 0) { const float mt = st / (float)B; s_klw = expf(-5.0f * mt); out[1] = s_klw; out[2] = mt; }
+    // data parallel: the annealing weight exp(-5 mean t) (:611) is a statistic of the GLOBAL batch, handed in by the caller
+    if (threadIdx.x == 0) { const float mt = mean_t_global ? mean_t_global[0] : st / (float)B; s_klw = expf(-5.0f * mt); out[1] = s_klw; out[2] = mt; }
     __syncthreads();
     const float c = kcfg * s_klw / (float)B;
     acc = 0.f;
@@ -380,6 +382,20 @@ size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec,
     return n + (1 << 16);
 }
 
+int aid_sample_time(const float* time_importance, int first_call, int B, uint64_t seed, uint64_t offset, float* t_out, void* wsp,
+                    size_t ws_bytes, void* stream) {
+    AID_REQUIRE(time_importance && t_out, AID_E_NULL, "aid_sample_time: null argument");
+    AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_sample_time: B=%d", B);
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    float* u1 = ws.f32(B); float* u2 = ws.f32(B); AID_WS_OK(ws);
+    AID_TRY(philox_fill(u1, B, 1, 0.f, seed, offset, s));
+    AID_TRY(philox_fill(u2, B, 1, 0.f, seed, offset + (uint64_t)(B + 3) / 4, s));
+    hipLaunchKernelGGL(sample_time_kernel, dim3(1), dim3(256), 0, s, time_importance, first_call, u1, u2, t_out, B);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
 int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDiffusionParams* dp, const AidDiffusionParams* dgrads,
                   const AidDecoderNet* dec, const AidRewardNet* rew, int B, const float* obs, const float* rewards, const float* latents,
                   const AidElboNoise* noise, const AidElboCfg* cfg, float* time_importance, float* t_out, float* per_sample_out,
@@ -469,7 +485,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
 
     // ---- prior / KL term, reward NLL, metrics, time-importance EMA
     hipLaunchKernelGGL(kl_prior_kernel, dim3(1), dim3(1024), 0, s, latents, peps, dp->prior_mean, dp->prior_log_std, t, cfg->kl_weight,
-                       dgrads->prior_mean, dgrads->prior_log_std, tmp, B, L);
+                       dgrads->prior_mean, dgrads->prior_log_std, tmp, B, L, noise->mean_t);
     AID_LAUNCH_CHECK();
     {
         RewardSave rs; const size_t mk = ws.mark();

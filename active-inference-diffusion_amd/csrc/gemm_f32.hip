@@ -22,6 +22,8 @@
 // 32x32 + 4-way in-workgroup split-K for the batch<=512 layers where the grid would otherwise
 // leave most of the 256 CUs idle.  Register-staged double buffering: tile t+1's global loads are
 // in flight while tile t is contracted.
+#include <atomic>
+#include <mutex>
 #include "aid_common.h"
 
 namespace aid {
@@ -1062,8 +1064,36 @@ static int launch_thin_tn(const GemmArgs& g, hipStream_t s) {
     hipLaunchKernelGGL(gemm_thin_tn_kernel, dim3(tm * tn), dim3(1024), 0, s, g, tn);
     return AID_OK;
 }
-static int g_low_lds = 0;        // aid_gemm_force_kernel bit 9: prefer the 35 KB panel variant for small problems (launches meant to overlap another stream)
-static int g_force_kernel = 0;   // aid_gemm_force_kernel: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
+// Dispatch hints are a property of the STREAM a launch goes to (aid_stream_hint), never of the process: a side stream whose small
+// GEMMs must co-reside with another stream's big ones is marked once, and a thread launching on any other stream (the collector's
+// inference thread of utils/async_collector.py:388,451) is unaffected by it.  Lock-free readers; writers serialise on a mutex.
+struct StreamHint { std::atomic<void*> stream{nullptr}; std::atomic<int> flags{0}; std::atomic<int> used{0}; };
+static StreamHint g_stream_hints[64];
+static std::mutex g_stream_hints_mu;
+int stream_hint_set(hipStream_t s, int flags) {
+    std::lock_guard<std::mutex> lk(g_stream_hints_mu);
+    int free_slot = -1;
+    for (int i = 0; i < 64; ++i) {
+        if (g_stream_hints[i].used.load(std::memory_order_acquire)) {
+            if (g_stream_hints[i].stream.load(std::memory_order_relaxed) == (void*)s) { g_stream_hints[i].flags.store(flags, std::memory_order_release); return AID_OK; }
+        } else if (free_slot < 0) free_slot = i;
+    }
+    if (flags == 0) return AID_OK;                 // nothing recorded for this stream and nothing to record
+    if (free_slot < 0) return AID_E_SHAPE;
+    g_stream_hints[free_slot].stream.store((void*)s, std::memory_order_relaxed);
+    g_stream_hints[free_slot].flags.store(flags, std::memory_order_relaxed);
+    g_stream_hints[free_slot].used.store(1, std::memory_order_release);
+    return AID_OK;
+}
+static inline int stream_hint_get(hipStream_t s) {
+    for (int i = 0; i < 64; ++i) {
+        if (!g_stream_hints[i].used.load(std::memory_order_acquire)) continue;
+        if (g_stream_hints[i].stream.load(std::memory_order_relaxed) == (void*)s) return g_stream_hints[i].flags.load(std::memory_order_acquire);
+    }
+    return 0;
+}
+// TESTS / BENCHES ONLY (aid_gemm_force_kernel): a process-wide kernel override, deliberately not part of the product path and not thread-safe.
+static int g_force_kernel = 0;   // 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
 
 template <bool AKM, bool BKM>
 static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
@@ -1104,7 +1134,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     if (t64 >= 160) return launch_tile<64, 64, AKM, BKM>(g, vec, s);        // unaligned operands / K < 64
     // < 160 tiles: the grid cannot fill the chip with 64x64 tiles; the 32x32 LDS-DMA panel kernel (whole K in flight, 4-way
     // in-workgroup split-K) has the shortest critical path.
-    if (p32_ok && t32 <= 1536 && g_low_lds) return launch_panel128<AKM, BKM, 64>(g, s);      // side-stream launches: co-reside with the big GEMM
+    if (p32_ok && t32 <= 1536 && (stream_hint_get(s) & 1)) return launch_panel128<AKM, BKM, 64>(g, s);      // side-stream launches: co-reside with the big GEMM
     if (p32_ok && t32 <= 1536) {
         // more tiles than CUs and >= 16 row tiles (the 768-row reverse loop, 1024-row batches): two 67 KB workgroups per CU beat two
         // rounds of the 133 KB kernel by 12-18 us per launch in situ; a 256-row x 2048-column layer is the exception
@@ -1123,7 +1153,7 @@ static inline bool routes_to_tile(const GemmArgs& g) {
     return g_force_kernel == 0 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 160;
 }
 
-void gemm_force_kernel(int k) { g_force_kernel = k & 0xff; g_big_map = (k >> 8) & 1; g_low_lds = (k >> 9) & 1; }
+void gemm_force_kernel(int k) { g_force_kernel = k & 0xff; g_big_map = (k >> 8) & 1; }
 
 __global__ void slab_fold_kernel(const float* __restrict__ slab, int nslab, GemmArgs g) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

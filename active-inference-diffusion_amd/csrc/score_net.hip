@@ -386,6 +386,7 @@ int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float*
 }
 
 int aid_gemm_force_kernel(int k) { gemm_force_kernel(k); return AID_OK; }
+int aid_stream_hint(void* stream, int flags) { return stream_hint_set((hipStream_t)stream, flags); }
 
 int aid_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
     return philox_fill(out, n, 0, 0.f, seed, offset, (hipStream_t)stream);

@@ -327,22 +327,29 @@ int aid_lambda_returns(const float* rewards, const float* next_values, const flo
 }
 
 size_t aid_small_net_workspace(int B, int D) { return sizeof(float) * (size_t)B * (64 * (size_t)D + 1024) + (1 << 16); }
-size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 * aid_small_net_workspace(B, val->D) : 0; }
+size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 * aid_small_net_workspace(B + 64, val->D) : 0; }
 size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B) { return dyn ? aid_small_net_workspace(B, dyn->D) : 0; }
 
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
                    const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out, float* loss_out,
                    void* wsp, size_t ws_bytes, void* stream) {
+    return aid_value_step_ex(val, vgrads, B, B, latents, next_latents, rewards, dones, gamma, lam, n_steps, targets_out, loss_out, wsp, ws_bytes, stream);
+}
+
+int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, int Bx, const float* latents, const float* next_latents,
+                      const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out, float* loss_out,
+                      void* wsp, size_t ws_bytes, void* stream) {
     AID_REQUIRE(val && vgrads && latents && next_latents && rewards && dones && loss_out, AID_E_NULL, "aid_value_step: null argument");
+    AID_REQUIRE(B > 0 && Bx >= B && Bx <= B + 64, AID_E_SHAPE, "aid_value_step: B=%d B_ext=%d", B, Bx);
     hipStream_t s = (hipStream_t)stream;
     Workspace ws(wsp, ws_bytes);
-    float* t0 = ws.f32(B); float* t1 = ws.f32(B); float* v = ws.f32(B); float* nv = ws.f32(B); float* tg = ws.f32(B); float* dv = ws.f32(B);
+    float* t0 = ws.f32(B); float* t1 = ws.f32(Bx); float* v = ws.f32(B); float* nv = ws.f32(Bx); float* tg = ws.f32(Bx); float* dv = ws.f32(B);
     AID_WS_OK(ws);
-    AID_TRY(fill_const(t0, 0.f, B, s)); AID_TRY(fill_const(t1, 1.f, B, s));
+    AID_TRY(fill_const(t0, 0.f, B, s)); AID_TRY(fill_const(t1, 1.f, Bx, s));
     ValueSave sv, sv2;
     AID_TRY(value_fwd(*val, B, latents, val->L, t0, v, sv, ws, s));
-    { const size_t mk = ws.mark(); AID_TRY(value_fwd(*val, B, next_latents, val->L, t1, nv, sv2, ws, s)); ws.release(mk); }
-    AID_TRY(aid_lambda_returns(rewards, nv, dones, B, gamma, lam, n_steps, tg, stream));
+    { const size_t mk = ws.mark(); AID_TRY(value_fwd(*val, Bx, next_latents, val->L, t1, nv, sv2, ws, s)); ws.release(mk); }
+    AID_TRY(aid_lambda_returns(rewards, nv, dones, Bx, gamma, lam, n_steps, tg, stream));   // rows >= B: halo, their targets are unused
     hipLaunchKernelGGL(huber_kernel, dim3(1), dim3(1024), 0, s, v, tg, B, dv, loss_out);
     AID_LAUNCH_CHECK();
     AID_TRY(value_bwd(*val, vgrads, B, t0, sv, dv, nullptr, 0, ws, s));

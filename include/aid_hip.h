@@ -67,10 +67,15 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream);
-/* kernel-selection override for benches/tests: 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 8 thin TN (weight gradients of narrow layers),
- * 9 / 11 gemm_big_kernel with prefetch distance 2 / 1, 10 skinny (M <= 32 rows: act() / collector batches), 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel; bit 9 (value 512, with kernel code 0) is a
- * dispatch HINT, not an override: small problems use the 35 KB-LDS panel variant (launches meant to overlap a big GEMM on another stream) */
+/* TESTS / BENCHES ONLY - not part of the product path, process-wide and not thread-safe: kernel-selection override.  0 auto, 1 panel32,
+ * 2 ring64, 4 tile64, 6 splitk, 8 thin TN (weight gradients of narrow layers), 9 / 11 gemm_big_kernel with prefetch distance 2 / 1,
+ * 10 skinny (M <= 32 rows: act() / collector batches), 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel. */
 int aid_gemm_force_kernel(int k);
+/* Dispatch hints are per STREAM (the library keeps no per-call global state): flags bit 0 = launches on `stream` prefer the 35 KB-LDS
+ * small-problem GEMM variant, so that they co-reside with large GEMMs another stream is running (speed only, results identical).  Set it
+ * once for a side stream; flags = 0 clears.  Launches on every other stream - e.g. a collector thread's inference stream
+ * (utils/async_collector.py:388,451) - are unaffected.  Thread-safe. */
+int aid_stream_hint(void* stream, int flags);
 
 /* ---- Philox fills (production RNG; parity tests pass explicit tensors instead) ---------------- */
 int aid_fill_normal(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
@@ -223,6 +228,10 @@ typedef struct AidElboNoise {
     float* d_obs_out;   /* optional OUTPUT [B,O]: accumulates d(loss)/d(observations) from the score net's obs encoder (main + GP pass);
                            pixel mode, where the observations are the DrQ-v2 encoder's features.  With dec == NULL the reconstruction
                            term is taken from metrics[0] as pre-set by the caller (aid_feature_decoder_step). */
+    const float* mean_t;/* optional device scalar: mean of t over the GLOBAL batch.  The KL annealing weight exp(-5 mean t)
+                           (active_inference.py:611) is a batch statistic; a data-parallel caller draws t first (aid_sample_time),
+                           all-gathers it and passes the global mean so that N ranks x B rows equal one N*B-row step.  NULL => mean
+                           over this call's B rows. */
 } AidElboNoise;
 typedef struct AidElboCfg {
     float kl_weight, diffusion_weight, reward_weight, gp_weight;
@@ -233,6 +242,10 @@ typedef struct AidElboCfg {
 } AidElboCfg;
 /* the sequential time-importance EMA of active_inference.py:750-771 over n (t, per-sample loss) pairs, in order */
 int aid_time_importance_update(float* time_importance, const float* t, const float* per_sample, int n, int first_call, void* stream);
+/* _importance_sample_time (active_inference.py:731-748) alone: t_out [B] ~ uniform (first_call) or importance-sampled from
+ * time_importance[100], device Philox (seed, offset).  ws: >= 2*B floats. */
+int aid_sample_time(const float* time_importance, int first_call, int B, uint64_t seed, uint64_t offset, float* t_out, void* ws,
+                    size_t ws_bytes, void* stream);
 size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B);
 int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDiffusionParams* dp,
                   const AidDiffusionParams* dgrads, const AidDecoderNet* dec, const AidRewardNet* rew, int B,
@@ -351,6 +364,13 @@ size_t aid_value_step_workspace(const AidValueNet* val, int B);
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
                    const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,
                    float* loss_out, void* ws, size_t ws_bytes, void* stream);
+/* aid_value_step with a lambda-return HALO: next_latents / rewards / dones hold B_ext >= B rows; the first B are this call's minibatch,
+ * rows B..B_ext-1 continue the sequence (data parallel: the first n_steps rows of the next rank's shard), so that the windows of the
+ * last rows see the same neighbours as in one global batch (compute_lambda_returns treats minibatch order as time, :638-707).
+ * Targets, Huber loss (mean over B) and gradients are those of the first B rows. */
+int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, int B_ext, const float* latents, const float* next_latents,
+                      const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,
+                      float* loss_out, void* ws, size_t ws_bytes, void* stream);
 size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B);
 int aid_dynamics_step(const AidDynamicsNet* dyn, const AidDynamicsNet* dgrads, int B, const float* latents, const float* actions,
                       const float* next_latents, float* loss_out, void* ws, size_t ws_bytes, void* stream);

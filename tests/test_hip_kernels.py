@@ -307,3 +307,45 @@ def test_replay_buffer_uint8_frames(nat):
     assert torch.equal(a["observations"][0].cpu(), torch.from_numpy(frames[B - 1].astype(np.float32)))
     with pytest.raises(TypeError):
         rb8.add(frames[0].astype(np.float32), act[0], 0.0, nxt[0], False)
+
+
+def test_stream_hint_is_per_stream_and_thread_safe(nat, tmp_path):
+    """The dispatch hint lives with the stream (aid_stream_hint), not the process: two host threads launch the same GEMM concurrently on
+    two streams; only the hinted stream's launches take the 35 KB-LDS variant (profiling label 15), the other's never do, and both get
+    the same numbers.  (The reference runs collector inference from a daemon thread on its own stream: utils/async_collector.py:388,451.)"""
+    import csv
+    import threading
+    rng = np.random.default_rng(0)
+    M, N, K = 256, 512, 512
+    A, W = dev(rng.standard_normal((M, K))), dev(rng.standard_normal((N, K)) / 16)
+    s_hint, s_plain = torch.cuda.Stream(), torch.cuda.Stream()
+    nat.stream_hint(s_hint, 1)
+    outs = {}
+    nat.prof_enable(True); nat.prof_reset()
+
+    def run(name, stream, reps):
+        with torch.cuda.stream(stream):
+            o = torch.zeros(M, N, device="cuda")
+            for _ in range(reps):
+                nat.gemm(A, W, o, M, N, K, K, K, N)
+            outs[name] = o
+    try:
+        th = [threading.Thread(target=run, args=("hint", s_hint, 40)), threading.Thread(target=run, args=("plain", s_plain, 24))]
+        for t in th: t.start()
+        for t in th: t.join()
+        torch.cuda.synchronize()
+        path = str(tmp_path / "launches.csv")
+        nat.prof_dump(path)
+    finally:
+        nat.prof_enable(False); nat.prof_reset()
+        nat.stream_hint(s_hint, 0)
+    variants = [int(r["variant"]) for r in csv.DictReader(open(path)) if int(r["M"]) == M and int(r["N"]) == N]
+    assert variants.count(15) == 40 and len(variants) == 64 and 15 not in [v for v in variants if v != 15]
+    assert torch.equal(outs["hint"], outs["plain"]) or torch.allclose(outs["hint"], outs["plain"], rtol=1e-5, atol=1e-5)
+    # cleared: the formerly hinted stream dispatches like any other
+    nat.prof_enable(True); nat.prof_reset()
+    try:
+        run("after", s_hint, 3); torch.cuda.synchronize(); nat.prof_dump(path)
+    finally:
+        nat.prof_enable(False); nat.prof_reset()
+    assert all(int(r["variant"]) != 15 for r in csv.DictReader(open(path)))

@@ -10,6 +10,6 @@ def run(n=10):
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 for rep in range(3):
     for ov, low in ((True, True), (True, False), (False, False)):
-        agent.overlap_streams = ov; agent.elbo_low_lds = low
+        agent.overlap_streams = ov; agent.side_low_lds = low; agent._comm = None
         run(2)
-        print(f"overlap={ov} elbo_low_lds={low}: {run():.2f} ms/step", flush=True)
+        print(f"overlap={ov} side_low_lds={low}: {run():.2f} ms/step", flush=True)

@@ -1,0 +1,280 @@
+// Linear -> LayerNorm -> activation (-> skip add) as ONE kernel for tall inputs:  Y = act(LN(A W^T + b) * gamma + beta) + add.
+//
+// Replaces, for the 25 600-row (and, with the perturbed copies batched, 128 000-row) activations of the gradient-free MINE estimator
+// (reference: core/active_inference.py:237-242 `observation_decoder[1..2]` = Linear, LayerNorm, SiLU, Dropout inside
+// FunctionSpaceEpistemicEstimator.compute_jacobian_features :940-993), the sequence  64x64-tile GEMM -> write [M,N] -> LayerNorm kernel
+// reads [M,N] (+ skip) -> writes [M,N]:  here a workgroup owns 64 COMPLETE output rows (BN = the layer width, 512 or 1024), so the
+// row statistics are formed from the accumulators and the normalised, activated row is the only thing written.
+//
+// MI355X mapping
+//   * 512 threads = 8 waves; wave w owns all 64 rows x columns [w BN/8, (w+1) BN/8): 2 x (BN/256) accumulators of 32x32
+//     (v_mfma_f32_32x32x2_f32; 128 accumulator registers at BN = 1024), two waves per SIMD, one workgroup per CU.
+//   * K is walked in stages of BKT (16 at BN = 1024, 32 at BN = 512): one stage of the weight operand is BN x BKT x 4 B = 64 KB, double
+//     buffered in LDS (128 KB) next to the 64 x BKT activation stage; per stage a wave issues 64 MFMAs (4 096 cycles of its SIMD's
+//     matrix pipe) between two workgroup barriers - four times the work per barrier of the 64x64-tile kernel, whose per-K-tile barrier
+//     convoy was measured to idle the pipe 28 % of the time (profiles/r01_gemm_big_stall_breakdown.txt).
+//   * the weight stage is read from L2 once per 64 rows: 68 KB per 8 192 SIMD-cycles = 8.3 B/clk/CU (the 64x64 tile needs 16).
+//   * LDS images are unpadded [row][BKT] with the 16-B chunk index XOR-swizzled by the row (chunk ^= (row / rows-per-256B) % chunks),
+//     which makes both the b128 staging writes and the b128 fragment reads bank-conflict free (MI355X_MICROARCH.md, LDS table).
+//   * register staging, prefetch distance 1: stage t+1's global loads are issued before stage t is contracted and written to the
+//     other LDS buffer after it; loads are branch-free (clamped addresses, zeroed at the LDS write when beyond K).
+//   * epilogue: bias; two-pass LayerNorm (mean, then centred second moment - torch's numerics) with a butterfly that folds a lane's 32
+//     row partials to one row per lane in 31 cross-lane moves, cross-wave sums through LDS; affine, activation, skip; one store.
+#include "aid_common.h"
+#include "rowwise.h"
+
+namespace aid {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct RowLnArgs {
+    const float* A; int lda;             // [M][K] activations
+    const float* W; int ldw;             // [BN][K] torch Linear weight
+    const float* bias;                   // [BN] or null
+    const float* gamma; const float* beta;   // LayerNorm affine, [BN] each (null => 1 / 0)
+    const float* add; int ldadd;         // optional skip, added after the activation
+    float* Y; int ldy;
+    int M, K;
+    float eps;
+};
+
+template <int BKT> struct RowSw {
+    static constexpr int CPR = BKT / 4;          // 16-B chunks per row
+    static constexpr int RPB = 64 / BKT;         // rows per 256-B bank row
+    __device__ static __forceinline__ int off(int row, int chunk) { return row * BKT + (((chunk ^ ((row / RPB) % CPR))) << 2); }
+};
+
+template <int ACT> __device__ __forceinline__ float rowln_act(float x) {
+    if constexpr (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
+    else if constexpr (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + expf(-x));
+    else return x;
+}
+
+// 32 per-lane values (one per accumulator row) -> lane li (of each 32-lane half) ends with the half-wide sum of value li.
+__device__ __forceinline__ float fold32(float (&x)[32], int li) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const bool up = li & 16; const float recv = __shfl_xor(up ? x[i] : x[i + 16], 16, 64); x[i] = (up ? x[i + 16] : x[i]) + recv; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const bool up = li & 8; const float recv = __shfl_xor(up ? x[i] : x[i + 8], 8, 64); x[i] = (up ? x[i + 8] : x[i]) + recv; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const bool up = li & 4; const float recv = __shfl_xor(up ? x[i] : x[i + 4], 4, 64); x[i] = (up ? x[i + 4] : x[i]) + recv; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const bool up = li & 2; const float recv = __shfl_xor(up ? x[i] : x[i + 2], 2, 64); x[i] = (up ? x[i + 2] : x[i]) + recv; }
+    { const bool up = li & 1; const float recv = __shfl_xor(up ? x[0] : x[1], 1, 64); x[0] = (up ? x[1] : x[0]) + recv; }
+    return x[0];
+}
+
+template <int BN, int BKT, int ACT>
+__global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
+    constexpr int NT = 512, BM = 64, TN = BN / 256, CPR = BKT / 4;
+    constexpr int A_FL = BM * BKT, B_FL = BN * BKT;
+    constexpr int F4A = BM * CPR, F4B = BN * CPR, PB = F4B / NT;
+    static_assert(F4B % NT == 0 && F4A <= NT && NT % F4A == 0, "stage shapes");
+    using SW = RowSw<BKT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [2][BM][BKT]
+    float* Bs = smem + 2 * A_FL;        // [2][BN][BKT]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wn = wave * (BN / 8);
+    const int m0 = blockIdx.x * BM;
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // ---- staging maps (fixed per thread)
+    const int fa = tid % F4A, a_row = fa / CPR, a_c = fa % CPR;
+    const int a_gr = min(m0 + a_row, g.M - 1);                  // rows beyond M repeat the last row (computed, never stored)
+    const float* a_src = g.A + (size_t)a_gr * g.lda + 4 * a_c;
+    const int a_dst = SW::off(a_row, a_c);
+    const bool a_owner = tid < F4A;
+    const float* b_src[PB]; int b_dst[PB];
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int f = tid + NT * i, row = f / CPR, c = f % CPR;
+        b_src[i] = g.W + (size_t)row * g.ldw + 4 * c; b_dst[i] = SW::off(row, c);
+    }
+    const int nk = (g.K + BKT - 1) / BKT;
+    f32x4 ra, rb[PB];
+    auto load_stage = [&](int kt) {      // branch-free: clamped k, zeroed at the LDS write
+        const int k0 = kt * BKT;
+        const int ka = (k0 + 4 * a_c < g.K) ? k0 : 0;
+        ra = *reinterpret_cast<const f32x4*>(a_src + ka);
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int c = (tid + NT * i) % CPR;
+            const int kb = (k0 + 4 * c < g.K) ? k0 : 0;
+            rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kb);
+        }
+    };
+    auto store_stage = [&](int kt, int buf) {
+        const int k0 = kt * BKT;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (a_owner) *reinterpret_cast<f32x4*>(As + buf * A_FL + a_dst) = (k0 + 4 * a_c < g.K) ? ra : z;
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int c = (tid + NT * i) % CPR;
+            *reinterpret_cast<f32x4*>(Bs + buf * B_FL + b_dst[i]) = (k0 + 4 * c < g.K) ? rb[i] : z;
+        }
+    };
+    auto contract = [&](int buf) {
+        const float* a_s = As + buf * A_FL;
+        const float* b_s = Bs + buf * B_FL;
+#pragma unroll
+        for (int g8 = 0; g8 < BKT / 8; ++g8) {
+            f32x4 av[2], bv[TN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const f32x4*>(a_s + SW::off(32 * i + li, 2 * g8 + h));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j + li, 2 * g8 + h));
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+        }
+    };
+    load_stage(0);
+    store_stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        load_stage(kt + 1 < nk ? kt + 1 : kt);          // the last iteration re-loads its own stage (never written back)
+        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch ahead of the MFMA block
+        contract(cur);
+        if (kt + 1 < nk) store_stage(kt + 1, cur ^ 1);
+        __syncthreads();
+    }
+    // ---- epilogue.  LDS scratch (the stage buffers are dead after the loop's last barrier)
+    float* part = smem;                 // [8 waves][64 rows]
+    float* rowv = smem + 8 * BM;        // [64]: mean, then 1/std
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bcol[j] = g.bias ? g.bias[wn + 32 * j + li] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    // accumulator register r of row-tile i is row 32 i + (r & 3) + 8 (r >> 2) + 4 h; fold index 16 i + r
+    const int my_row = 32 * (li >> 4) + ((li & 15) & 3) + 8 * ((li & 15) >> 2) + 4 * h;     // the row lane li ends up owning after fold32
+    float x[32];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) s += acc[i][j][r];
+            x[16 * i + r] = s;
+        }
+    part[wave * BM + my_row] = fold32(x, li);
+    __syncthreads();
+    if (tid < BM) { float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += part[w * BM + tid];
+        rowv[tid] = s / (float)BN; }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 m4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] -= m4[e];
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) s += acc[i][j][r] * acc[i][j][r];
+            x[16 * i + r] = s;
+        }
+    __syncthreads();                                     // every wave has read the means before `rowv` / `part` are reused
+    part[wave * BM + my_row] = fold32(x, li);
+    __syncthreads();
+    if (tid < BM) { float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += part[w * BM + tid];
+        rowv[tid] = 1.0f / sqrtf(s / (float)BN + g.eps); }
+    __syncthreads();
+    float gcol[TN], becol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gcol[j] = g.gamma ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = g.beta ? g.beta[wn + 32 * j + li] : 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rq = 0; rq < 4; ++rq) {
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
+                if (row < g.M) {
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        const int col = wn + 32 * j + li;
+                        float o = rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]);
+                        if (g.add) o += g.add[(size_t)row * g.ldadd + col];
+                        g.Y[(size_t)row * g.ldy + col] = o;
+                    }
+                }
+            }
+        }
+}
+
+template <int BN, int BKT, int ACT>
+static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT>), dim3((g.M + 63) / 64), dim3(512), lds, s, g);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy) {
+    const bool al = ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)add | (uintptr_t)y) & 15) == 0) && ldx % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldadd % 4 == 0;
+    return al && M >= 2048 && (N == 512 || N == 1024) && K >= 64 && (act == ACT_SILU || act == ACT_RELU || act == ACT_NONE);
+}
+
+// y[M,N] = act(LN(x W^T + b) * gamma + beta) + add, N in {512, 1024}; x [M,K] (row stride ldx), W [N,K] contiguous rows.
+int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act, const float* add,
+                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s) {
+    AID_REQUIRE(linear_ln_act_rows_ok(M, N, K, act, x, ldx, W, add, ldadd, y, ldy), AID_E_SHAPE, "linear_ln_act_rows: unsupported M=%d N=%d K=%d act=%d", M, N, K, act);
+    RowLnArgs g; memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = ldx; g.W = W; g.ldw = K; g.bias = b; g.gamma = gamma; g.beta = beta; g.add = add; g.ldadd = ldadd; g.Y = y; g.ldy = ldy;
+    g.M = M; g.K = K; g.eps = 1e-5f;
+    ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 0; prof.variant = N == 1024 ? 20 : 21;
+    if (N == 1024) {
+        if (act == ACT_SILU) return launch_rowln<1024, 16, ACT_SILU>(g, s);
+        if (act == ACT_RELU) return launch_rowln<1024, 16, ACT_RELU>(g, s);
+        return launch_rowln<1024, 16, ACT_NONE>(g, s);
+    }
+    if (act == ACT_SILU) return launch_rowln<512, 32, ACT_SILU>(g, s);
+    if (act == ACT_RELU) return launch_rowln<512, 32, ACT_RELU>(g, s);
+    return launch_rowln<512, 32, ACT_NONE>(g, s);
+}
+
+}  // namespace aid
+
+using namespace aid;
+extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
+                                 const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
+    AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");
+    return linear_ln_act_rows(x, ldx, W, b, gamma, beta, act, add, ldadd, y, ldy, M, N, K, (hipStream_t)stream);
+}

@@ -10,6 +10,11 @@ namespace aid {
 int copy_cols(const float* src, int lds, float* dst, int ldd, int M, int nc, hipStream_t s);   // lds==0 broadcasts a row
 int axpby_cols(const float* a, int lda, float alpha, const float* b, int ldb, float beta, float* dst, int ldd, int M, int nc, hipStream_t s);
 
+// Linear -> LayerNorm -> activation (-> + add) in ONE full-row-tile MFMA kernel (gemm_rowln.hip): tall inference inputs, N in {512, 1024}
+bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy);
+int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act, const float* add,
+                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s);
+
 // y = act(LN(x W^T + b)) * mask      (Linear -> LayerNorm -> activation [-> dropout])
 struct LlaSave { float *lin, *stats, *y; };
 int lla_alloc(int M, int out, Workspace& ws, LlaSave& sv);

@@ -40,6 +40,9 @@ int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, con
     // K <= 32 (first layer of a net): one fused pass; the pre-LN values and statistics are written only when a backward pass will read them
     if (lin_smallk_ln_act_ok(l.in, l.out, act, l.w, sv.y, need_lin ? sv.lin : nullptr, mask, l.out) && ((((uintptr_t)add | (uintptr_t)l.b | (uintptr_t)ln.g | (uintptr_t)ln.b) & 15) == 0))
         return lin_smallk_ln_act(x, ldx, l.in, l.w, l.b, ln.g, ln.b, act, mask, add, need_lin ? sv.lin : nullptr, sv.y, l.out, need_lin ? sv.stats : nullptr, M, l.out, s);
+    // inference on tall inputs (the estimator's 25 600+ sample rows): the LayerNorm lives in the GEMM's epilogue, nothing but y is written
+    if (!need_lin && !mask && linear_ln_act_rows_ok(M, l.out, l.in, act, x, ldx, l.w, add, l.out, sv.y, l.out))
+        return linear_ln_act_rows(x, ldx, l.w, l.b, ln.g, ln.b, act, add, l.out, sv.y, l.out, M, l.out, l.in, s);
     AID_TRY(linear_fwd(x, ldx, l.w, l.b, sv.lin, l.out, M, l.out, l.in, ACT_NONE, s));
     AID_TRY(ln_act(sv.lin, l.out, ln.g, ln.b, act, mask, sv.y, l.out, sv.stats, M, l.out, s, add));
     return AID_OK;
@@ -93,8 +96,8 @@ int decoder_fwd(const AidDecoderNet& d, int M, const float* z, int ldz, const fl
     lla_alloc(M, d.s[0].out, ws, s0); lla_alloc(M, d.s[1].out, ws, s1); lla_alloc(M, d.s[2].out, ws, s2);
     AID_WS_OK(ws);
     AID_TRY(lla_fwd(d.s[0], d.ln[0], ACT_SILU, masks ? masks[0] : nullptr, z, ldz, M, s0, s, nullptr, false));   // inference: nothing saved
-    AID_TRY(lla_fwd(d.s[1], d.ln[1], ACT_SILU, masks ? masks[1] : nullptr, s0.y, d.s[0].out, M, s1, s, s0.y));   // h2 = stage(h1) + h1 (skip, :240)
-    AID_TRY(lla_fwd(d.s[2], d.ln[2], ACT_SILU, masks ? masks[2] : nullptr, s1.y, d.s[1].out, M, s2, s));
+    AID_TRY(lla_fwd(d.s[1], d.ln[1], ACT_SILU, masks ? masks[1] : nullptr, s0.y, d.s[0].out, M, s1, s, s0.y, false));   // h2 = stage(h1) + h1 (skip, :240)
+    AID_TRY(lla_fwd(d.s[2], d.ln[2], ACT_SILU, masks ? masks[2] : nullptr, s1.y, d.s[1].out, M, s2, s, nullptr, false));
     AID_TRY(linear_fwd(s2.y, d.s[2].out, d.out.w, d.out.b, out, ldo, M, d.out.out, d.out.in, ACT_NONE, s));
     ws.release(mark);
     return AID_OK;

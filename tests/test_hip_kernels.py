@@ -349,3 +349,32 @@ def test_stream_hint_is_per_stream_and_thread_safe(nat, tmp_path):
     finally:
         nat.prof_enable(False); nat.prof_reset()
     assert all(int(r["variant"]) != 15 for r in csv.DictReader(open(path)))
+
+
+@pytest.mark.parametrize("M,N,K,act,skip", [(2048, 1024, 1024, "silu", True), (4100, 512, 1024, "silu", False), (2560, 512, 384, "relu", False),
+                                             (2049, 1024, 72, "none", True), (25600, 1024, 1024, "silu", True)])
+def test_linear_ln_act_full_row_kernel(nat, M, N, K, act, skip):
+    """Linear -> LayerNorm -> activation (+ skip) with the LayerNorm in the GEMM's epilogue (csrc/gemm_rowln.hip) against torch fp32 on
+    the same inputs (ragged row counts, K not a multiple of the stage depth, non-trivial affine, a row-dependent offset so that the
+    mean matters).  Reference op chain: the decoder stages of core/active_inference.py:237-242."""
+    rng = np.random.default_rng(M + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = (0.5 * rng.standard_normal(N) + 0.3).astype(np.float32)
+    ga = (1 + 0.2 * rng.standard_normal(N)).astype(np.float32); be = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    x[:, 0] += np.linspace(-3, 3, M).astype(np.float32)
+    add = rng.standard_normal((M, N)).astype(np.float32) if skip else None
+    T = torch.from_numpy
+    lin = torch.nn.functional.linear(T(x).double(), T(W).double(), T(b).double())
+    ref = torch.nn.functional.layer_norm(lin, (N,), T(ga).double(), T(be).double(), 1e-5)
+    ref = {"silu": torch.nn.functional.silu, "relu": torch.relu, "none": lambda v: v}[act](ref)
+    if skip:
+        ref = ref + T(add).double()
+    got = nat.linear_ln_act(dev(x), dev(W), dev(b), dev(ga), dev(be), act, dev(add) if skip else None)
+    np.testing.assert_allclose(got.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    # and against the two-kernel path the small-M layers keep using (GEMM, then the row-wise LayerNorm kernel)
+    two = torch.empty(M, N, device="cuda")
+    nat.gemm(dev(x), dev(W), two, M, N, K, K, K, N, bias=dev(b))
+    ref32 = torch.nn.functional.layer_norm(two, (N,), dev(ga), dev(be), 1e-5)
+    ref32 = {"silu": torch.nn.functional.silu, "relu": torch.relu, "none": lambda v: v}[act](ref32) + (dev(add) if skip else 0)
+    np.testing.assert_allclose(got.cpu().numpy(), ref32.cpu().numpy(), rtol=2e-5, atol=2e-5)

@@ -65,7 +65,7 @@ __device__ __forceinline__ float fold32(float (&x)[32], int li) {
     return x[0];
 }
 
-template <int BN, int BKT, int ACT>
+template <int BN, int BKT, int ACT, bool KTAIL, int DBG = 0>
 __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     constexpr int NT = 512, BM = 64, TN = BN / 256, CPR = BKT / 4;
     constexpr int A_FL = BM * BKT, B_FL = BN * BKT;
@@ -97,59 +97,89 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     for (int i = 0; i < PB; ++i) {
         const int f = tid + NT * i, row = f / CPR, c = f % CPR;
         b_src[i] = g.W + (size_t)row * g.ldw + 4 * c; b_dst[i] = SW::off(row, c);
+        if constexpr (DBG == 1) b_src[i] = g.W + (size_t)f * 4;        // timing experiment: fully coalesced (wrong) weight addresses
     }
     const int nk = (g.K + BKT - 1) / BKT;
     f32x4 ra, rb[PB];
     auto load_stage = [&](int kt) {      // branch-free: clamped k, zeroed at the LDS write
         const int k0 = kt * BKT;
-        const int ka = (k0 + 4 * a_c < g.K) ? k0 : 0;
-        ra = *reinterpret_cast<const f32x4*>(a_src + ka);
+        if constexpr (KTAIL) {
+            const int ka = (k0 + 4 * a_c < g.K) ? k0 : 0;
+            ra = *reinterpret_cast<const f32x4*>(a_src + ka);
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int c = (tid + NT * i) % CPR;
-            const int kb = (k0 + 4 * c < g.K) ? k0 : 0;
-            rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kb);
+            for (int i = 0; i < PB; ++i) {
+                const int c = (tid + NT * i) % CPR;
+                const int kb = (k0 + 4 * c < g.K) ? k0 : 0;
+                rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kb);
+            }
+        } else {
+            ra = *reinterpret_cast<const f32x4*>(a_src + k0);
+            if constexpr (DBG >= 2) { if (kt > 0) return; }             // timing experiments: no weight loads after the first stage
+#pragma unroll
+            for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + (DBG == 1 ? k0 * (BN / 4) : k0));
         }
     };
-    auto store_stage = [&](int kt, int buf) {
+    // piece p of the staged tile -> LDS buffer `buf` (p = 0 .. PB-1: weight pieces, p = PB: the activation piece)
+    auto store_piece = [&](int p, int kt, int buf) {
         const int k0 = kt * BKT;
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        if (a_owner) *reinterpret_cast<f32x4*>(As + buf * A_FL + a_dst) = (k0 + 4 * a_c < g.K) ? ra : z;
-#pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int c = (tid + NT * i) % CPR;
-            *reinterpret_cast<f32x4*>(Bs + buf * B_FL + b_dst[i]) = (k0 + 4 * c < g.K) ? rb[i] : z;
+        if (p == PB) {
+            if (a_owner) *reinterpret_cast<f32x4*>(As + buf * A_FL + a_dst) = (!KTAIL || k0 + 4 * a_c < g.K) ? ra : z;
+        } else {
+            const int c = (tid + NT * p) % CPR;
+            *reinterpret_cast<f32x4*>(Bs + buf * B_FL + b_dst[p]) = (!KTAIL || k0 + 4 * c < g.K) ? rb[p] : z;
         }
     };
-    auto contract = [&](int buf) {
-        const float* a_s = As + buf * A_FL;
-        const float* b_s = Bs + buf * B_FL;
+    // One stage: NM = 64 MFMAs per wave.  The hand-over work of the NEXT stage (wait for its global loads, write its PB + 1 pieces to the
+    // other LDS buffer) is spread over the second half of this stage's MFMAs: an fp32 MFMA occupies the matrix pipe for 64 cycles but the
+    // issue port for 8, so the same wave's ds_write / s_waitcnt issue in its shadow instead of in a phase of their own in which (both
+    // waves of a SIMD being in lock-step behind the workgroup barrier) the pipe would idle.
+    constexpr int NG = BKT / 8, NM = NG * 4 * 2 * TN, NS = PB + 1, S0 = NM / 2, STEP = (NM - S0) / NS;
+    static_assert(STEP >= 1, "more hand-over pieces than MFMA slots");
+    auto stage = [&](int cur, int kt_next) {
+        const float* a_s = As + cur * A_FL;
+        const float* b_s = Bs + cur * B_FL;
+        f32x4 av[2][2], bv[2][TN];             // [parity of g8]: fragments of group g8 + 1 are read while group g8 is contracted
 #pragma unroll
-        for (int g8 = 0; g8 < BKT / 8; ++g8) {
-            f32x4 av[2], bv[TN];
+        for (int i = 0; i < 2; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(a_s + SW::off(32 * i + li, h));
 #pragma unroll
-            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const f32x4*>(a_s + SW::off(32 * i + li, 2 * g8 + h));
+        for (int j = 0; j < TN; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j + li, h));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j + li, 2 * g8 + h));
+        for (int g8 = 0; g8 < NG; ++g8) {
+            const int pc = g8 & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[j][q], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < TN; ++j) {
+                        const int idx = ((g8 * 4 + q) * 2 + i) * TN + j;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[pc][i][q], bv[pc][j][q], acc[i][j], 0, 0, 0);
+                        if (q == 1 && i == 0 && j == 0 && g8 + 1 < NG) {     // next group's fragments, early in this group
+#pragma unroll
+                            for (int i2 = 0; i2 < 2; ++i2) av[pc ^ 1][i2] = *reinterpret_cast<const f32x4*>(a_s + SW::off(32 * i2 + li, 2 * (g8 + 1) + h));
+#pragma unroll
+                            for (int j2 = 0; j2 < TN; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j2 + li, 2 * (g8 + 1) + h));
+                        }
+                        if (idx >= S0 && (idx - S0) % STEP == 0 && (idx - S0) / STEP < NS) {
+                            if constexpr (DBG < 3) store_piece((idx - S0) / STEP, kt_next, cur ^ 1);      // DBG 3, 4: no LDS hand-over writes
+                            __builtin_amdgcn_sched_barrier(0);           // pin the piece here: the scheduler otherwise sinks every write to the end
+                        }
+                    }
         }
     };
     load_stage(0);
-    store_stage(0, 0);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) store_piece(p, 0, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
-        load_stage(kt + 1 < nk ? kt + 1 : kt);          // the last iteration re-loads its own stage (never written back)
-        __builtin_amdgcn_sched_barrier(0);               // keep the prefetch ahead of the MFMA block
-        contract(cur);
-        if (kt + 1 < nk) store_stage(kt + 1, cur ^ 1);
-        __syncthreads();
+        // the last iteration re-loads its own stage and writes it to the idle buffer: nobody reads it, and the loop stays branch-free
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;
+        load_stage(ktn);
+        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of the MFMA block
+        stage(cur, ktn);
+        if constexpr (DBG != 3) __syncthreads();     // DBG 3: no barrier either (fragment reads + MFMAs only)
     }
     // ---- epilogue.  LDS scratch (the stage buffers are dead after the loop's last barrier)
     float* part = smem;                 // [8 waves][64 rows]
@@ -233,17 +263,40 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
         }
 }
 
-template <int BN, int BKT, int ACT>
-static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
+template <int BN, int BKT, int ACT, bool KTAIL>
+static int launch_rowln_t(const RowLnArgs& g, hipStream_t s) {
     constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
     static bool attr_done = false;
     if (!attr_done) {
-        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT, KTAIL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT>), dim3((g.M + 63) / 64), dim3(512), lds, s, g);
+    hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, KTAIL>), dim3((g.M + 63) / 64), dim3(512), lds, s, g);
     AID_LAUNCH_CHECK();
     return AID_OK;
+}
+static int g_rowln_dbg = 0;     // timing experiments only (tools/perf/rowln_bench.py): 1 coalesced-but-wrong weight addresses, 2 no weight loads,
+                                // 4 no weight loads and no LDS hand-over writes, 3 no barrier either.  Results are wrong by construction.
+template <int BN, int BKT, int ACT, int DBG>
+static int launch_rowln_dbg(const RowLnArgs& g, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
+    (void)hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT, false, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, false, DBG>), dim3((g.M + 63) / 64), dim3(512), lds, s, g);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+template <int BN, int BKT, int ACT>
+static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
+    if constexpr (ACT == ACT_SILU) {
+        switch (g_rowln_dbg) {
+            case 1: return launch_rowln_dbg<BN, BKT, ACT, 1>(g, s);
+            case 2: return launch_rowln_dbg<BN, BKT, ACT, 2>(g, s);
+            case 3: return launch_rowln_dbg<BN, BKT, ACT, 3>(g, s);
+            case 4: return launch_rowln_dbg<BN, BKT, ACT, 4>(g, s);
+            default: break;
+        }
+    }
+    return g.K % BKT == 0 ? launch_rowln_t<BN, BKT, ACT, false>(g, s) : launch_rowln_t<BN, BKT, ACT, true>(g, s);
 }
 
 bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy) {
@@ -273,6 +326,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 }  // namespace aid
 
 using namespace aid;
+extern "C" int aid_rowln_debug(int mode) { g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                                  const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");

@@ -13,6 +13,8 @@ def timeit(fn, reps):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e-3
 shapes = [(25600, 1024, 1024, True), (25600, 512, 1024, False), (128000, 1024, 1024, True), (128000, 512, 1024, False), (25600, 512, 512, False)]
+if len(sys.argv) > 1:
+    shapes = [tuple(int(v) for v in a.split("x")[:3]) + (a.split("x")[3] == "1",) for a in sys.argv[1:]]
 for (M, N, K, skip) in shapes:
     As = [torch.randn(M, K, device="cuda") for _ in range(3)]; W = torch.randn(N, K, device="cuda") / K ** 0.5
     b = torch.randn(N, device="cuda"); ga = torch.rand(N, device="cuda") + 0.5; be = torch.randn(N, device="cuda")
@@ -26,9 +28,14 @@ for (M, N, K, skip) in shapes:
         i[0] = (i[0] + 1) % 3
         nat.gemm(As[i[0]], W, C, M, N, K, K, K, N, bias=b)
     reps = 5 if M > 50000 else 15
+    fl = 2.0 * M * N * K
     tf, tg = timeit(fused, reps), timeit(gemm_only, reps)
     y = fused(); gemm_only()
     ref = torch.nn.functional.silu(torch.nn.functional.layer_norm(C, (N,), ga, be, 1e-5)) + (add if skip else 0)
     err = float((y - ref).abs().max())
-    fl = 2.0 * M * N * K
-    print(f"M={M:6d} N={N:5d} K={K:5d}: fused {tf*1e6:8.1f} us ({fl/tf/1e12:5.1f} TF)   gemm_big alone {tg*1e6:8.1f} us ({fl/tg/1e12:5.1f} TF)   max|diff| {err:.2e}", flush=True)
+    extra = ""
+    if os.environ.get("ROWLN_DBG"):
+        for mode in (1, 2, 4, 3):
+            nat.lib().aid_rowln_debug(mode); t = timeit(fused, reps); nat.lib().aid_rowln_debug(0)
+            extra += f"  dbg{mode} {t*1e6:8.1f} us ({fl/t/1e12:5.1f} TF)"
+    print(f"M={M:6d} N={N:5d} K={K:5d}:{extra} fused {tf*1e6:8.1f} us ({fl/tf/1e12:5.1f} TF)   gemm_big alone {tg*1e6:8.1f} us ({fl/tg/1e12:5.1f} TF)   max|diff| {err:.2e}", flush=True)

@@ -638,12 +638,12 @@ def gemm_force_kernel(k: int):
     check(lib().aid_gemm_force_kernel(int(k)), "aid_gemm_force_kernel")
 
 
-def linear_ln_act(x, W, b, gamma, beta, act="silu", add=None):
-    """y = act(LayerNorm(x W^T + b) * gamma + beta) + add  (aid_linear_ln_act: LayerNorm in the GEMM epilogue; N in {512, 1024}, M >= 2048)."""
+def linear_ln_act(x, W, b, gamma, beta, act="silu", add=None, mask=None):
+    """y = act(LayerNorm(x W^T + b) * gamma + beta) * mask + add  (aid_linear_ln_act: LayerNorm in the GEMM epilogue; N in {512, 1024}, M >= 2048)."""
     M, K = x.shape; N = W.shape[0]
     y = torch.empty(M, N, device=x.device, dtype=torch.float32)
     code = {"none": 0, "relu": 1, "silu": 2}[act]
-    check(lib().aid_linear_ln_act(_ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(gamma), _ptr(beta), code, _ptr(add), add.stride(0) if add is not None else N,
+    check(lib().aid_linear_ln_act(_ptr(x), x.stride(0), _ptr(W), _ptr(b), _ptr(gamma), _ptr(beta), code, _ptr(mask), _ptr(add), add.stride(0) if add is not None else N,
                                   _ptr(y), N, M, N, K, _stream()), "aid_linear_ln_act")
     return y
 

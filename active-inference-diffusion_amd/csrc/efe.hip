@@ -40,6 +40,26 @@ __global__ void mine_sample_kernel(const float* __restrict__ nm, const float* __
     const size_t src = ((size_t)k * B + b) * L + l;
     z[i] = nm[src] + eps[i] * (lv ? expf(0.5f * lv[src]) : sd);
 }
+// The four perturbed copies of every sample row, interleaved: zp4[4 r + j] = z[r] + normalize(delta[j][r]) * eps_scale.  Row order
+// (r major, j minor) is what makes the concatenated Jacobian features [R, 4 FE] fall out of ONE 4R-row pass of the feature extractor.
+__global__ void perturb4_kernel(const float* __restrict__ z, const float* __restrict__ d /*[4][R][L]*/, const float* __restrict__ scale,
+                                float* __restrict__ zp4, size_t R, int L) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 4 * R) return;
+    const size_t r = t >> 2; const int j = (int)(t & 3);
+    const float* dj = d + ((size_t)j * R + r) * L;
+    float n2 = 0.f;
+    for (int l = 0; l < L; ++l) { const float v = dj[l]; n2 += v * v; }
+    const float inv = scale[0] / fmaxf(sqrtf(n2), 1e-12f);
+    for (int l = 0; l < L; ++l) zp4[t * L + l] = z[r * L + l] + dj[l] * inv;
+}
+// finite differences of the decoder outputs, in place on the perturbed rows: fp4[4 r + j] = (fp4[4 r + j] - fz[r]) / eps_scale   (:963-970)
+__global__ void fd4_kernel(float* __restrict__ fp4, const float* __restrict__ fz, const float* __restrict__ scale, size_t R, int O) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 4 * R * O) return;
+    const size_t row = i / O; const int o = (int)(i % O);
+    fp4[i] = (fp4[i] - fz[(row >> 2) * O + o]) / scale[0];
+}
 // zp = z + normalize(delta) * eps_scale (F.normalize: / max(||d||, 1e-12))   (:962)
 __global__ void perturb_kernel(const float* __restrict__ z, const float* __restrict__ d, const float* __restrict__ scale,
                                float* __restrict__ zp, size_t R, int L) {
@@ -185,8 +205,12 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     const size_t R = (size_t)K * S * B;
     const int Rm = (int)R;
     const size_t mark = ws.mark();
-    float* z_all = ws.f32(R * L); float* zp = ws.f32(R * L); float* fz = ws.f32(R * O); float* fp = ws.f32(R * O);
-    float* f0 = ws.f32(R * e.fe0.out); float* f1 = ws.f32(R * e.fe2.out);
+    // state branch: the sample rows and their 4 perturbed copies go through the decoder as ONE 5R-row batch (rows [0, R): z, rows R + 4 r + j:
+    // copy j of row r), and the four feature-extractor passes as ONE 4R-row batch: same per-row arithmetic, 128 000-row GEMMs instead of
+    // five 25 600-row ones (no tail effect, a fifth of the launches)
+    const size_t RB = px ? R : 5 * R;
+    float* z_all = ws.f32(RB * L); float* fz = px ? nullptr : ws.f32(RB * O);
+    float* f0 = px ? nullptr : ws.f32(4 * R * e.fe0.out); float* f1 = px ? nullptr : ws.f32(4 * R * e.fe2.out);
     float* jin = ws.f32(R * 4 * e.fe4.out);
     float* comb = ws.f32(R * (e.jp4.out + e.lp2.out)); float* comb_m = ws.f32(R * (e.jp4.out + e.lp2.out));
     float* l0 = ws.f32(R * e.lp0.out);
@@ -200,17 +224,17 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     if (px) {   // pixel branch: ConvDecoder finite differences -> 5x5 convs -> attention aggregator (conv.hip)
         AID_TRY(pixel_jacobian_features(*px->dec, *px->epi, Rm, z_all, delta, px->attn_mask, train, px->seed, px->offset, jin, ws, s));
     } else {
-    AID_TRY(decoder_fwd(dec, Rm, z_all, L, nullptr, fz, O, ws, s));           // decoder in eval mode (:949)
-    for (int j = 0; j < 4; ++j) {
-        LAUNCH1D(perturb_kernel, R, s, z_all, delta + (size_t)j * R * L, e.perturbation_scale, zp, R, L);
-        AID_TRY(decoder_fwd(dec, Rm, zp, L, nullptr, fp, O, ws, s));
-        LAUNCH1D(fd_kernel, R * O, s, fp, fz, e.perturbation_scale, fp, R * O);
-        AID_TRY(linear_fwd(fp, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, Rm, e.fe0.out, O, ACT_RELU, s));
-        AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, Rm, e.fe2.out, e.fe0.out, ACT_RELU, s));
-        AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin + (size_t)j * FE, 4 * FE, Rm, FE, e.fe2.out, ACT_NONE, s));
+        AID_REQUIRE(5 * R < (size_t)1 << 30, AID_E_SHAPE, "mine_forward: %zu sample rows", R);
+        float* zp4 = z_all + R * L; float* fp4 = fz + R * O;
+        LAUNCH1D(perturb4_kernel, 4 * R, s, z_all, delta, e.perturbation_scale, zp4, R, L);
+        AID_TRY(decoder_fwd(dec, (int)(5 * R), z_all, L, nullptr, fz, O, ws, s));       // decoder in eval mode (:949)
+        LAUNCH1D(fd4_kernel, 4 * R * O, s, fp4, fz, e.perturbation_scale, R, O);
+        const int R4 = (int)(4 * R);
+        AID_TRY(linear_fwd(fp4, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, R4, e.fe0.out, O, ACT_RELU, s));
+        AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, R4, e.fe2.out, e.fe0.out, ACT_RELU, s));
+        AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin, FE, R4, FE, e.fe2.out, ACT_NONE, s));   // row 4 r + j of [4R, FE] == columns j FE.. of row r of [R, 4 FE]
     }
-    }
-    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s));
+    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s, nullptr, false));   // gradient-free: nothing saved
     AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, comb, CW, Rm, e.jp4.out, e.jp0.out, ACT_NONE, s));
     AID_TRY(linear_fwd(z_all, L, e.lp0.w, e.lp0.b, l0, e.lp0.out, Rm, e.lp0.out, L, ACT_RELU, s));
     AID_TRY(linear_fwd(l0, e.lp0.out, e.lp2.w, e.lp2.b, comb + e.jp4.out, CW, Rm, e.lp2.out, e.lp0.out, ACT_NONE, s));
@@ -269,7 +293,7 @@ __global__ void scale_out_kernel(float* __restrict__ dst, const float* __restric
 
 static size_t mine_ws_bytes(const AidDecoderNet& dec, int K, int S, int B) {
     const size_t R = (size_t)K * S * B;
-    return decoder_ws_bytes(dec, (int)R) + sizeof(float) * R * (2 * 128 + 2 * dec.O + 128 + 256 + 512 + 2 * 384 + 128 + 1024 + 2 + 1024 + 16) + (1 << 16);
+    return decoder_ws_bytes(dec, (int)(5 * R)) + sizeof(float) * R * (size_t)(5 * (dec.L > 128 ? dec.L : 128) + 5 * dec.O + 4 * 128 + 4 * 256 + 512 + 2 * 384 + 128 + 1024 + 2 + 1024 + 16) + (1 << 16);
 }
 
 }  // namespace aid

@@ -1,4 +1,4 @@
-// Linear -> LayerNorm -> activation (-> skip add) as ONE kernel for tall inputs:  Y = act(LN(A W^T + b) * gamma + beta) + add.
+// Linear -> LayerNorm -> activation (-> dropout mask, skip add) as ONE kernel for tall inputs:  Y = act(LN(A W^T + b) * gamma + beta) * mask + add.
 //
 // Replaces, for the 25 600-row (and, with the perturbed copies batched, 128 000-row) activations of the gradient-free MINE estimator
 // (reference: core/active_inference.py:237-242 `observation_decoder[1..2]` = Linear, LayerNorm, SiLU, Dropout inside
@@ -33,7 +33,8 @@ struct RowLnArgs {
     const float* W; int ldw;             // [BN][K] torch Linear weight
     const float* bias;                   // [BN] or null
     const float* gamma; const float* beta;   // LayerNorm affine, [BN] each (null => 1 / 0)
-    const float* add; int ldadd;         // optional skip, added after the activation
+    const float* add; int ldadd;         // optional skip, added after the activation (and after the mask)
+    const float* mask; int ldmask;       // optional multiplicative (dropout) mask applied to the activation
     float* Y; int ldy;
     int M, K;
     float eps;
@@ -101,22 +102,18 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     }
     const int nk = (g.K + BKT - 1) / BKT;
     f32x4 ra, rb[PB];
-    auto load_stage = [&](int kt) {      // branch-free: clamped k, zeroed at the LDS write
+    // piece p of stage kt: global -> registers (p = 0 .. PB-1: weight pieces, p = PB: the activation piece).  Branch-free: clamped k,
+    // zeroed at the LDS write.
+    auto load_piece = [&](int p, int kt) {
         const int k0 = kt * BKT;
-        if constexpr (KTAIL) {
-            const int ka = (k0 + 4 * a_c < g.K) ? k0 : 0;
+        if (p == PB) {
+            const int ka = (!KTAIL || k0 + 4 * a_c < g.K) ? k0 : 0;
             ra = *reinterpret_cast<const f32x4*>(a_src + ka);
-#pragma unroll
-            for (int i = 0; i < PB; ++i) {
-                const int c = (tid + NT * i) % CPR;
-                const int kb = (k0 + 4 * c < g.K) ? k0 : 0;
-                rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + kb);
-            }
         } else {
-            ra = *reinterpret_cast<const f32x4*>(a_src + k0);
             if constexpr (DBG >= 2) { if (kt > 0) return; }             // timing experiments: no weight loads after the first stage
-#pragma unroll
-            for (int i = 0; i < PB; ++i) rb[i] = *reinterpret_cast<const f32x4*>(b_src[i] + (DBG == 1 ? k0 * (BN / 4) : k0));
+            const int c = (tid + NT * p) % CPR;
+            const int kb = (!KTAIL || k0 + 4 * c < g.K) ? k0 : 0;
+            rb[p] = *reinterpret_cast<const f32x4*>(b_src[p] + (DBG == 1 ? kb * (BN / 4) : kb));
         }
     };
     // piece p of the staged tile -> LDS buffer `buf` (p = 0 .. PB-1: weight pieces, p = PB: the activation piece)
@@ -133,9 +130,11 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     // One stage: NM = 64 MFMAs per wave.  The hand-over work of the NEXT stage (wait for its global loads, write its PB + 1 pieces to the
     // other LDS buffer) is spread over the second half of this stage's MFMAs: an fp32 MFMA occupies the matrix pipe for 64 cycles but the
     // issue port for 8, so the same wave's ds_write / s_waitcnt issue in its shadow instead of in a phase of their own in which (both
-    // waves of a SIMD being in lock-step behind the workgroup barrier) the pipe would idle.
-    constexpr int NG = BKT / 8, NM = NG * 4 * 2 * TN, NS = PB + 1, S0 = NM / 2, STEP = (NM - S0) / NS;
-    static_assert(STEP >= 1, "more hand-over pieces than MFMA slots");
+    // waves of a SIMD being in lock-step behind the workgroup barrier) the pipe would idle.  The global loads of the next stage are
+    // spread over the FIRST half the same way: issued as one burst behind the barrier, the 72 wave-instructions of a workgroup queue at
+    // the CU's one address unit and every wave sits in that queue before it can issue its first MFMA (measured: 0.4 - 1.2 us per stage).
+    constexpr int NG = BKT / 8, NM = NG * 4 * 2 * TN, NS = PB + 1, S0 = NM / 2, STEP = (NM - S0) / NS, LSTEP = S0 / NS;
+    static_assert(STEP >= 1 && LSTEP >= 1, "more hand-over pieces than MFMA slots");
     auto stage = [&](int cur, int kt_next) {
         const float* a_s = As + cur * A_FL;
         const float* b_s = Bs + cur * B_FL;
@@ -161,6 +160,10 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
 #pragma unroll
                             for (int j2 = 0; j2 < TN; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j2 + li, 2 * (g8 + 1) + h));
                         }
+                        if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) {
+                            load_piece(idx / LSTEP, kt_next);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                         if (idx >= S0 && (idx - S0) % STEP == 0 && (idx - S0) / STEP < NS) {
                             if constexpr (DBG < 3) store_piece((idx - S0) / STEP, kt_next, cur ^ 1);      // DBG 3, 4: no LDS hand-over writes
                             __builtin_amdgcn_sched_barrier(0);           // pin the piece here: the scheduler otherwise sinks every write to the end
@@ -168,7 +171,8 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
                     }
         }
     };
-    load_stage(0);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) load_piece(p, 0);
 #pragma unroll
     for (int p = 0; p < NS; ++p) store_piece(p, 0, 0);
     __syncthreads();
@@ -176,8 +180,6 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
         const int cur = kt & 1;
         // the last iteration re-loads its own stage and writes it to the idle buffer: nobody reads it, and the loop stays branch-free
         const int ktn = kt + 1 < nk ? kt + 1 : kt;
-        load_stage(ktn);
-        __builtin_amdgcn_sched_barrier(0);           // keep the prefetch ahead of the MFMA block
         stage(cur, ktn);
         if constexpr (DBG != 3) __syncthreads();     // DBG 3: no barrier either (fragment reads + MFMAs only)
     }
@@ -242,25 +244,41 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     float gcol[TN], becol[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) { gcol[j] = g.gamma ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = g.beta ? g.beta[wn + 32 * j + li] : 0.f; }
+    // 8 groups of 4 rows x TN columns per lane; the skip values of group gq + 1 are loaded before group gq is finished and stored, so
+    // their latency hides behind the previous group's math and stores (one workgroup per CU: nothing else would cover it)
+    float sk[2][4][TN], mk[2][4][TN];
+    auto load_aux = [&](int gq, int pb) {
+        const int i = gq >> 2, rq = gq & 3;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int e = 0; e < 4; ++e) {
+            const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
 #pragma unroll
-        for (int rq = 0; rq < 4; ++rq) {
-            const f32x4 r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
-                if (row < g.M) {
-#pragma unroll
-                    for (int j = 0; j < TN; ++j) {
-                        const int col = wn + 32 * j + li;
-                        float o = rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]);
-                        if (g.add) o += g.add[(size_t)row * g.ldadd + col];
-                        g.Y[(size_t)row * g.ldy + col] = o;
-                    }
-                }
+            for (int j = 0; j < TN; ++j) {
+                if (g.add) sk[pb][e][j] = g.add[(size_t)row * g.ldadd + wn + 32 * j + li];
+                if (g.mask) mk[pb][e][j] = g.mask[(size_t)row * g.ldmask + wn + 32 * j + li];
             }
         }
+    };
+    const bool aux = g.add || g.mask;
+    if (aux) load_aux(0, 0);
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        const int i = gq >> 2, rq = gq & 3, pb = gq & 1;
+        if (aux && gq + 1 < 8) load_aux(gq + 1, pb ^ 1);
+        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn + 32 * j + li;
+                float o = rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]);
+                if (g.mask) o *= mk[pb][e][j];
+                if (g.add) o += sk[pb][e][j];
+                if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
+            }
+        }
+    }
 }
 
 template <int BN, int BKT, int ACT, bool KTAIL>
@@ -300,16 +318,16 @@ static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
 }
 
 bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy) {
-    const bool al = ((((uintptr_t)x | (uintptr_t)W | (uintptr_t)add | (uintptr_t)y) & 15) == 0) && ldx % 4 == 0 && K % 4 == 0 && ldy % 4 == 0 && ldadd % 4 == 0;
+    const bool al = ((((uintptr_t)x | (uintptr_t)W) & 15) == 0) && ldx % 4 == 0 && K % 4 == 0;
     return al && M >= 2048 && (N == 512 || N == 1024) && K >= 64 && (act == ACT_SILU || act == ACT_RELU || act == ACT_NONE);
 }
 
 // y[M,N] = act(LN(x W^T + b) * gamma + beta) + add, N in {512, 1024}; x [M,K] (row stride ldx), W [N,K] contiguous rows.
 int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act, const float* add,
-                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s) {
+                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s, const float* mask, int ldmask) {
     AID_REQUIRE(linear_ln_act_rows_ok(M, N, K, act, x, ldx, W, add, ldadd, y, ldy), AID_E_SHAPE, "linear_ln_act_rows: unsupported M=%d N=%d K=%d act=%d", M, N, K, act);
     RowLnArgs g; memset(&g, 0, sizeof(g));
-    g.A = x; g.lda = ldx; g.W = W; g.ldw = K; g.bias = b; g.gamma = gamma; g.beta = beta; g.add = add; g.ldadd = ldadd; g.Y = y; g.ldy = ldy;
+    g.A = x; g.lda = ldx; g.W = W; g.ldw = K; g.bias = b; g.gamma = gamma; g.beta = beta; g.add = add; g.ldadd = ldadd; g.mask = mask; g.ldmask = ldmask; g.Y = y; g.ldy = ldy;
     g.M = M; g.K = K; g.eps = 1e-5f;
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     prof.m = M; prof.n = N; prof.k = K; prof.layout = 0; prof.variant = N == 1024 ? 20 : 21;
@@ -328,7 +346,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 using namespace aid;
 extern "C" int aid_rowln_debug(int mode) { g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
-                                 const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
+                                 const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");
-    return linear_ln_act_rows(x, ldx, W, b, gamma, beta, act, add, ldadd, y, ldy, M, N, K, (hipStream_t)stream);
+    return linear_ln_act_rows(x, ldx, W, b, gamma, beta, act, add, ldadd, y, ldy, M, N, K, (hipStream_t)stream, mask, N);
 }

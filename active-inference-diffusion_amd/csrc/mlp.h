@@ -13,7 +13,7 @@ int axpby_cols(const float* a, int lda, float alpha, const float* b, int ldb, fl
 // Linear -> LayerNorm -> activation (-> + add) in ONE full-row-tile MFMA kernel (gemm_rowln.hip): tall inference inputs, N in {512, 1024}
 bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy);
 int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act, const float* add,
-                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s);
+                       int ldadd, float* y, int ldy, int M, int N, int K, hipStream_t s, const float* mask = nullptr, int ldmask = 0);
 
 // y = act(LN(x W^T + b)) * mask      (Linear -> LayerNorm -> activation [-> dropout])
 struct LlaSave { float *lin, *stats, *y; };

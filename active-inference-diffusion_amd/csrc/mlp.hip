@@ -41,8 +41,8 @@ int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, con
     if (lin_smallk_ln_act_ok(l.in, l.out, act, l.w, sv.y, need_lin ? sv.lin : nullptr, mask, l.out) && ((((uintptr_t)add | (uintptr_t)l.b | (uintptr_t)ln.g | (uintptr_t)ln.b) & 15) == 0))
         return lin_smallk_ln_act(x, ldx, l.in, l.w, l.b, ln.g, ln.b, act, mask, add, need_lin ? sv.lin : nullptr, sv.y, l.out, need_lin ? sv.stats : nullptr, M, l.out, s);
     // inference on tall inputs (the estimator's 25 600+ sample rows): the LayerNorm lives in the GEMM's epilogue, nothing but y is written
-    if (!need_lin && !mask && linear_ln_act_rows_ok(M, l.out, l.in, act, x, ldx, l.w, add, l.out, sv.y, l.out))
-        return linear_ln_act_rows(x, ldx, l.w, l.b, ln.g, ln.b, act, add, l.out, sv.y, l.out, M, l.out, l.in, s);
+    if (!need_lin && linear_ln_act_rows_ok(M, l.out, l.in, act, x, ldx, l.w, add, l.out, sv.y, l.out))
+        return linear_ln_act_rows(x, ldx, l.w, l.b, ln.g, ln.b, act, add, l.out, sv.y, l.out, M, l.out, l.in, s, mask, l.out);
     AID_TRY(linear_fwd(x, ldx, l.w, l.b, sv.lin, l.out, M, l.out, l.in, ACT_NONE, s));
     AID_TRY(ln_act(sv.lin, l.out, ln.g, ln.b, act, mask, sv.y, l.out, sv.stats, M, l.out, s, add));
     return AID_OK;

@@ -63,12 +63,12 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
                  int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha,
                  int accumulate, void* stream);
 
-/* y[M,N] = act(LayerNorm(x W^T + b) * gamma + beta) + add in ONE kernel (full-row tiles, LayerNorm in the GEMM epilogue; csrc/gemm_rowln.hip):
- * N in {512, 1024}, M >= 2048, K >= 64 and a multiple of 4, 16-B aligned operands, act in {0 none, 1 relu, 2 silu}; add / gamma / beta / b
+/* y[M,N] = act(LayerNorm(x W^T + b) * gamma + beta) * mask + add in ONE kernel (full-row tiles, LayerNorm in the GEMM epilogue; csrc/gemm_rowln.hip):
+ * N in {512, 1024}, M >= 2048, K >= 64 and a multiple of 4, 16-B aligned operands, act in {0 none, 1 relu, 2 silu}; mask [M,N] (row stride N) / add / gamma / beta / b
  * may be NULL.  What Linear -> LayerNorm -> SiLU stages of the observation decoder run as on the estimator's sample rows
  * (core/active_inference.py:237-242, 940-993).  Unit-test / bench entry. */
 int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
-                      const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream);
+                      const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream);
 
 /* C[M,N] += A[M,K] W[N,K]^T + bias with K split over `ksplit` workgroups that atomically add into C (C holds the residual).
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */

@@ -372,6 +372,11 @@ def test_linear_ln_act_full_row_kernel(nat, M, N, K, act, skip):
         ref = ref + T(add).double()
     got = nat.linear_ln_act(dev(x), dev(W), dev(b), dev(ga), dev(be), act, dev(add) if skip else None)
     np.testing.assert_allclose(got.cpu().numpy(), ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    if M <= 4100:      # dropout mask between the activation and the skip (train-mode Linear-LN-act-Dropout stages)
+        mask = ((rng.random((M, N)) >= 0.1) / 0.9).astype(np.float32)
+        gm = nat.linear_ln_act(dev(x), dev(W), dev(b), dev(ga), dev(be), act, dev(add) if skip else None, dev(mask))
+        refm = (ref - (T(add).double() if skip else 0)) * T(mask).double() + (T(add).double() if skip else 0)
+        np.testing.assert_allclose(gm.cpu().numpy(), refm.float().numpy(), rtol=2e-5, atol=2e-5)
     # and against the two-kernel path the small-M layers keep using (GEMM, then the row-wise LayerNorm kernel)
     two = torch.empty(M, N, device="cuda")
     nat.gemm(dev(x), dev(W), two, M, N, K, K, K, N, bias=dev(b))

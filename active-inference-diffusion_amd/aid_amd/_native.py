@@ -648,6 +648,29 @@ def linear_ln_act(x, W, b, gamma, beta, act="silu", add=None, mask=None):
     return y
 
 
+def gemm_mid(A, W, bias=None, act="none", residual=None, ksplit=1):
+    """aid_gemm_mid: ksplit == 1 -> C [M,N] = act(A W^T + bias) + residual;  ksplit > 1 -> slabs [ksplit, M, N] of raw partial products."""
+    M, K = A.shape; N = W.shape[0]
+    if ksplit == 1:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        check(lib().aid_gemm_mid(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), ACT[act], _ptr(residual), residual.stride(0) if residual is not None else 0,
+                                 _ptr(out), N, None, M, N, K, 1, _stream()), "aid_gemm_mid")
+        return out
+    slab = torch.empty(ksplit, M, N, device=A.device, dtype=torch.float32)
+    check(lib().aid_gemm_mid(_ptr(A), A.stride(0), _ptr(W), W.stride(0), None, 0, None, 0, None, 0, _ptr(slab), M, N, K, ksplit, _stream()), "aid_gemm_mid")
+    return slab
+
+
+def adaln_sum(res, slab, bias, mod, want_x=True):
+    """aid_adaln_sum: x = res + bias + sum(slab, 0); y = LN(x) (1 + mod[:, :D]) + mod[:, D:] -> (x or None, y)"""
+    M, D = res.shape
+    x = torch.empty_like(res) if want_x else None
+    y = torch.empty_like(res)
+    check(lib().aid_adaln_sum(_ptr(res), D, _ptr(slab), 0 if slab is None else slab.shape[0], _ptr(bias), _ptr(mod), mod.stride(0), _ptr(x), D, _ptr(y), D,
+                              M, D, _stream()), "aid_adaln_sum")
+    return x, y
+
+
 def gemm_ksplit_add(A, W, C_out, bias, ksplit):
     M, K = A.shape; N = W.shape[0]
     check(lib().aid_gemm_ksplit_add(_ptr(A), K, _ptr(W), K, _ptr(C_out), N, M, N, K, _ptr(bias), int(ksplit), _stream()), "aid_gemm_ksplit_add")

@@ -1,0 +1,286 @@
+// Mid-M GEMM for the reverse-diffusion loop: C[M,N] = act(A W^T + b) (+ residual), or split-K partial slabs, at 129..1024 rows.
+//
+// Where it runs: the z-dependent trunk of one denoise step (reference: core/diffusion.py:176-206 -> models/score_networks.py:214-235,
+// DiTBlock.forward) at the 256 / 512 / 768 rows a train_step's merged belief updates have.  Per block that is x Wov^T (512x512),
+// x W1^T + GELU (512 -> 2048) and u W2^T (2048 -> 512): 0.1 - 1.6 GFLOP each, i.e. 1 - 10 us of the chip's fp32 matrix pipes, fifty
+// times six times per loop.  The 64x64-tile kernels left the pipes mostly idle on these shapes: 384 tiles on 256 CUs (1.5 rounds),
+// 96 tiles for the 512-wide outputs, every K tile behind a workgroup barrier with nothing else resident on the CU to fill it.
+//
+// MI355X mapping
+//   * exactly one workgroup per CU: the row count is cut into 8 row tiles (BM = 32 ceil(M / 256): 96 rows at M = 768), columns into
+//     64-wide tiles, and the K dimension of the 512-wide outputs into `ksplit` slices, so that a layer is 8 x 32 (x 1) or 8 x 8 x 4 = 256
+//     equal work items.  Split-K slices write raw partial tiles to slabs [ksplit][M][N]; the NEXT kernel of the chain (the adaLN that
+//     consumes the residual stream anyway, aid::adaln_sum) adds them up in a fixed order - no atomics, no extra launch, reproducible.
+//   * 4 waves as 2 x 2, each (BM/2) x 32 outputs = BMT x 2 accumulators of v_mfma_f32_16x16x4_f32 (32-cycle issue, so a 96 x 64 x 64
+//     stage is 3 072 cycles of each SIMD's pipe; 24 accumulator registers leave room for two stages of prefetch).
+//   * K in stages of 64: [rows][64] LDS images with the 16-B chunk index XOR-ed by (row & 15) - b128 staging writes and b128 fragment
+//     reads are bank-conflict free (checked exhaustively: tools/perf/README.md) - double buffered (80 KB at BM = 96).
+//   * register staging with the hand-over hidden in the MFMA stream (the structure measured on gemm_rowln): the next stage's 6 + 4 global
+//     loads are issued one by one between the MFMAs of the first half of a stage, its LDS writes between those of the second half, the
+//     fragments of k-group g + 1 are read while group g is contracted; one barrier per stage.
+//   * a lane's float4 fragment holds k = 16 g + 4 (lane >> 4) + {0..3} of its row; MFMA j of the group contracts element j of every
+//     lane, i.e. k in {16 g + j, + 4, + 8, + 12}: the same permutation for both operands, so the reduction order is fixed and k-contiguous
+//     operands need no transpose.
+//   * blockIdx -> tile: the 8 row tiles of one (column tile, K slice) sit on ONE XCD (b % 8 labels the XCD group; speed only), so a
+//     weight panel is pulled from the Infinity Cache once per layer and the 1.5 MB activation operand once per XCD.
+#include "aid_common.h"
+#include "rowwise.h"
+
+namespace aid {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct MidArgs {
+    const float* A; int lda;              // [M][K]
+    const float* W; int ldw;              // [N][K]
+    const float* bias;                    // [N] or null (ignored in slab mode)
+    const float* residual; int ldr;       // optional, added after the activation (ksplit == 1 only)
+    float* C; int ldc;                    // ksplit == 1: output; else unused
+    float* slab;                          // ksplit > 1: [ksplit][M][N] raw partial products
+    int M, N, K, ksplit, act;
+};
+
+constexpr int MID_BK = 64, MID_BN = 64;
+__device__ __forceinline__ int mid_off(int row, int chunk) { return row * MID_BK + ((chunk ^ (row & 15)) << 2); }
+
+template <int ACT> __device__ __forceinline__ float mid_act(float x) {
+    if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
+    else if constexpr (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + expf(-x));
+    else if constexpr (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
+    else return x;
+}
+
+template <int BMT, int ACT>
+__global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) {
+    constexpr int NT = 256, BM = 32 * BMT, BN = MID_BN, BK = MID_BK, CPR = BK / 4;
+    constexpr int A_FL = BM * BK, B_FL = BN * BK;
+    constexpr int PA = BM * CPR / NT, PB = BN * CPR / NT, NS = PA + PB;          // float4 pieces per thread per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                 // [2][BM][BK]
+    float* Bs = smem + 2 * A_FL;      // [2][BN][BK]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    // tile map: T = (column tile, K slice) pairs; whole rounds of 8 pairs go one per XCD group, each with its `tiles_m` row tiles
+    int tm, tn, ky;
+    {
+        const int b = blockIdx.x, npair = tiles_n * g.ksplit, n8 = npair & ~7, full = n8 * tiles_m;
+        int T;
+        if (b < full) { const int x = b & 7, q = b >> 3; T = x + 8 * (q / tiles_m); tm = q % tiles_m; }
+        else { const int r = b - full; T = n8 + r / tiles_m; tm = r % tiles_m; }
+        tn = T % tiles_n; ky = T / tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kper = g.K / g.ksplit, kbeg = ky * kper, nk = kper / BK;
+    f32x4 acc[BMT][2];
+#pragma unroll
+    for (int i = 0; i < BMT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging maps: piece p < PA is an A piece, else a W piece; thread f = tid + NT p covers (row f / 16, chunk f % 16)
+    const float* src[NS]; int dst[NS];
+#pragma unroll
+    for (int p = 0; p < NS; ++p) {
+        const int f = tid + NT * (p < PA ? p : p - PA), row = f / CPR, c = f % CPR;
+        if (p < PA) { src[p] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * c; dst[p] = mid_off(row, c); }
+        else        { src[p] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + kbeg + 4 * c; dst[p] = 2 * A_FL + mid_off(row, c); }
+    }
+    f32x4 rg[NS];
+    auto load_piece = [&](int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + kt * BK); };
+    auto store_piece = [&](int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
+    constexpr int NG = BK / 16, MPG = 4 * BMT * 2, NM = NG * MPG, S0 = NM / 2;
+    constexpr int LSTEP = S0 / NS > 0 ? S0 / NS : 1, SSTEP = (NM - S0) / NS > 0 ? (NM - S0) / NS : 1;
+    static_assert(S0 / NS >= 1, "more staging pieces than MFMA slots in half a stage");
+    auto stage = [&](int cur, int kt_next) {
+        const float* a_s = As + cur * A_FL + (wm + r16) * BK;
+        const float* b_s = Bs + cur * B_FL + (wn + r16) * BK;
+        // (row & 15) == r16 for every fragment row of this lane: the swizzle term is lane-constant
+        f32x4 av[2][BMT], bv[2][2];
+#pragma unroll
+        for (int i = 0; i < BMT; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(a_s + 16 * i * BK + ((kq ^ r16) << 2));
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(b_s + 16 * j * BK + ((kq ^ r16) << 2));
+#pragma unroll
+        for (int gk = 0; gk < NG; ++gk) {
+            const int pc = gk & 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < BMT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int idx = ((gk * 4 + q) * BMT + i) * 2 + j;
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pc][i][q], bv[pc][j][q], acc[i][j], 0, 0, 0);
+                        if (q == 0 && i == 0 && j == 1 && gk + 1 < NG) {      // next k-group's fragments, early in this group
+#pragma unroll
+                            for (int i2 = 0; i2 < BMT; ++i2) av[pc ^ 1][i2] = *reinterpret_cast<const f32x4*>(a_s + 16 * i2 * BK + (((4 * (gk + 1) + kq) ^ r16) << 2));
+#pragma unroll
+                            for (int j2 = 0; j2 < 2; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + 16 * j2 * BK + (((4 * (gk + 1) + kq) ^ r16) << 2));
+                        }
+                        if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) { load_piece(idx / LSTEP, kt_next); __builtin_amdgcn_sched_barrier(0); }
+                        if (idx >= S0 && (idx - S0) % SSTEP == 0 && (idx - S0) / SSTEP < NS) { store_piece((idx - S0) / SSTEP, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+                    }
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NS; ++p) load_piece(p, 0);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) store_piece(p, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        // the last stage re-loads itself into the idle buffer (never read): the loop stays branch-free
+        stage(kt & 1, kt + 1 < nk ? kt + 1 : kt);
+        __syncthreads();
+    }
+    // ---- epilogue.  C/D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + {0..3}
+#pragma unroll
+    for (int i = 0; i < BMT; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn + 16 * j + r16;
+            const float bcol = (g.ksplit == 1 && g.bias && col < g.N) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int row = m0 + wm + 16 * i + 4 * kq + e;
+                if (row < g.M && col < g.N) {
+                    if (g.ksplit > 1) g.slab[((size_t)ky * g.M + row) * g.N + col] = acc[i][j][e];
+                    else {
+                        float v = mid_act<ACT>(acc[i][j][e] + bcol);
+                        if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                        g.C[(size_t)row * g.ldc + col] = v;
+                    }
+                }
+            }
+        }
+}
+
+template <int BMT, int ACT>
+static int launch_mid(const MidArgs& g, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 2 * ((size_t)32 * BMT * MID_BK + (size_t)MID_BN * MID_BK);
+    static bool attr_done = false;
+    if (lds > 65536 && !attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_mid_kernel<BMT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const int tiles_m = (g.M + 32 * BMT - 1) / (32 * BMT), tiles_n = (g.N + MID_BN - 1) / MID_BN;
+    hipLaunchKernelGGL((gemm_mid_kernel<BMT, ACT>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+template <int ACT>
+static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
+    const int bmt = (g.M + 255) / 256;        // 8 row tiles: BM = 32 ceil(M / 256)
+    switch (bmt) {
+        case 1: return launch_mid<1, ACT>(g, s);
+        case 2: return launch_mid<2, ACT>(g, s);
+        case 3: return launch_mid<3, ACT>(g, s);
+        default: return launch_mid<4, ACT>(g, s);
+    }
+}
+
+bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
+    const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
+    return al && M > 128 && M <= 1024 && N >= 64 && ksplit >= 1 && K % (MID_BK * ksplit) == 0 && K / ksplit >= MID_BK &&
+           (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU || act == ACT_RELU);
+}
+
+// ksplit == 1: C = act(A W^T + bias) + residual.  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T (raw partials; bias / act / residual are the
+// consumer's: adaln_sum or slab_sum); act must be NONE then.
+int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+             float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
+    AID_REQUIRE(gemm_mid_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
+    AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && act == ACT_NONE && !residual), AID_E_SHAPE, "gemm_mid: split-K writes raw slabs only");
+    MidArgs g; memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.slab = slab;
+    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
+    ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 0; prof.variant = 22;
+    switch (act) {
+        case ACT_GELU: return launch_mid_bm<ACT_GELU>(g, s);
+        case ACT_SILU: return launch_mid_bm<ACT_SILU>(g, s);
+        case ACT_RELU: return launch_mid_bm<ACT_RELU>(g, s);
+        default: return launch_mid_bm<ACT_NONE>(g, s);
+    }
+}
+
+// ---- consumers of the split-K slabs ---------------------------------------------------------------------------------------------
+// x_new = res + bias + sum_y slab[y]  (fixed order);  y = LN(x_new) (1 + scale) + shift with [scale | shift] = mod row.  One wave per
+// row, D = 256 NV.  Writes x_new (the residual stream) and y.  Reference: DiTBlock.forward's `x = x + ...` followed by the next adaLN
+// (models/score_networks.py:214-235, 257-270).
+template <int NV>
+__global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const float* __restrict__ slab, int nslab, size_t slab_stride,
+                                 const float* __restrict__ bias, const float* __restrict__ mod, int ldmod, float* __restrict__ xout, int ldxo,
+                                 float* __restrict__ y, int ldy, int M) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
+    const f4* sh = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod + D);
+    f4 v[NV], a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] = reinterpret_cast<const f4*>(res + (size_t)row * ldres)[lane + 64 * i];
+        a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i];
+        if (bias) v[i] += reinterpret_cast<const f4*>(bias)[lane + 64 * i];
+    }
+    for (int y0 = 0; y0 < nslab; ++y0) {
+        const f4* sp = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += sp[lane + 64 * i];
+    }
+    if (xout) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) reinterpret_cast<f4*>(xout + (size_t)row * ldxo)[lane + 64 * i] = v[i];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + b[i][j];
+        reinterpret_cast<f4*>(y + (size_t)row * ldy)[lane + 64 * i] = o;
+    }
+}
+
+bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
+                  const float* y, int ldy) {
+    return (D == 256 || D == 512 || D == 1024) && ((((uintptr_t)res | (uintptr_t)slab | (uintptr_t)bias | (uintptr_t)mod | (uintptr_t)xout | (uintptr_t)y) & 15) == 0) &&
+           ldres % 4 == 0 && ldmod % 4 == 0 && ldxo % 4 == 0 && ldy % 4 == 0;
+}
+int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
+              float* y, int ldy, int M, int D, hipStream_t s) {
+    AID_REQUIRE(adaln_sum_ok(D, res, ldres, slab, bias, mod, ldmod, xout, ldxo, y, ldy), AID_E_SHAPE, "adaln_sum: D=%d or alignment unsupported", D);
+    const dim3 grid((M + 3) / 4);
+    const size_t stride = (size_t)M * D;
+    if (D == 256) hipLaunchKernelGGL(adaln_sum_kernel<1>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
+    else if (D == 512) hipLaunchKernelGGL(adaln_sum_kernel<2>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
+    else hipLaunchKernelGGL(adaln_sum_kernel<4>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+}  // namespace aid
+
+using namespace aid;
+extern "C" {
+int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+                 float* slab, int M, int N, int K, int ksplit, void* stream) {
+    AID_REQUIRE(A && W, AID_E_NULL, "aid_gemm_mid: null operand");
+    return gemm_mid(A, lda, W, ldw, bias, act, residual, ldr, C, ldc, slab, M, N, K, ksplit, (hipStream_t)stream);
+}
+int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
+                  float* y, int ldy, int M, int D, void* stream) {
+    AID_REQUIRE(res && mod && y, AID_E_NULL, "aid_adaln_sum: null tensor");
+    return adaln_sum(res, ldres, slab, nslab, bias, mod, ldmod, xout, ldxo, y, ldy, M, D, (hipStream_t)stream);
+}
+}

@@ -48,6 +48,16 @@ int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const floa
 int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
                   const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
 
+// ---- mid-M GEMM of the reverse loop (gemm_mid.hip): 129..1024 rows, one workgroup per CU, optional split-K into raw slabs
+bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
+int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+             float* slab, int M, int N, int K, int ksplit, hipStream_t s);
+// x_new = res + bias + sum of `nslab` slabs [M,D] (fixed order) -> xout (optional);  y = LN(x_new) (1 + scale) + shift (adaLN, mod row = [scale | shift])
+bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
+                  const float* y, int ldy);
+int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
+              float* y, int ldy, int M, int D, hipStream_t s);
+
 int fill_const(float* p, float v, size_t n, hipStream_t s);
 int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 int copy_f32(const float* a, float* out, size_t n, hipStream_t s);

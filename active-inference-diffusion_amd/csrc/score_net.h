@@ -48,7 +48,8 @@ int score_obs_stage0(const AidScoreNet& n, int B, const float* obs, ScoreActs& a
 // rest of the obs path + cond/sc + all 13 modulations.  temb row stride ld_temb (0 = shared row).
 int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float* temb, int ld_temb, ScoreActs& a, hipStream_t s);
 // out_proj(V_proj(x)) collapsed into one weight per block (valid while the weights do not change: inference loops)
-struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; };
+// slab: [4][rows][D] scratch for the split-K partial products of the mid-M pipeline (null: not used)
+struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; float* slab = nullptr; };
 int score_fuse_attention(const AidScoreNet& n, Workspace& ws, ScoreFused& f, hipStream_t s);
 // latent_proj, DiT blocks, final adaLN, output_proj -> a.raw [B,L]
 int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused = nullptr, bool skip_last = false);

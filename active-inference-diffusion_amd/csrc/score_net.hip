@@ -133,8 +133,43 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
     return score_cond_mod(n, B, temb, ld_temb, a, s);
 }
 
+// The z-dependent trunk at 129..1024 rows (the merged belief updates of a train_step: 256 / 512 / 768 rows), inference only.  Same
+// arithmetic as score_trunk below; what changes is the work decomposition: every GEMM is exactly one workgroup per CU (gemm_mid), the two
+// 512-wide products of a block are split four ways over K into raw slabs, and the adaLN that follows them - it reads the residual stream
+// anyway - adds the slabs, the bias and the residual in a fixed order (adaln_sum).  36 launches per step as before, each about half as long.
+static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const ScoreFused* f) {
+    const int D = n.D;
+    if (!f || !f->slab || n.n_blocks < 1) return false;
+    const ScoreBlockActs& b = a.blk[0];
+    return gemm_mid_ok(B, D, D, 4, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
+           gemm_mid_ok(B, D, 4 * D, 4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
+           adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
+}
+static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, const ScoreFused& f, bool skip_last) {
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = 4;
+    AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
+    const float* pend_res = nullptr; const float* pend_bias = nullptr;      // a residual stream still waiting for its slabs
+    for (int i = 0; i < n.n_blocks; ++i) {
+        const AidDiTBlock& w = n.blk[i];
+        ScoreBlockActs& b = a.blk[i];
+        const float* mod1 = a.mod + (size_t)(2 * i) * 2 * D; const float* mod2 = a.mod + (size_t)(2 * i + 1) * 2 * D;
+        if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
+        AID_TRY(gemm_mid(b.nx1, D, f.wov[i], D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D, D, KS, s));
+        AID_TRY(adaln_sum(b.h_in, D, f.slab, KS, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
+        AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
+        AID_TRY(gemm_mid(b.u, 4 * D, w.mlp2_w, 4 * D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D, 4 * D, KS, s));
+        pend_res = b.h_mid; pend_bias = w.mlp2_b;                                                               // h_out = h_mid + u W2^T + b2
+    }
+    AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
+    AID_TRY(linear_fwd(a.nxf, D, n.op0_w, n.op0_b, a.p0, D / 2, B, D / 2, D, ACT_SILU, s, a.p0_pre));
+    if (!skip_last) AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
+    return AID_OK;
+}
+
 int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused, bool skip_last) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
+    if (!keep && trunk_mid_ok(n, B, a, fused)) return score_trunk_mid(n, B, z, a, s, *fused, skip_last);
     AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     for (int i = 0; i < n.n_blocks; ++i) {
         const AidDiTBlock& w = n.blk[i];
@@ -226,6 +261,7 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D) + (size_t)n_steps * B * L);
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
+    n += sizeof(float) * 4 * (size_t)B * D + 256;                    // split-K slabs of the mid-M pipeline
     return n + (1 << 16);
 }
 
@@ -293,6 +329,7 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* mod_all = ws.f32((size_t)C * B * ldmod);
     ScoreFused fused;
     AID_TRY(score_fuse_attention(n, ws, fused, s));
+    if (B > 128 && B <= 1024) { fused.slab = ws.f32((size_t)4 * B * D); AID_WS_OK(ws); }      // mid-M pipeline (score_trunk_mid)
     ScoreActs a;
     AID_TRY(score_acts_alloc(n, B > N ? B : N, false, ws, a));
     float* mod_own = a.mod;

@@ -70,6 +70,16 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
 int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                       const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream);
 
+/* Mid-M GEMM of the reverse loop (csrc/gemm_mid.hip; 128 < M <= 1024, one workgroup per CU): ksplit == 1: C = act(A W^T + bias) + residual
+ * (act: 0 none, 1 relu, 2 silu, 3 gelu);  ksplit > 1 (K % (64 ksplit) == 0): slab[y][M][N] = raw partial product of K slice y (bias / act /
+ * residual belong to the consumer).  aid_adaln_sum is that consumer for the DiT blocks (models/score_networks.py:214-235, 257-270):
+ * x_new = res + bias + sum_y slab[y] in a fixed order -> xout (optional), y = LayerNorm(x_new) (1 + mod[:, :D]) + mod[:, D:].
+ * Unit-test / bench entries; the reverse loop calls them through aid_denoise_loop. */
+int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+                 float* slab, int M, int N, int K, int ksplit, void* stream);
+int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
+                  float* y, int ldy, int M, int D, void* stream);
+
 /* C[M,N] += A[M,K] W[N,K]^T + bias with K split over `ksplit` workgroups that atomically add into C (C holds the residual).
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,

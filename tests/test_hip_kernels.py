@@ -383,3 +383,47 @@ def test_linear_ln_act_full_row_kernel(nat, M, N, K, act, skip):
     ref32 = torch.nn.functional.layer_norm(two, (N,), dev(ga), dev(be), 1e-5)
     ref32 = {"silu": torch.nn.functional.silu, "relu": torch.relu, "none": lambda v: v}[act](ref32) + (dev(add) if skip else 0)
     np.testing.assert_allclose(got.cpu().numpy(), ref32.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M", [129, 256, 300, 512, 768, 1000, 1024])
+def test_gemm_mid_and_adaln_sum(nat, M):
+    """The mid-M pipeline of the reverse loop (csrc/gemm_mid.hip): one-workgroup-per-CU GEMM with GELU / bias / residual epilogue, its split-K
+    slab form, and the adaLN that folds the slabs into the residual stream, against float64 torch.  Row counts: every BM the kernel
+    instantiates (32 / 64 / 96 / 128-row tiles), ragged ones included.  Reference ops: models/score_networks.py:214-235 (DiTBlock.forward)."""
+    rng = np.random.default_rng(M)
+    D = 512
+    T = lambda a: torch.from_numpy(a).double()
+    x = rng.standard_normal((M, D)).astype(np.float32)
+    W1 = (rng.standard_normal((4 * D, D)) / np.sqrt(D)).astype(np.float32); b1 = rng.standard_normal(4 * D).astype(np.float32)
+    W2 = (rng.standard_normal((D, 4 * D)) / np.sqrt(4 * D)).astype(np.float32); b2 = rng.standard_normal(D).astype(np.float32)
+    res = rng.standard_normal((M, D)).astype(np.float32)
+    # ksplit = 1: GELU(x W1^T + b1)
+    u = nat.gemm_mid(dev(x), dev(W1), dev(b1), "gelu")
+    u_ref = torch.nn.functional.gelu(T(x) @ T(W1).T + T(b1))
+    np.testing.assert_allclose(u.cpu().numpy(), u_ref.float().numpy(), rtol=1e-5, atol=2e-6)
+    # ksplit = 1 with residual, no activation, N not a multiple of the 64-column tile
+    Wn = W2[:200, :D].copy(); bn = b2[:200].copy(); rn = res[:, :200].copy()
+    y = nat.gemm_mid(dev(x), dev(Wn), dev(bn), "none", dev(rn))
+    np.testing.assert_allclose(y.cpu().numpy(), (T(x) @ T(Wn).T + T(bn) + T(rn)).float().numpy(), rtol=1e-5, atol=2e-6)
+    # split-K slabs: the ordered sum of the 4 slices is the product
+    un = u_ref.float().numpy()
+    slab = nat.gemm_mid(dev(un), dev(W2), ksplit=4)
+    assert slab.shape == (4, M, D)
+    prod = T(un) @ T(W2).T
+    np.testing.assert_allclose(slab.double().sum(0).cpu().numpy(), prod.numpy(), rtol=1e-5, atol=2e-6)
+    for yk in range(4):     # each slab is exactly its K slice
+        sl = slice(yk * D, (yk + 1) * D)
+        np.testing.assert_allclose(slab[yk].cpu().numpy(), (T(un[:, sl]) @ T(W2[:, sl]).T).float().numpy(), rtol=1e-5, atol=2e-6)
+    # adaLN over residual + bias + slabs
+    mod = (0.3 * rng.standard_normal((M, 3 * 2 * D))).astype(np.float32)         # a row of several modulations: take the middle one
+    mview = dev(mod)[:, 2 * D:4 * D]
+    xo, yo = nat.adaln_sum(dev(res), slab, dev(b2), mview)
+    x_ref = T(res) + T(b2) + prod
+    sc, sh = T(mod[:, 2 * D:3 * D]), T(mod[:, 3 * D:4 * D])
+    y_ref = torch.nn.functional.layer_norm(x_ref, (D,), None, None, 1e-5) * (1 + sc) + sh
+    np.testing.assert_allclose(xo.cpu().numpy(), x_ref.float().numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(yo.cpu().numpy(), y_ref.float().numpy(), rtol=2e-5, atol=2e-5)
+    # no slabs, no bias, no x output: plain adaLN
+    _, y0 = nat.adaln_sum(dev(res), None, None, mview, want_x=False)
+    y0_ref = torch.nn.functional.layer_norm(T(res), (D,), None, None, 1e-5) * (1 + sc) + sh
+    np.testing.assert_allclose(y0.cpu().numpy(), y0_ref.float().numpy(), rtol=2e-5, atol=2e-5)

@@ -666,7 +666,8 @@ def adaln_sum(res, slab, bias, mod, want_x=True):
     M, D = res.shape
     x = torch.empty_like(res) if want_x else None
     y = torch.empty_like(res)
-    check(lib().aid_adaln_sum(_ptr(res), D, _ptr(slab), 0 if slab is None else slab.shape[0], _ptr(bias), _ptr(mod), mod.stride(0), _ptr(x), D, _ptr(y), D,
+    assert mod.is_cuda and mod.dtype == torch.float32 and mod.stride(1) == 1          # a [M, 2D] column window of the wide modulation buffer
+    check(lib().aid_adaln_sum(_ptr(res), D, _ptr(slab), 0 if slab is None else slab.shape[0], _ptr(bias), C.c_void_p(mod.data_ptr()), mod.stride(0), _ptr(x), D, _ptr(y), D,
                               M, D, _stream()), "aid_adaln_sum")
     return x, y
 

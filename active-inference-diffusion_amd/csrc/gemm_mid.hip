@@ -15,9 +15,9 @@
 //     stage is 3 072 cycles of each SIMD's pipe; 24 accumulator registers leave room for two stages of prefetch).
 //   * K in stages of 64: [rows][64] LDS images with the 16-B chunk index XOR-ed by (row & 15) - b128 staging writes and b128 fragment
 //     reads are bank-conflict free (checked exhaustively: tools/perf/README.md) - double buffered (80 KB at BM = 96).
-//   * register staging with the hand-over hidden in the MFMA stream (the structure measured on gemm_rowln): the next stage's 6 + 4 global
-//     loads are issued one by one between the MFMAs of the first half of a stage, its LDS writes between those of the second half, the
-//     fragments of k-group g + 1 are read while group g is contracted; one barrier per stage.
+//   * register staging with the hand-over hidden in the MFMA stream (the structure measured on gemm_rowln), prefetch distance 2: the 6 + 4
+//     global loads of tile kt + 2 are issued one by one between the MFMAs of the first half of stage kt, the LDS writes of tile kt + 1
+//     between those of the second half, the fragments of k-group g + 1 are read while group g is contracted; one barrier per stage.
 //   * a lane's float4 fragment holds k = 16 g + 4 (lane >> 4) + {0..3} of its row; MFMA j of the group contracts element j of every
 //     lane, i.e. k in {16 g + j, + 4, + 8, + 12}: the same permutation for both operands, so the reduction order is fixed and k-contiguous
 //     operands need no transpose.
@@ -85,13 +85,18 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
         if (p < PA) { src[p] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * c; dst[p] = mid_off(row, c); }
         else        { src[p] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + kbeg + 4 * c; dst[p] = 2 * A_FL + mid_off(row, c); }
     }
-    f32x4 rg[NS];
-    auto load_piece = [&](int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + kt * BK); };
-    auto store_piece = [&](int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
+    // Prefetch distance 2: while tile kt is contracted, tile kt + 2 is loaded into the register set tile kt + 1 does not use and tile kt + 1
+    // (loaded a whole stage ago) is written to the other LDS buffer: a global load has 1.5 stages (~2 us) to arrive - the weights of a block
+    // are cold every denoise step (56 MB stream through 32 MB of L2) and one wave per SIMD has nobody to hide a late load behind.  With one
+    // workgroup per CU registers are free (122 + 40 of 512).  The loop is unrolled by two so both sets are named statically.
+    f32x4 rg0[NS], rg1[NS];
+    auto load_piece = [&](f32x4 (&rg)[NS], int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + kt * BK); };
+    auto store_piece = [&](const f32x4 (&rg)[NS], int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
     constexpr int NG = BK / 16, MPG = 4 * BMT * 2, NM = NG * MPG, S0 = NM / 2;
     constexpr int LSTEP = S0 / NS > 0 ? S0 / NS : 1, SSTEP = (NM - S0) / NS > 0 ? (NM - S0) / NS : 1;
     static_assert(S0 / NS >= 1, "more staging pieces than MFMA slots in half a stage");
-    auto stage = [&](int cur, int kt_next) {
+    // contract LDS buffer `cur`; first half: load tile `kt_load` into `ld`; second half: write `st` (the tile after this one) to buffer cur ^ 1
+    auto stage = [&](int cur, int kt_load, f32x4 (&ld)[NS], const f32x4 (&st)[NS]) {
         const float* a_s = As + cur * A_FL + (wm + r16) * BK;
         const float* b_s = Bs + cur * B_FL + (wn + r16) * BK;
         // (row & 15) == r16 for every fragment row of this lane: the swizzle term is lane-constant
@@ -117,19 +122,26 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
 #pragma unroll
                             for (int j2 = 0; j2 < 2; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + 16 * j2 * BK + (((4 * (gk + 1) + kq) ^ r16) << 2));
                         }
-                        if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) { load_piece(idx / LSTEP, kt_next); __builtin_amdgcn_sched_barrier(0); }
-                        if (idx >= S0 && (idx - S0) % SSTEP == 0 && (idx - S0) / SSTEP < NS) { store_piece((idx - S0) / SSTEP, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+                        if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) { load_piece(ld, idx / LSTEP, kt_load); __builtin_amdgcn_sched_barrier(0); }
+                        if (idx >= S0 && (idx - S0) % SSTEP == 0 && (idx - S0) / SSTEP < NS) { store_piece(st, (idx - S0) / SSTEP, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
                     }
         }
     };
+    // prologue: tile 0 -> LDS buffer 0, tile 1 -> register set 1 (written to buffer 1 during stage 0)
+    const int last = nk - 1;
 #pragma unroll
-    for (int p = 0; p < NS; ++p) load_piece(p, 0);
+    for (int p = 0; p < NS; ++p) load_piece(rg0, p, 0);
 #pragma unroll
-    for (int p = 0; p < NS; ++p) store_piece(p, 0);
+    for (int p = 0; p < NS; ++p) load_piece(rg1, p, min(1, last));
+#pragma unroll
+    for (int p = 0; p < NS; ++p) store_piece(rg0, p, 0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        // the last stage re-loads itself into the idle buffer (never read): the loop stays branch-free
-        stage(kt & 1, kt + 1 < nk ? kt + 1 : kt);
+    // nk is even (checked on the host).  Tiles beyond the end are clamped to the last one: they are loaded / written to an idle buffer and
+    // never contracted, which keeps the loop branch-free.
+    for (int kt = 0; kt < nk; kt += 2) {
+        stage(0, min(kt + 2, last), rg0, rg1);       // contract tile kt (buffer 0); load kt + 2 -> set 0; write tile kt + 1 (set 1) -> buffer 1
+        __syncthreads();
+        stage(1, min(kt + 3, last), rg1, rg0);       // contract tile kt + 1 (buffer 1); load kt + 3 -> set 1; write tile kt + 2 (set 0) -> buffer 0
         __syncthreads();
     }
     // ---- epilogue.  C/D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + {0..3}
@@ -180,7 +192,8 @@ static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
 
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
     const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
-    return al && M > 128 && M <= 1024 && N >= 64 && ksplit >= 1 && K % (MID_BK * ksplit) == 0 && K / ksplit >= MID_BK &&
+    return al && M > 128 && M <= 1024 && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
+          
            (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU || act == ACT_RELU);
 }
 

@@ -410,10 +410,10 @@ def test_gemm_mid_and_adaln_sum(nat, M):
     slab = nat.gemm_mid(dev(un), dev(W2), ksplit=4)
     assert slab.shape == (4, M, D)
     prod = T(un) @ T(W2).T
-    np.testing.assert_allclose(slab.double().sum(0).cpu().numpy(), prod.numpy(), rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(slab.double().sum(0).cpu().numpy(), prod.numpy(), rtol=1e-5, atol=5e-6)      # K = 2048 fp32 products
     for yk in range(4):     # each slab is exactly its K slice
         sl = slice(yk * D, (yk + 1) * D)
-        np.testing.assert_allclose(slab[yk].cpu().numpy(), (T(un[:, sl]) @ T(W2[:, sl]).T).float().numpy(), rtol=1e-5, atol=2e-6)
+        np.testing.assert_allclose(slab[yk].cpu().numpy(), (T(un[:, sl]) @ T(W2[:, sl]).T).float().numpy(), rtol=1e-5, atol=5e-6)
     # adaLN over residual + bias + slabs
     mod = (0.3 * rng.standard_normal((M, 3 * 2 * D))).astype(np.float32)         # a row of several modulations: take the middle one
     mview = dev(mod)[:, 2 * D:4 * D]
@@ -421,7 +421,7 @@ def test_gemm_mid_and_adaln_sum(nat, M):
     x_ref = T(res) + T(b2) + prod
     sc, sh = T(mod[:, 2 * D:3 * D]), T(mod[:, 3 * D:4 * D])
     y_ref = torch.nn.functional.layer_norm(x_ref, (D,), None, None, 1e-5) * (1 + sc) + sh
-    np.testing.assert_allclose(xo.cpu().numpy(), x_ref.float().numpy(), rtol=1e-5, atol=3e-6)
+    np.testing.assert_allclose(xo.cpu().numpy(), x_ref.float().numpy(), rtol=1e-5, atol=6e-6)
     np.testing.assert_allclose(yo.cpu().numpy(), y_ref.float().numpy(), rtol=2e-5, atol=2e-5)
     # no slabs, no bias, no x output: plain adaLN
     _, y0 = nat.adaln_sum(dev(res), None, None, mview, want_x=False)

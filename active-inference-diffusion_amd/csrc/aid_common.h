@@ -85,6 +85,10 @@ inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
     return g;
 }
 int gemm_f32(const GemmArgs& g, hipStream_t s);
+// tall plain Linear through 64-row x 512-column full-K workgroups (gemm_rowln.hip); gemm_f32 routes to it
+bool linear_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, int ldw);
+int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b, int act, const float* mask, int ldmask, const float* add, int ldadd,
+                float* y, int ldy, int M, int N, int K, hipStream_t s);
 void gemm_force_kernel(int k);   // tests / benches only: process-wide kernel override, 0 = automatic selection
 int stream_hint_set(hipStream_t s, int flags);   // per-stream dispatch hints (bit 0: prefer low-LDS small-problem kernels)
 // y = x W^T + b with optional activation: the torch.nn.Linear forward.

@@ -48,6 +48,7 @@ template <int BKT> struct RowSw {
 
 template <int ACT> __device__ __forceinline__ float rowln_act(float x) {
     if constexpr (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
+    else if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
     else if constexpr (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + expf(-x));
     else return x;
 }
@@ -66,7 +67,7 @@ __device__ __forceinline__ float fold32(float (&x)[32], int li) {
     return x[0];
 }
 
-template <int BN, int BKT, int ACT, bool KTAIL, int DBG = 0>
+template <int BN, int BKT, int ACT, bool KTAIL, int DBG = 0, bool LN = true>
 __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     constexpr int NT = 512, BM = 64, TN = BN / 256, CPR = BKT / 4;
     constexpr int A_FL = BM * BKT, B_FL = BN * BKT;
@@ -80,6 +81,13 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     const int li = lane & 31, h = lane >> 5;
     const int wn = wave * (BN / 8);
     const int m0 = blockIdx.x * BM;
+    if constexpr (!LN) {    // plain Linear (+ act, mask, add): the output may be several BN-wide column blocks (blockIdx.y); rows still whole per block
+        const int n0 = blockIdx.y * BN;
+        g.W += (size_t)n0 * g.ldw; g.Y += n0;
+        if (g.bias) g.bias += n0;
+        if (g.add) g.add += n0;
+        if (g.mask) g.mask += n0;
+    }
     f32x16 acc[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -195,6 +203,7 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    if constexpr (LN) {
     // accumulator register r of row-tile i is row 32 i + (r & 3) + 8 (r >> 2) + 4 h; fold index 16 i + r
     const int my_row = 32 * (li >> 4) + ((li & 15) & 3) + 8 * ((li & 15) >> 2) + 4 * h;     // the row lane li ends up owning after fold32
     float x[32];
@@ -241,9 +250,10 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
         for (int w = 0; w < 8; ++w) s += part[w * BM + tid];
         rowv[tid] = 1.0f / sqrtf(s / (float)BN + g.eps); }
     __syncthreads();
+    }   // LN
     float gcol[TN], becol[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { gcol[j] = g.gamma ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = g.beta ? g.beta[wn + 32 * j + li] : 0.f; }
+    for (int j = 0; j < TN; ++j) { gcol[j] = (LN && g.gamma) ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = (LN && g.beta) ? g.beta[wn + 32 * j + li] : 0.f; }
     // 8 groups of 4 rows x TN columns per lane; the skip values of group gq + 1 are loaded before group gq is finished and stored, so
     // their latency hides behind the previous group's math and stores (one workgroup per CU: nothing else would cover it)
     float sk[2][4][TN], mk[2][4][TN];
@@ -265,14 +275,15 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     for (int gq = 0; gq < 8; ++gq) {
         const int i = gq >> 2, rq = gq & 3, pb = gq & 1;
         if (aux && gq + 1 < 8) load_aux(gq + 1, pb ^ 1);
-        const f32x4 r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+        f32x4 r4 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (LN) r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = wn + 32 * j + li;
-                float o = rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]);
+                float o = LN ? rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]) : rowln_act<ACT>(acc[i][j][4 * rq + e]);
                 if (g.mask) o *= mk[pb][e][j];
                 if (g.add) o += sk[pb][e][j];
                 if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
@@ -315,6 +326,42 @@ static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
         }
     }
     return g.K % BKT == 0 ? launch_rowln_t<BN, BKT, ACT, false>(g, s) : launch_rowln_t<BN, BKT, ACT, true>(g, s);
+}
+
+template <int ACT>
+static int launch_rows_plain(const RowLnArgs& g, int N, hipStream_t s) {
+    constexpr int BN = 512, BKT = 32;
+    constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT, true, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const dim3 grid((g.M + 63) / 64, N / BN);
+    if (g.K % BKT == 0) hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, false, 0, false>), grid, dim3(512), lds, s, g);
+    else hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, true, 0, false>), grid, dim3(512), lds, s, g);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+// y[M,N] = act(x W^T + b) * mask + add through the same 64-row x 512-column full-K workgroups (no LayerNorm): the tall plain Linear layers
+// (the MINE statistics network, the hoisted adaLN-modulation GEMM of the reverse loop).  N % 512 == 0.
+bool linear_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, int ldw) {
+    const bool al = ((((uintptr_t)x | (uintptr_t)W) & 15) == 0) && ldx % 4 == 0 && ldw % 4 == 0 && K % 4 == 0;
+    return al && M >= 4096 && N >= 512 && N % 512 == 0 && K >= 64 && (act == ACT_NONE || act == ACT_RELU || act == ACT_SILU || act == ACT_GELU);
+}
+int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b, int act, const float* mask, int ldmask, const float* add, int ldadd,
+                float* y, int ldy, int M, int N, int K, hipStream_t s) {
+    AID_REQUIRE(linear_rows_ok(M, N, K, act, x, ldx, W, ldw), AID_E_SHAPE, "linear_rows: unsupported M=%d N=%d K=%d act=%d", M, N, K, act);
+    RowLnArgs g; memset(&g, 0, sizeof(g));
+    g.A = x; g.lda = ldx; g.W = W; g.ldw = ldw; g.bias = b; g.add = add; g.ldadd = ldadd; g.mask = mask; g.ldmask = ldmask; g.Y = y; g.ldy = ldy;
+    g.M = M; g.K = K; g.eps = 1e-5f;
+    switch (act) {
+        case ACT_RELU: return launch_rows_plain<ACT_RELU>(g, N, s);
+        case ACT_SILU: return launch_rows_plain<ACT_SILU>(g, N, s);
+        case ACT_GELU: return launch_rows_plain<ACT_GELU>(g, N, s);
+        default: return launch_rows_plain<ACT_NONE>(g, N, s);
+    }
 }
 
 bool linear_ln_act_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, const float* add, int ldadd, const float* y, int ldy) {

@@ -120,7 +120,11 @@ def kernel_name(variant, layout):
             4: f"gemm_tile_kernel<64, 64, {a}, {k}, true>", 5: f"gemm_tile_kernel<64, 64, {a}, {k}, false>",
             6: f"gemm_splitk_kernel<{a}, {k}, true>", 7: f"gemm_splitk_kernel<{a}, {k}, false>", 8: "gemm_thin_tn_kernel", 10: "gemm_skinny_kernel", 9: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 2>",
             11: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 1>", 14: f"gemm_panel128_kernel<{a}, {k}, 128>",
-            15: f"gemm_panel128_kernel<{a}, {k}, 64>"}.get(variant, f"variant{variant}<{a}, {k}>")
+            15: f"gemm_panel128_kernel<{a}, {k}, 64>",
+            # Linear -> LayerNorm -> act in one full-row-tile kernel (csrc/gemm_rowln.hip); the reverse loop's one-workgroup-per-CU kernel
+            # (csrc/gemm_mid.hip, every BM / activation instantiation folded into one row)
+            20: "gemm_rowln_kernel<1024, 16, ...>", 21: "gemm_rowln_kernel<512, 32, ...>", 22: "gemm_mid_kernel<...>",
+            23: "gemm_rowln_kernel<512, 32, ...> (plain epilogue)"}.get(variant, f"variant{variant}<{a}, {k}>")
 
 
 def per_kernel_table(path):
@@ -134,6 +138,82 @@ def per_kernel_table(path):
         M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
         e["launches"] += 1; e["ms"] += float(r["ms"]); e["flops"] += 2.0 * M * N * K; e["bytes"] += 4.0 * (M * K + N * K + M * N)
     return agg
+
+
+def small_batch_loops(agent):
+    """act() / collector batches: one 50-step reverse loop at B = 1 and B = 32, eval mode as the collector runs it.  These are
+    weight-streaming problems: every denoise step reads the live score-network weights once, so the figure of merit is bytes per step / time
+    against the 8 TB/s HBM roof (the 96 MB fit the 256 MB Infinity Cache, so the true ceiling is higher)."""
+    ai = agent.active_inference
+    live_bytes = 4.0 * sum(p.numel() for n_, p in ai.latent_score_network.named_parameters() if "in_proj" not in n_)     # Q/K/V rows: V only is read, folded into Wov
+    live_bytes += 4.0 * 6 * 512 * 512                                                                                      # the six collapsed Wo Wv matrices
+    was_training = ai.training
+    ai.eval()
+    out = {}
+    try:
+        for name, b in (("act_b1", 1), ("collector_b32", 32)):
+            obs = torch.randn(b, O, device=agent.device)
+            for _ in range(3):
+                ai.denoise_only(obs)
+            torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 10
+            for _ in range(reps):
+                ai.denoise_only(obs)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
+            out[name] = {"rows": b, "loop_us": 1e6 * dt, "us_per_denoise_step": 1e6 * dt / NSTEPS, "denoise_steps_per_s": NSTEPS / dt,
+                         "weight_bytes_per_step": live_bytes, "achieved_GBps": live_bytes * NSTEPS / dt / 1e9, "peak_GBps": 8000.0,
+                         "frac": live_bytes * NSTEPS / dt / 8e12, "bound": "hbm", "note": "hipGraph replay of the whole loop; launch-chain bound (36 dependent kernels per step)"}
+    finally:
+        ai.train(was_training)
+    return out
+
+
+def other_configs(device):
+    """BASELINE configs[2] and configs[3] at full size (timed outside the headline's timed region): ms per train_step and the algorithmic
+    FLOP rate against the fp32-MFMA peak.  Algorithmic FLOPs: cfg 3 = SURVEY 8(d)'s 18.1 TFLOP (Hopper dims, B = 1024, shared-t hoisting);
+    cfg 4 = what the pixel step executes - two DrQ-v2 encoder passes forward + backward (2 x 4.81 GFLOP per row), one 512-row and no third
+    reverse loop (2 x 50 x 256 x 46.4 MFLOP at L = 128 is within 1 % of the L = 17 figure), ELBO 0.12 TFLOP, rollout 0.2 TFLOP; the
+    gradient-free ConvDecoder estimator is opt-in and off."""
+    import aid_amd
+    res = {}
+
+    def timed(agent, warm=2, steps=3):
+        for _ in range(warm):
+            agent.train_step()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(steps):
+            m = agent.train_step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, m
+    o3, a3, b3 = 11, 3, 1024
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b3, efe_horizon=HORIZON, latent_dim=o3, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
+
+    class Env3:
+        observation_space, action_space = _Box((o3,)), _Box((a3,))
+    agent = aid_amd.DiffusionStateAgent(Env3(), cfg, aid_amd.TrainingConfig(buffer_size=8192))
+    rng = np.random.default_rng(0); n = 4096
+    agent.replay_buffer.add_batch(rng.standard_normal((n, o3)), rng.uniform(-1, 1, (n, a3)), rng.standard_normal(n), rng.standard_normal((n, o3)), rng.random(n) < 0.01)
+    dt, m = timed(agent)
+    fl3 = 18.1e12
+    res["cfg3_hopper_b1024"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_tflops": fl3 / dt / 1e12, "frac_of_f32_mfma_peak": fl3 / dt / PEAK_F32_MFMA,
+                                "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    del agent; torch.cuda.empty_cache()
+    l4, a4, b4 = 128, 6, 256
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b4, efe_horizon=HORIZON, latent_dim=l4, hidden_dim=D, pixel_observation=True)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
+
+    class Env4:
+        observation_space, action_space = _Box((3, 3, 84, 84)), _Box((a4,))
+    agent = aid_amd.DiffusionPixelAgent(Env4(), cfg, aid_amd.TrainingConfig(buffer_size=512), aid_amd.PixelObservationConfig())
+    n = 512
+    frames = rng.integers(0, 256, (n, 3, 3, 84, 84), dtype=np.uint8)
+    agent.replay_buffer.add_batch(frames, rng.uniform(-1, 1, (n, a4)).astype(np.float32), rng.standard_normal(n).astype(np.float32), np.roll(frames, -1, axis=0), rng.random(n) < 0.01)
+    dt, m = timed(agent)
+    fl4 = 2 * 4.81e9 * b4 + 2 * NSTEPS * b4 * ALGO_FLOP_PER_DENOISE_ROW_STEP + 0.12e12 + 0.2e12
+    res["cfg4_pixel_b256"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_tflops": fl4 / dt / 1e12, "frac_of_f32_mfma_peak": fl4 / dt / PEAK_F32_MFMA,
+                              "algorithmic_flop_per_step": fl4, "replay": "uint8 frames", "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    del agent; torch.cuda.empty_cache()
+    return res
 
 
 def self_launch(n: int) -> int:
@@ -216,6 +296,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="keep every phase on one stream (rocprofv3 --pmc passes: counter collection "
                     "serialises dispatches anyway and crashes on this pool when two streams dispatch concurrently)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch GEMM timings of the profiled step to this CSV")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (small-batch loops, cfg 3 / cfg 4 train_steps)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -290,6 +371,9 @@ def main():
         os.remove(dump)
     nat.prof_enable(False); nat.prof_reset()
     agent.overlap_streams = not args.no_overlap
+    extras = {}
+    if rank == 0 and world == 1 and not args.no_extras:      # outside the timed region, one GPU only
+        extras["small_batch"] = small_batch_loops(agent)
     if rank != 0:
         return
     steps_per_s = args.steps / elapsed
@@ -297,7 +381,7 @@ def main():
     tf = lambda d: (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0
     pmc = {}
     try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md: how they were taken and corrected)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
     except Exception:
         pass
     def traffic(prefix):
@@ -308,7 +392,8 @@ def main():
     # One entry per kernel instantiation (= one row of the rocprofv3 --stats summary), ordered by its share of the profiled step.
     def entry(name, d):
         e = {"bound": "mfma", "kernel": "aid::" + name, "achieved": tf(d), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
-             "frac": tf(d) * 1e12 / PEAK_F32_MFMA, "traffic": traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name),
+             "frac": tf(d) * 1e12 / PEAK_F32_MFMA,
+             "traffic": traffic(name.split(", ...")[0].split("...")[0] if "..." in name else (name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name)),
              "launches_per_step": d["launches"], "ms_per_step": d["ms"], "flop_per_launch": d["flops"] / max(d["launches"], 1),
              "algorithmic_bytes_per_launch": d["bytes"] / max(d["launches"], 1),
              "us_per_launch": 1e3 * d["ms"] / max(d["launches"], 1)}
@@ -345,6 +430,15 @@ def main():
                          "achieved": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": (o["bytes"] / (o["ms"] * 1e-3) / 8e12) if o["ms"] > 0 else None},
     }
+    for e in [out["roofline"], out["roofline_second_kernel"], *out["roofline_kernels"], out["roofline_big_family"], out["roofline_small_family"],
+              out["roofline_gemm_family"], out["roofline_hbm"]]:
+        if e is not None:
+            e["profiled"] = "single-stream"      # the event-bracketed step outside the timed region (the timed steps run two streams)
+    if extras:
+        out.update(extras)
+    if world == 1 and not args.no_extras:
+        del agent; torch.cuda.empty_cache()
+        out["other_configs"] = other_configs(device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

@@ -427,3 +427,26 @@ def test_gemm_mid_and_adaln_sum(nat, M):
     _, y0 = nat.adaln_sum(dev(res), None, None, mview, want_x=False)
     y0_ref = torch.nn.functional.layer_norm(T(res), (D,), None, None, 1e-5) * (1 + sc) + sh
     np.testing.assert_allclose(y0.cpu().numpy(), y0_ref.float().numpy(), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,N,K,act", [(4096, 512, 384, "relu"), (4100, 1024, 72, "none"), (5000, 1536, 512, "gelu"), (25600, 512, 512, "silu")])
+def test_tall_linear_full_row_blocks(nat, M, N, K, act):
+    """aid_gemm_f32 routes tall Linear forwards whose width is a multiple of 512 to the 64-row x 512-column full-K workgroups of
+    csrc/gemm_rowln.hip (plain epilogue: bias, activation, dropout mask, residual): ragged rows, a K tail, several column blocks."""
+    rng = np.random.default_rng(M + N)
+    x = rng.standard_normal((M, K)).astype(np.float32); W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).double()
+    pre = T(x) @ T(W).T + T(b)
+    ref = {"relu": torch.relu, "silu": torch.nn.functional.silu, "gelu": torch.nn.functional.gelu, "none": lambda v: v}[act](pre) + T(R)
+    out = torch.zeros(M, N, device="cuda")
+    import csv, tempfile
+    nat.prof_enable(True); nat.prof_reset()
+    try:
+        nat.gemm(dev(x), dev(W), out, M, N, K, K, K, N, bias=dev(b), act=act, residual=dev(R), ldr=N)
+        torch.cuda.synchronize()
+        path = tempfile.mktemp(suffix=".csv"); nat.prof_dump(path)
+    finally:
+        nat.prof_enable(False); nat.prof_reset()
+    assert [int(r["variant"]) for r in csv.DictReader(open(path))] == [23]          # the full-row kernel ran, not the 64x64 tile
+    np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5)

@@ -1,9 +1,9 @@
-"""Aggregate a bench.py --dump-launches CSV by (family, layout, M, N, K): count, total ms, TFLOP/s.  Usage: launch_table.py CSV"""
+"""Aggregate a bench.py --dump-launches CSV by (kernel variant, layout, M, N, K): count, total ms, TFLOP/s.  Usage: launch_table.py CSV"""
 import csv, sys, collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for r in rows:
-    key = (r["kernel_id"], r["layout"], int(r["M"]), int(r["N"]), int(r["K"]))
+    key = (r.get("variant", r["kernel_id"]), r["layout"], int(r["M"]), int(r["N"]), int(r["K"]))
     a = agg[key]; a[0] += 1; a[1] += float(r["ms"]); a[2] += 2.0 * int(r["M"]) * int(r["N"]) * int(r["K"])
 tot = sum(a[1] for a in agg.values())
 print(f"total {tot:.2f} ms over {len(rows)} launches")

@@ -15,13 +15,14 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps * 1e-3
 for M in (256, 512, 768):
     for (N, K, ks, act) in ((512, 512, 4, "none"), (2048, 512, 1, "gelu"), (512, 2048, 4, "none")):
-        A = torch.randn(M, K, device="cuda"); Ws = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(24)]   # 24 x 4 MB: beyond the 32 MB of L2
+        NW = int(os.environ.get("MID_NW", "24"))
+        A = torch.randn(M, K, device="cuda"); Ws = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(NW)]   # 24 x 4 MB: beyond the 32 MB of L2
         b = torch.randn(N, device="cuda"); C = torch.empty(M, N, device="cuda"); i = [0]
         def mid():
-            i[0] = (i[0] + 1) % 24
+            i[0] = (i[0] + 1) % NW
             nat.gemm_mid(A, Ws[i[0]], b if ks == 1 else None, act, None, ks)
         def auto():
-            i[0] = (i[0] + 1) % 24
+            i[0] = (i[0] + 1) % NW
             nat.gemm(A, Ws[i[0]], C, M, N, K, K, K, N, bias=b, act=act)
         tm, ta = timeit(mid, 96), timeit(auto, 96)
         fl = 2.0 * M * N * K

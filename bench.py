@@ -164,6 +164,8 @@ def small_batch_loops(agent):
                          "frac": live_bytes * NSTEPS / dt / 8e12, "bound": "hbm", "note": "hipGraph replay of the whole loop; launch-chain bound (36 dependent kernels per step)"}
     finally:
         ai.train(was_training)
+        ai.__dict__.get("_denoise_graphs", {}).clear()      # the captured loops (and their private memory pools) are not needed any more
+        torch.cuda.synchronize()
     return out
 
 
@@ -176,14 +178,16 @@ def other_configs(device):
     import aid_amd
     res = {}
 
-    def timed(agent, warm=2, steps=3):
+    def timed(agent, warm=3, steps=5):
         for _ in range(warm):
             agent.train_step()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ts = []
         for _ in range(steps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
             m = agent.train_step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / steps, m
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        print("[bench] other config, ms per step:", [round(1e3 * t, 1) for t in ts], file=sys.stderr, flush=True)
+        return float(np.median(ts)), m
     o3, a3, b3 = 11, 3, 1024
     cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b3, efe_horizon=HORIZON, latent_dim=o3, hidden_dim=D)
     cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
@@ -349,9 +353,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
     # ---- outside the timed region: denoise-only rate and the live GEMM roofline (event-bracketed launches)
+    SKIP = set(os.environ.get("AID_BENCH_SKIP", "").split(","))      # diagnostics only
     ai = agent.active_inference
     obs = torch.randn(BATCH, O, device=device)
-    for _ in range(2):
+    for _ in range(0 if "denoise" in SKIP else 2):
         ai.denoise_only(obs)
     torch.cuda.synchronize(); t1 = time.perf_counter(); reps = 5
     for _ in range(reps):
@@ -360,7 +365,7 @@ def main():
     # event-bracketed launches need one stream: the side-stream overlap of train_step is switched off for this one step
     agent.overlap_streams = False
     agent.train_step(); torch.cuda.synchronize()
-    nat.prof_enable(True); nat.prof_reset()
+    nat.prof_enable("prof" not in SKIP); nat.prof_reset()
     agent.train_step(); torch.cuda.synchronize()
     gt = nat.prof_read(nat.PROF_GEMM_TILE); gs = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
     import tempfile
@@ -373,7 +378,9 @@ def main():
     agent.overlap_streams = not args.no_overlap
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # outside the timed region, one GPU only
-        extras["small_batch"] = small_batch_loops(agent)
+        extras["other_configs"] = other_configs(device)
+        if "graphs" not in SKIP:
+            extras["small_batch"] = small_batch_loops(agent)
     if rank != 0:
         return
     steps_per_s = args.steps / elapsed
@@ -436,9 +443,6 @@ def main():
             e["profiled"] = "single-stream"      # the event-bracketed step outside the timed region (the timed steps run two streams)
     if extras:
         out.update(extras)
-    if world == 1 and not args.no_extras:
-        del agent; torch.cuda.empty_cache()
-        out["other_configs"] = other_configs(device)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]

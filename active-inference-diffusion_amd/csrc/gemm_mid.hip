@@ -68,7 +68,9 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
         int T;
         if (b < full) { const int x = b & 7, q = b >> 3; T = x + 8 * (q / tiles_m); tm = q % tiles_m; }
         else { const int r = b - full; T = n8 + r / tiles_m; tm = r % tiles_m; }
-        tn = T % tiles_n; ky = T / tiles_n;
+        // K slice fastest: an XCD group (T % 8) then sees ONE K slice when ksplit divides 8, i.e. 1/ksplit of the activation operand instead
+        // of all of it (768 x 2048 layer: 17 MB instead of 54 MB pulled through the eight L2s per launch, rocprofv3 FETCH_SIZE)
+        ky = T % g.ksplit; tn = T / g.ksplit;
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kper = g.K / g.ksplit, kbeg = ky * kper, nk = kper / BK;
@@ -220,8 +222,8 @@ int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias
 // x_new = res + bias + sum_y slab[y]  (fixed order);  y = LN(x_new) (1 + scale) + shift with [scale | shift] = mod row.  One wave per
 // row, D = 256 NV.  Writes x_new (the residual stream) and y.  Reference: DiTBlock.forward's `x = x + ...` followed by the next adaLN
 // (models/score_networks.py:214-235, 257-270).
-template <int NV>
-__global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const float* __restrict__ slab, int nslab, size_t slab_stride,
+template <int NV, int NSLAB>
+__global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const float* __restrict__ slab, size_t slab_stride,
                                  const float* __restrict__ bias, const float* __restrict__ mod, int ldmod, float* __restrict__ xout, int ldxo,
                                  float* __restrict__ y, int ldy, int M) {
     typedef float f4 __attribute__((ext_vector_type(4)));
@@ -230,17 +232,24 @@ __global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const
     if (row >= M) return;
     const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
     const f4* sh = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod + D);
-    f4 v[NV], a[NV], b[NV];
+    // every load of the row is issued before the first use: one memory round trip instead of NSLAB + 2 (768 waves on 256 CUs: nothing
+    // else hides the latency)
+    f4 v[NV], a[NV], b[NV], bi[NV], sl[NSLAB > 0 ? NSLAB : 1][NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         v[i] = reinterpret_cast<const f4*>(res + (size_t)row * ldres)[lane + 64 * i];
         a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i];
-        if (bias) v[i] += reinterpret_cast<const f4*>(bias)[lane + 64 * i];
+        bi[i] = bias ? reinterpret_cast<const f4*>(bias)[lane + 64 * i] : (f4){0.f, 0.f, 0.f, 0.f};
     }
-    for (int y0 = 0; y0 < nslab; ++y0) {
-        const f4* sp = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * D);
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] += sp[lane + 64 * i];
+    for (int y0 = 0; y0 < NSLAB; ++y0)
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sl[y0][i] = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * D)[lane + 64 * i];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        v[i] += bi[i];
+#pragma unroll
+        for (int y0 = 0; y0 < NSLAB; ++y0) v[i] += sl[y0][i];          // fixed order: slab 0, 1, 2, ...
     }
     if (xout) {
 #pragma unroll
@@ -270,16 +279,28 @@ bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const f
     return (D == 256 || D == 512 || D == 1024) && ((((uintptr_t)res | (uintptr_t)slab | (uintptr_t)bias | (uintptr_t)mod | (uintptr_t)xout | (uintptr_t)y) & 15) == 0) &&
            ldres % 4 == 0 && ldmod % 4 == 0 && ldxo % 4 == 0 && ldy % 4 == 0;
 }
+template <int NV>
+static int launch_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
+                            float* y, int ldy, int M, hipStream_t s) {
+    const dim3 grid((M + 3) / 4);
+    const size_t stride = (size_t)M * 256 * NV;
+    switch (nslab) {
+        case 0: hipLaunchKernelGGL((adaln_sum_kernel<NV, 0>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        case 1: hipLaunchKernelGGL((adaln_sum_kernel<NV, 1>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        case 2: hipLaunchKernelGGL((adaln_sum_kernel<NV, 2>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        case 4: hipLaunchKernelGGL((adaln_sum_kernel<NV, 4>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        default: ::aid::set_error("adaln_sum: %d slabs (0, 1, 2 or 4 are built)", nslab); return AID_E_SHAPE;
+    }
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
 int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
               float* y, int ldy, int M, int D, hipStream_t s) {
     AID_REQUIRE(adaln_sum_ok(D, res, ldres, slab, bias, mod, ldmod, xout, ldxo, y, ldy), AID_E_SHAPE, "adaln_sum: D=%d or alignment unsupported", D);
-    const dim3 grid((M + 3) / 4);
-    const size_t stride = (size_t)M * D;
-    if (D == 256) hipLaunchKernelGGL(adaln_sum_kernel<1>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
-    else if (D == 512) hipLaunchKernelGGL(adaln_sum_kernel<2>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
-    else hipLaunchKernelGGL(adaln_sum_kernel<4>, grid, dim3(256), 0, s, res, ldres, slab, nslab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M);
-    AID_LAUNCH_CHECK();
-    return AID_OK;
+    if (!slab) nslab = 0;
+    if (D == 256) return launch_adaln_sum<1>(res, ldres, slab, nslab, bias, mod, ldmod, xout, ldxo, y, ldy, M, s);
+    if (D == 512) return launch_adaln_sum<2>(res, ldres, slab, nslab, bias, mod, ldmod, xout, ldxo, y, ldy, M, s);
+    return launch_adaln_sum<4>(res, ldres, slab, nslab, bias, mod, ldmod, xout, ldxo, y, ldy, M, s);
 }
 
 }  // namespace aid

@@ -274,6 +274,138 @@ __global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const
     }
 }
 
+// Block 0's adaLN with the latent projection folded in: x = z W_lp^T + b_lp (K = latent_dim <= 128: 17 FMAs per output at HalfCheetah dims, a
+// launch of its own before), then y = LN(x) (1 + scale) + shift.  Wt is W_lp transposed to [L][D] once per reverse loop so that a lane's
+// 4 consecutive columns are one 16-B load; the z row is a wave-uniform (broadcast) load.  Reference: models/score_networks.py:143 (latent_proj)
+// + the first AdaptiveLayerNorm of block 0.
+template <int NV>
+__global__ void adaln_lp_kernel(const float* __restrict__ z, int L, const float* __restrict__ Wt, const float* __restrict__ blp,
+                                const float* __restrict__ mod, int ldmod, float* __restrict__ xout, int ldxo, float* __restrict__ y, int ldy, int M) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 256 * NV;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
+    const f4* sh = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod + D);
+    f4 v[NV], a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = reinterpret_cast<const f4*>(blp)[lane + 64 * i]; a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i]; }
+    const float* zr = z + (size_t)row * L;
+    for (int k = 0; k < L; ++k) {
+        const float zk = zr[k];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const f4 w = reinterpret_cast<const f4*>(Wt + (size_t)k * D)[lane + 64 * i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[i][j] = fmaf(zk, w[j], v[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<f4*>(xout + (size_t)row * ldxo)[lane + 64 * i] = v[i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + b[i][j];
+        reinterpret_cast<f4*>(y + (size_t)row * ldy)[lane + 64 * i] = o;
+    }
+}
+__global__ void transpose_small_kernel(const float* __restrict__ W /*[R][C]*/, float* __restrict__ Wt /*[C][R]*/, int R, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < R * C) { const int r = i / C, c = i % C; Wt[(size_t)c * R + r] = W[i]; }
+}
+int transpose_small(const float* W, float* Wt, int R, int C, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_small_kernel, dim3((R * C + 255) / 256), dim3(256), 0, s, W, Wt, R, C);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+int adaln_lp(const float* z, int L, const float* Wt, const float* blp, const float* mod, int ldmod, float* xout, int ldxo, float* y, int ldy, int M, int D,
+             hipStream_t s) {
+    AID_REQUIRE((D == 256 || D == 512 || D == 1024) && ((((uintptr_t)Wt | (uintptr_t)blp | (uintptr_t)mod | (uintptr_t)xout | (uintptr_t)y) & 15) == 0) &&
+                ldmod % 4 == 0 && ldxo % 4 == 0 && ldy % 4 == 0, AID_E_SHAPE, "adaln_lp: D=%d or alignment unsupported", D);
+    const dim3 grid((M + 3) / 4);
+    if (D == 256) hipLaunchKernelGGL(adaln_lp_kernel<1>, grid, dim3(256), 0, s, z, L, Wt, blp, mod, ldmod, xout, ldxo, y, ldy, M);
+    else if (D == 512) hipLaunchKernelGGL(adaln_lp_kernel<2>, grid, dim3(256), 0, s, z, L, Wt, blp, mod, ldmod, xout, ldxo, y, ldy, M);
+    else hipLaunchKernelGGL(adaln_lp_kernel<4>, grid, dim3(256), 0, s, z, L, Wt, blp, mod, ldmod, xout, ldxo, y, ldy, M);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+// The score head's last layer + the reverse step with the FIRST head layer taken from split-K slabs: p0 = SiLU(b0 + sum_y slab[y]) is formed
+// in registers (fixed order), then out = p0 W2^T, clamp, scale, p_sample - one wave per row, as head2_p_sample's wave kernel (rowwise.hip).
+// Reference: models/score_networks.py:164-171 + core/diffusion.py:208-255.
+template <int KV, int NSLAB>
+__global__ void __launch_bounds__(256) head2_slab_p_sample_kernel(const float* __restrict__ slab, size_t slab_stride, const float* __restrict__ b0,
+                                                                  const float* __restrict__ W2, int Kp, const float* __restrict__ mult, float tv, int cont,
+                                                                  const float* __restrict__ coef, int step, const float* __restrict__ z,
+                                                                  const float* __restrict__ eps, float* __restrict__ zo, float* __restrict__ traj, int M, int L) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;                                  // no barrier below
+    f4 pv[KV], sl[NSLAB][KV];
+#pragma unroll
+    for (int j = 0; j < KV; ++j) pv[j] = reinterpret_cast<const f4*>(b0)[lane + 64 * j];
+#pragma unroll
+    for (int y0 = 0; y0 < NSLAB; ++y0)
+#pragma unroll
+        for (int j = 0; j < KV; ++j) sl[y0][j] = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * Kp)[lane + 64 * j];
+#pragma unroll
+    for (int j = 0; j < KV; ++j) {
+#pragma unroll
+        for (int y0 = 0; y0 < NSLAB; ++y0) pv[j] += sl[y0][j];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pv[j][e] = act_apply(pv[j][e], ACT_SILU);
+    }
+    for (int l0 = 0; l0 < L; l0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f4* w = reinterpret_cast<const f4*>(W2 + (size_t)min(l0 + q, L - 1) * Kp);
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < KV; ++j) {
+                const f4 wv = w[lane + 64 * j];
+                a = fmaf(pv[j][0], wv[0], a); a = fmaf(pv[j][1], wv[1], a); a = fmaf(pv[j][2], wv[2], a); a = fmaf(pv[j][3], wv[3], a);
+            }
+            acc[q] = a;
+        }
+        const float mine = fold8(acc, lane);
+        const int l = l0 + (lane >> 3);
+        if ((lane & 7) == 0 && l < L) {
+            const size_t i = (size_t)row * L + l;
+            float scv = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
+            if (cont) scv *= sqrtf(1.0f / (1e-5f + tv));
+            const float zt = z[i];
+            const float z0 = (zt + coef[0] * scv) * coef[1];
+            float v = coef[2] * z0 + coef[3] * zt;
+            if (step > 0) v += coef[4] * eps[i];
+            zo[i] = v;
+            if (traj) traj[i] = v;
+        }
+    }
+}
+bool head2_slab_ok(int Kp, int nslab, const float* slab, const float* b0, const float* W2) {
+    return (Kp == 256 || Kp == 512) && nslab == 4 && ((((uintptr_t)slab | (uintptr_t)b0 | (uintptr_t)W2) & 15) == 0);
+}
+int head2_slab_p_sample(const float* slab, int nslab, const float* b0, const float* W2, int Kp, const float* mult, float t_value, int continuous,
+                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s) {
+    AID_REQUIRE(head2_slab_ok(Kp, nslab, slab, b0, W2) && L >= 1 && L <= 128, AID_E_SHAPE, "head2_slab_p_sample: Kp=%d nslab=%d L=%d", Kp, nslab, L);
+    const size_t stride = (size_t)M * Kp;
+    if (Kp == 256) hipLaunchKernelGGL((head2_slab_p_sample_kernel<1, 4>), dim3((M + 3) / 4), dim3(256), 0, s, slab, stride, b0, W2, Kp, mult, t_value, continuous,
+                                      coef, step, z, eps, z_out, traj_out, M, L);
+    else hipLaunchKernelGGL((head2_slab_p_sample_kernel<2, 4>), dim3((M + 3) / 4), dim3(256), 0, s, slab, stride, b0, W2, Kp, mult, t_value, continuous,
+                            coef, step, z, eps, z_out, traj_out, M, L);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
 bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
                   const float* y, int ldy) {
     return (D == 256 || D == 512 || D == 1024) && ((((uintptr_t)res | (uintptr_t)slab | (uintptr_t)bias | (uintptr_t)mod | (uintptr_t)xout | (uintptr_t)y) & 15) == 0) &&

@@ -58,6 +58,14 @@ bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const f
 int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
               float* y, int ldy, int M, int D, hipStream_t s);
 
+// block 0's adaLN with the latent projection folded in (Wt = W_lp^T, [L][D]); the head's reverse step with its first layer given as split-K slabs
+int transpose_small(const float* W, float* Wt, int R, int C, hipStream_t s);
+int adaln_lp(const float* z, int L, const float* Wt, const float* blp, const float* mod, int ldmod, float* xout, int ldxo, float* y, int ldy, int M, int D,
+             hipStream_t s);
+bool head2_slab_ok(int Kp, int nslab, const float* slab, const float* b0, const float* W2);
+int head2_slab_p_sample(const float* slab, int nslab, const float* b0, const float* W2, int Kp, const float* mult, float t_value, int continuous,
+                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
+
 int fill_const(float* p, float v, size_t n, hipStream_t s);
 int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s);
 int copy_f32(const float* a, float* out, size_t n, hipStream_t s);

@@ -49,9 +49,11 @@ int score_obs_stage0(const AidScoreNet& n, int B, const float* obs, ScoreActs& a
 int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float* temb, int ld_temb, ScoreActs& a, hipStream_t s);
 // out_proj(V_proj(x)) collapsed into one weight per block (valid while the weights do not change: inference loops)
 // slab: [4][rows][D] scratch for the split-K partial products of the mid-M pipeline (null: not used)
-struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; float* slab = nullptr; };
+// wlp_t: latent_proj weight transposed to [L][D] (folded into block 0's adaLN); p0_slabs: set by the trunk when it left the head's first
+// layer as 4 raw slabs in `slab` ([4][rows][D/2]) for head2_slab_p_sample instead of writing p0
+struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; float* slab = nullptr; float* wlp_t = nullptr; bool p0_slabs = false; };
 int score_fuse_attention(const AidScoreNet& n, Workspace& ws, ScoreFused& f, hipStream_t s);
 // latent_proj, DiT blocks, final adaLN, output_proj -> a.raw [B,L]
-int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused = nullptr, bool skip_last = false);
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, ScoreFused* fused = nullptr, bool skip_last = false);
 
 }  // namespace aid

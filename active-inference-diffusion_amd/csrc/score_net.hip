@@ -145,15 +145,17 @@ static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const 
            gemm_mid_ok(B, D, 4 * D, 4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
-static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, const ScoreFused& f, bool skip_last) {
+static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = 4;
-    AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
+    const bool lp_fused = f.wlp_t != nullptr && n.n_blocks >= 1;
+    if (!lp_fused) AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     const float* pend_res = nullptr; const float* pend_bias = nullptr;      // a residual stream still waiting for its slabs
     for (int i = 0; i < n.n_blocks; ++i) {
         const AidDiTBlock& w = n.blk[i];
         ScoreBlockActs& b = a.blk[i];
         const float* mod1 = a.mod + (size_t)(2 * i) * 2 * D; const float* mod2 = a.mod + (size_t)(2 * i + 1) * 2 * D;
         if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        else if (lp_fused) AID_TRY(adaln_lp(z, L, f.wlp_t, n.lp_b, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));      // h_in = a.h0 = z W_lp^T + b_lp
         else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
         AID_TRY(gemm_mid(b.nx1, D, f.wov[i], D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D, D, KS, s));
         AID_TRY(adaln_sum(b.h_in, D, f.slab, KS, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
@@ -162,13 +164,21 @@ static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreAct
         pend_res = b.h_mid; pend_bias = w.mlp2_b;                                                               // h_out = h_mid + u W2^T + b2
     }
     AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
+    f.p0_slabs = false;
+    if (skip_last && gemm_mid_ok(B, D / 2, D, KS, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KS, f.slab, n.op0_b, n.op2_w)) {
+        // the head's first layer (N = D/2: 32 column tiles only) split four ways over K; bias, SiLU and the slab sum move into the reverse-step kernel
+        AID_TRY(gemm_mid(a.nxf, D, n.op0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D / 2, D, KS, s));
+        f.p0_slabs = true;
+        return AID_OK;
+    }
     AID_TRY(linear_fwd(a.nxf, D, n.op0_w, n.op0_b, a.p0, D / 2, B, D / 2, D, ACT_SILU, s, a.p0_pre));
     if (!skip_last) AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
     return AID_OK;
 }
 
-int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, const ScoreFused* fused, bool skip_last) {
+int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, ScoreFused* fused, bool skip_last) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
+    if (fused) fused->p0_slabs = false;
     if (!keep && trunk_mid_ok(n, B, a, fused)) return score_trunk_mid(n, B, z, a, s, *fused, skip_last);
     AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     for (int i = 0; i < n.n_blocks; ++i) {
@@ -261,7 +271,7 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D) + (size_t)n_steps * B * L);
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
-    n += sizeof(float) * 4 * (size_t)B * D + 256;                    // split-K slabs of the mid-M pipeline
+    n += sizeof(float) * (4 * (size_t)B * D + (size_t)L * D) + 512;   // split-K slabs of the mid-M pipeline, transposed latent_proj weight
     return n + (1 << 16);
 }
 
@@ -329,7 +339,10 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* mod_all = ws.f32((size_t)C * B * ldmod);
     ScoreFused fused;
     AID_TRY(score_fuse_attention(n, ws, fused, s));
-    if (B > 128 && B <= 1024) { fused.slab = ws.f32((size_t)4 * B * D); AID_WS_OK(ws); }      // mid-M pipeline (score_trunk_mid)
+    if (B > 128 && B <= 1024) {      // mid-M pipeline (score_trunk_mid)
+        fused.slab = ws.f32((size_t)4 * B * D); fused.wlp_t = ws.f32((size_t)L * D); AID_WS_OK(ws);
+        AID_TRY(transpose_small(n.lp_w, fused.wlp_t, D, L, s));
+    }
     ScoreActs a;
     AID_TRY(score_acts_alloc(n, B > N ? B : N, false, ws, a));
     float* mod_own = a.mod;
@@ -388,8 +401,12 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
             const float* eps = (t > 0) ? eps_all + (size_t)t * B * L : nullptr;
             float* dst = (t == 0) ? z_out : zn;
             const float tval = collector ? (float)t / (float)collector_max_index : (float)t;
-            AID_TRY(head2_p_sample(a.p0, D / 2, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
-                                   traj ? traj + (size_t)(N - t) * B * L : nullptr, nullptr, B, L, s));
+            if (fused.p0_slabs)
+                AID_TRY(head2_slab_p_sample(fused.slab, 4, n.op0_b, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps,
+                                            dst, traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
+            else
+                AID_TRY(head2_p_sample(a.p0, D / 2, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
+                                       traj ? traj + (size_t)(N - t) * B * L : nullptr, nullptr, B, L, s));
             if (collector) {   // whole-batch NaN/Inf re-initialisation, decided on device (a host sync in the reference)
                 const float* rn = reinit_noise ? reinit_noise + (size_t)t * B * L : nullptr;
                 if (!rn) { AID_TRY(philox_fill(re_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; rn = re_buf; }

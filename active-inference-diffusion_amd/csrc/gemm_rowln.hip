@@ -67,7 +67,10 @@ __device__ __forceinline__ float fold32(float (&x)[32], int li) {
     return x[0];
 }
 
-template <int BN, int BKT, int ACT, bool KTAIL, int DBG = 0, bool LN = true>
+typedef __attribute__((address_space(3))) void* rl_lds_vptr;
+typedef const __attribute__((address_space(1))) void* rl_gbl_vptr;
+
+template <int BN, int BKT, int ACT, bool KTAIL, int DBG = 0, bool LN = true, bool DMA = false>
 __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     constexpr int NT = 512, BM = 64, TN = BN / 256, CPR = BKT / 4;
     constexpr int A_FL = BM * BKT, B_FL = BN * BKT;
@@ -109,6 +112,32 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
         if constexpr (DBG == 1) b_src[i] = g.W + (size_t)f * 4;        // timing experiment: fully coalesced (wrong) weight addresses
     }
     const int nk = (g.K + BKT - 1) / BKT;
+    // DMA variant (K % BKT == 0): every staging piece is ONE global_load_lds_dwordx4 - 64 lanes x 16 B land in 1 KB of consecutive LDS, i.e. in
+    // 64 / CPR whole rows of the unpadded image; a lane fetches the logical chunk that belongs at ITS LDS position (chunk ^ swizzle(row): the
+    // same involution the fragment reads apply), so no VGPR staging, no ds_write and no vmcnt wait sits in the MFMA stream: a wave waits for
+    // its own DMAs once, in front of the barrier that ends the stage.
+    static_assert(!DMA || !KTAIL, "the DMA variant cannot zero a K tail");
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    constexpr int RPI = 64 / CPR;                                   // rows per DMA instruction
+    const float* dma_src_b[PB]; const float* dma_src_a = nullptr;
+    if constexpr (DMA) {
+        const int lr = lane / CPR, lc = lane % CPR;
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int row = (64 * wave + NT * p) / CPR + lr;
+            dma_src_b[p] = g.W + (size_t)row * g.ldw + 4 * (lc ^ ((row / SW::RPB) % CPR));
+        }
+        const int rowa = (64 * wave) / CPR + lr;                    // waves below F4A / 64 own the activation pieces
+        dma_src_a = g.A + (size_t)min(m0 + (rowa < BM ? rowa : 0), g.M - 1) * g.lda + 4 * (lc ^ ((rowa / SW::RPB) % CPR));
+    }
+    auto dma_piece = [&](int p, int kt, int buf) {
+        const int k0 = kt * BKT;
+        if (p == PB) {
+            if (wave_u < F4A / 64) __builtin_amdgcn_global_load_lds((rl_gbl_vptr)(dma_src_a + k0), (rl_lds_vptr)(As + buf * A_FL + wave_u * RPI * BKT), 16, 0, 0);
+        } else {
+            __builtin_amdgcn_global_load_lds((rl_gbl_vptr)(dma_src_b[p] + k0), (rl_lds_vptr)(Bs + buf * B_FL + ((64 * wave_u + NT * p) / CPR) * BKT), 16, 0, 0);
+        }
+    };
     f32x4 ra, rb[PB];
     // piece p of stage kt: global -> registers (p = 0 .. PB-1: weight pieces, p = PB: the activation piece).  Branch-free: clamped k,
     // zeroed at the LDS write.
@@ -169,20 +198,25 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
                             for (int j2 = 0; j2 < TN; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j2 + li, 2 * (g8 + 1) + h));
                         }
                         if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) {
-                            load_piece(idx / LSTEP, kt_next);
+                            if constexpr (DMA) dma_piece(idx / LSTEP, kt_next, cur ^ 1); else load_piece(idx / LSTEP, kt_next);
                             __builtin_amdgcn_sched_barrier(0);
                         }
-                        if (idx >= S0 && (idx - S0) % STEP == 0 && (idx - S0) / STEP < NS) {
+                        if (!DMA && idx >= S0 && (idx - S0) % STEP == 0 && (idx - S0) / STEP < NS) {
                             if constexpr (DBG < 3) store_piece((idx - S0) / STEP, kt_next, cur ^ 1);      // DBG 3, 4: no LDS hand-over writes
                             __builtin_amdgcn_sched_barrier(0);           // pin the piece here: the scheduler otherwise sinks every write to the end
                         }
                     }
         }
     };
+    if constexpr (DMA) {
 #pragma unroll
-    for (int p = 0; p < NS; ++p) load_piece(p, 0);
+        for (int p = 0; p < NS; ++p) dma_piece(p, 0, 0);
+    } else {
 #pragma unroll
-    for (int p = 0; p < NS; ++p) store_piece(p, 0, 0);
+        for (int p = 0; p < NS; ++p) load_piece(p, 0);
+#pragma unroll
+        for (int p = 0; p < NS; ++p) store_piece(p, 0, 0);
+    }
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -292,8 +326,24 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     }
 }
 
+static int g_rowln_dma = 1;     // 1: LDS-DMA staging where K % BKT == 0 (aid_rowln_debug(16) switches it off for A/B timing)
+template <int BN, int BKT, int ACT, bool LNF>
+static int launch_rowln_dma(const RowLnArgs& g, dim3 grid, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
+    static bool attr_done = false;
+    if (!attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, BKT, ACT, false, 0, LNF, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, false, 0, LNF, true>), grid, dim3(512), lds, s, g);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
 template <int BN, int BKT, int ACT, bool KTAIL>
 static int launch_rowln_t(const RowLnArgs& g, hipStream_t s) {
+    // LDS-DMA staging pays at 16-deep stages (BN = 1024: 105.4 vs 102.6 TFLOP/s at 128 000 rows) and loses at 32-deep ones (BN = 512: 110.2 vs
+    // 116.5), measured in one process (tools/perf/rowln_bench.py, ROWLN_AB=1): the 512-wide kernels keep the register path
+    if constexpr (!KTAIL && BN == 1024) { if (g_rowln_dma) return launch_rowln_dma<BN, BKT, ACT, true>(g, dim3((g.M + 63) / 64), s); }
     constexpr size_t lds = sizeof(float) * 2 * (64 * BKT + (size_t)BN * BKT);
     static bool attr_done = false;
     if (!attr_done) {
@@ -391,7 +441,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 }  // namespace aid
 
 using namespace aid;
-extern "C" int aid_rowln_debug(int mode) { g_rowln_dbg = mode; return AID_OK; }
+extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                                  const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");

@@ -34,6 +34,9 @@ for (M, N, K, skip) in shapes:
     ref = torch.nn.functional.silu(torch.nn.functional.layer_norm(C, (N,), ga, be, 1e-5)) + (add if skip else 0)
     err = float((y - ref).abs().max())
     extra = ""
+    if os.environ.get("ROWLN_AB"):
+        nat.lib().aid_rowln_debug(16); t = timeit(fused, reps); nat.lib().aid_rowln_debug(17)
+        extra += f"  register-staged {t*1e6:8.1f} us ({fl/t/1e12:5.1f} TF) "
     if os.environ.get("ROWLN_DBG"):
         for mode in (1, 2, 4, 3):
             nat.lib().aid_rowln_debug(mode); t = timeit(fused, reps); nat.lib().aid_rowln_debug(0)

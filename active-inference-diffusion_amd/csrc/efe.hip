@@ -305,8 +305,8 @@ extern "C" {
 size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec, int B, const AidEfeCfg* cfg) {
     if (!pol || !cfg || B <= 0 || (!dec && !cfg->skip_epistemic)) return 0;
     const size_t M = (size_t)cfg->K * B, R = M * cfg->S, D = pol->D, H = cfg->H;
-    size_t n = dec ? mine_ws_bytes(*dec, cfg->K, cfg->S, B) : 0;
-    n += sizeof(float) * H * M * (40 * D + 64);                       // per-step saved activations (policy, dynamics, reward, value)
+    size_t n = dec ? mine_ws_bytes(*dec, (int)(H * cfg->K), cfg->S, B) : 0;     // the estimator runs over all H horizon steps in one pass
+    n += sizeof(float) * H * M * (40 * D + 64 + pol->L);                       // per-step saved activations (policy, dynamics, reward, value)
     n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
     n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
     n += sizeof(int32_t) * H * R + (1 << 20);
@@ -365,13 +365,14 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
     float* acc = ws.f32(M); float* prag = ws.f32(M); float* cons = ws.f32(M);
     float* mine_all = ws.f32((size_t)H * K * 4);
     float* lat_rep = ws.f32((size_t)M * L);
+    float* next_mean_all = ws.f32((size_t)H * M * L);      // [H][K*B][L]: the estimator runs ONCE over the dynamics means of every horizon step
     AID_WS_OK(ws);
     LAUNCH1D(tile_rows_kernel, (size_t)M * L, s, latents, lat_rep, K, (size_t)B * L);   // latent.clone() per trajectory
     const float sd = expf(0.5f * logf(0.1f));
     const float* cur = lat_rep;
     for (int t = 0; t < H; ++t) {
         Step& q = st[t];
-        q.cur = (float*)cur; q.next_mean = ws.f32((size_t)M * L); q.nxt = ws.f32((size_t)M * L); q.V = ws.f32(M); q.tvec = ws.f32(M);
+        q.cur = (float*)cur; q.next_mean = next_mean_all + (size_t)t * M * L; q.nxt = ws.f32((size_t)M * L); q.V = ws.f32(M); q.tvec = ws.f32(M);
         AID_WS_OK(ws);
         AID_TRY(policy_fwd(*pol, M, cur, L, pol_eps + (size_t)t * M * A, q.ps, ws, s));
         AID_TRY(dynamics_fwd(*dyn, M, cur, L, q.ps.action, A, q.next_mean, q.ds, ws, s));
@@ -380,16 +381,19 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
         AID_TRY(reward_fwd(*rew, M, q.nxt, L, q.rs, ws, s));
         AID_TRY(fill_const(q.tvec, (float)t, M, s));
         AID_TRY(value_fwd(*val, M, q.nxt, L, q.tvec, q.V, q.vs, ws, s));
-        float* mine_t = nullptr;
-        if (do_epi) {
-            mine_t = mine_all + (size_t)t * K * 4;
-            AID_TRY(mine_forward(*dec, *epi, K, S, B, q.next_mean, z_eps + (size_t)t * R * L, delta + (size_t)t * 4 * R * L,
-                                 train ? pmask + (size_t)t * R * epi->jp0.out : nullptr, train ? mmask + (size_t)t * 4 * R * epi->mn0.out : nullptr,
-                                 perms + (size_t)t * R, train, mine_t, ws, s));
-        }
-        LAUNCH1D(efe_accum_kernel, M, s, q.rs.out, q.V, q.ps.ent, mine_t, powf(cfg->discount, (float)t), cfg->epistemic_weight,
-                 cfg->pragmatic_weight, cfg->consistency_weight, cfg->temperature, acc, prag, cons, M, B, t == 0);
         cur = q.nxt;
+    }
+    // The epistemic term is gradient-free and feeds nothing the rollout reads, so it is evaluated after the rollout, for all H steps at
+    // once: H*K trajectory segments = 128 000 sample rows (640 000 through the decoder) per GEMM instead of 25 600 five times - no
+    // partial last round of workgroups (25 600 rows are 1.56 rounds of the 64-row kernels), a fifth of the launches, and the rollout's
+    // small dependent kernels run back to back (next to the ELBO chain of the other stream) instead of between the big GEMMs.  The MINE
+    // statistics stay per (k, t) segment and the running mean is replayed in the reference's (k outer, t inner) order below.
+    if (do_epi)
+        AID_TRY(mine_forward(*dec, *epi, H * K, S, B, next_mean_all, z_eps, delta, train ? pmask : nullptr, train ? mmask : nullptr, perms, train, mine_all, ws, s));
+    for (int t = 0; t < H; ++t) {
+        Step& q = st[t];
+        LAUNCH1D(efe_accum_kernel, M, s, q.rs.out, q.V, q.ps.ent, do_epi ? mine_all + (size_t)t * K * 4 : nullptr, powf(cfg->discount, (float)t), cfg->epistemic_weight,
+                 cfg->pragmatic_weight, cfg->consistency_weight, cfg->temperature, acc, prag, cons, M, B, t == 0);
     }
     hipLaunchKernelGGL(efe_final_kernel, dim3(1), dim3(1024), 0, s, acc, prag, cons, do_epi ? mine_all + (size_t)(H - 1) * K * 4 : nullptr, K, B, efe_out, info);
     AID_LAUNCH_CHECK();

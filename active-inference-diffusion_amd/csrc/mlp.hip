@@ -87,13 +87,33 @@ int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, 
 
 // ---------------------------------------------------------------------------------------------- decoder (forward only)
 size_t decoder_ws_bytes(const AidDecoderNet& d, int M) {
-    return sizeof(float) * (size_t)M * ((size_t)2 * d.s[0].out + 2 * d.s[1].out + 2 * d.s[2].out + 8) + 16 * 256;
+    // tall inference inputs whose stages all take a fused Linear-LayerNorm path keep one buffer per stage (decoder_fwd); anything else two
+    auto wide = [](int n) { return n == 512 || n == 1024; };
+    const bool lean = M >= 4096 && wide(d.s[1].out) && wide(d.s[2].out) && d.s[1].in % 4 == 0 && d.s[2].in % 4 == 0 && d.s[1].in >= 64 && d.s[2].in >= 64 &&
+                      (d.s[0].in <= 32 ? d.s[0].out % 256 == 0 : (wide(d.s[0].out) && d.s[0].in % 4 == 0 && d.s[0].in >= 64));
+    return sizeof(float) * (size_t)M * ((size_t)(lean ? 1 : 2) * (d.s[0].out + d.s[1].out + d.s[2].out) + 8) + 64 * 256;
 }
 int decoder_fwd(const AidDecoderNet& d, int M, const float* z, int ldz, const float* const masks[3], float* out, int ldo, Workspace& ws,
                 hipStream_t s) {
     const size_t mark = ws.mark();
     LlaSave s0, s1, s2;
-    lla_alloc(M, d.s[0].out, ws, s0); lla_alloc(M, d.s[1].out, ws, s1); lla_alloc(M, d.s[2].out, ws, s2);
+    // inference on tall inputs writes nothing but each stage's output (LayerNorm in the GEMM epilogue): no pre-LN buffers then (at the
+    // estimator's 640 000 rows they would be 6.5 GB)
+    const bool tall = M >= 4096;
+    if (!tall) { lla_alloc(M, d.s[0].out, ws, s0); lla_alloc(M, d.s[1].out, ws, s1); lla_alloc(M, d.s[2].out, ws, s2); }
+    else {
+        s0.y = ws.f32((size_t)M * d.s[0].out); s1.y = ws.f32((size_t)M * d.s[1].out); s2.y = ws.f32((size_t)M * d.s[2].out);
+        // a stage gets pre-LN / statistics buffers only if it cannot take one of lla_fwd's fused paths (which write y alone)
+        const float* m0 = masks ? masks[0] : nullptr;
+        const bool f0 = (lin_smallk_ln_act_ok(d.s[0].in, d.s[0].out, ACT_SILU, d.s[0].w, s0.y, nullptr, m0, d.s[0].out) &&
+                         ((((uintptr_t)d.s[0].b | (uintptr_t)d.ln[0].g | (uintptr_t)d.ln[0].b) & 15) == 0)) ||
+                        linear_ln_act_rows_ok(M, d.s[0].out, d.s[0].in, ACT_SILU, z, ldz, d.s[0].w, nullptr, 0, s0.y, d.s[0].out);
+        const bool f1 = linear_ln_act_rows_ok(M, d.s[1].out, d.s[1].in, ACT_SILU, s0.y, d.s[0].out, d.s[1].w, s0.y, d.s[0].out, s1.y, d.s[1].out);
+        const bool f2 = linear_ln_act_rows_ok(M, d.s[2].out, d.s[2].in, ACT_SILU, s1.y, d.s[1].out, d.s[2].w, nullptr, 0, s2.y, d.s[2].out);
+        s0.lin = f0 ? nullptr : ws.f32((size_t)M * d.s[0].out); s0.stats = f0 ? nullptr : ws.f32((size_t)M * 2);
+        s1.lin = f1 ? nullptr : ws.f32((size_t)M * d.s[1].out); s1.stats = f1 ? nullptr : ws.f32((size_t)M * 2);
+        s2.lin = f2 ? nullptr : ws.f32((size_t)M * d.s[2].out); s2.stats = f2 ? nullptr : ws.f32((size_t)M * 2);
+    }
     AID_WS_OK(ws);
     AID_TRY(lla_fwd(d.s[0], d.ln[0], ACT_SILU, masks ? masks[0] : nullptr, z, ldz, M, s0, s, nullptr, false));   // inference: nothing saved
     AID_TRY(lla_fwd(d.s[1], d.ln[1], ACT_SILU, masks ? masks[1] : nullptr, s0.y, d.s[0].out, M, s1, s, s0.y, false));   // h2 = stage(h1) + h1 (skip, :240)

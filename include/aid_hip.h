@@ -283,8 +283,9 @@ int aid_adamw_step(float* p, const float* g, float* m, float* v, float* ema, siz
  * (active_inference.py:314-418, 940-1063).  The K trajectories are batched: row r = k*B + b.
  * Noise tensors (NULL member => Philox draw), H = horizon, M = K*B, R = K*S*B:
  *   policy_eps [H,M,A]  rsample draws;  reparam_eps [H,M,L]  reparameterize draws;
- *   mine_z_eps [H,R,L] (row (k*S+s)*B+b);  mine_delta [H,4,R,L] raw N(0,1) perturbation directions;
- *   proj_mask [H,R,512] jacobian_projector dropout;  mine_mask [H,4,R,512] = joint(0,1), marginal(2,3) masks;
+ *   mine_z_eps [H,R,L] (row (k*S+s)*B+b);  mine_delta [4,H,R,L] raw N(0,1) perturbation directions (direction j outermost);
+ *   proj_mask [H,R,512] jacobian_projector dropout;  mine_mask [4,H,R,512] = joint(0,1), marginal(2,3) masks (mask kind outermost: the
+ *   estimator runs ONCE over all H horizon steps, H*R rows, so each per-layer operand is one contiguous [H*R, .] matrix);
  *   perms [H,K,S,B] int32 permutations (randperm per sample block).
  * Outputs: efe[B]; info (device, 16 floats): 0 policy_loss(=mean efe) 1 epistemic_mean 2 pragmatic_mean
  * 3 consistency_mean 4 mi_estimate 5 joint_term 6 marginal_term (last (k,t) call) ;

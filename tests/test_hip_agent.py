@@ -68,7 +68,11 @@ def test_state_dict_layout_and_golden_train_steps(golden_dir, tag):
                 np.testing.assert_allclose(sd[k.split("/", 1)[1]].cpu().numpy(), g[k], rtol=1e-3, atol=2e-6, err_msg=k)
         # every parameter, via checksums of the reference's post-step state_dict
         cs = np.array([float(sd[n].double().sum()) for n, _ in specs])
-        bad = np.abs(cs - g[f"ts{step}_checksum"]) > 2e-5 * g[f"ts{step}_abssum"] + 2e-5
+        tol = 2e-5 * g[f"ts{step}_abssum"] + 2e-5
+        # the estimator's running mean is an EMA of mean(exp(T)) with T ~ 20-40 at these random weights (values ~1e9): an absolute fp32
+        # rounding difference of 2e-5 in T is a RELATIVE difference of 2e-5 in exp(T), so this one entry is held to 1e-4 relative
+        tol[[n for n, _ in specs].index("epistemic_estimator.running_mean")] *= 5.0
+        bad = np.abs(cs - g[f"ts{step}_checksum"]) > tol
         assert not bad.any(), [specs[i][0] for i in np.nonzero(bad)[0]]
         np.testing.assert_allclose(agent.score_ema.shadow["output_proj.2.weight"].cpu().numpy(),
                                    g[f"ts{step}_ema/latent_score_network.output_proj.2.weight"], rtol=1e-4, atol=1e-7)

@@ -90,9 +90,9 @@ def _sharded_noise(rank, world):
             out = {"policy_eps": g["policy_eps"].view(Hh, K, bg, Aa)[:, :, sl].reshape(Hh, K * b, Aa).contiguous(),
                    "reparam_eps": g["reparam_eps"].view(Hh, K, bg, L)[:, :, sl].reshape(Hh, K * b, L).contiguous(),
                    "mine_z_eps": g["mine_z_eps"].view(Hh, K, S, bg, L)[:, :, :, sl].reshape(Hh, K * S * b, L).contiguous(),
-                   "mine_delta": g["mine_delta"].view(Hh, 4, K, S, bg, L)[:, :, :, :, sl].reshape(Hh, 4, K * S * b, L).contiguous(),
+                   "mine_delta": g["mine_delta"].view(4, Hh, K, S, bg, L)[:, :, :, :, sl].reshape(4, Hh, K * S * b, L).contiguous(),
                    "proj_mask": g["proj_mask"].view(Hh, K, S, bg, 512)[:, :, :, sl].reshape(Hh, K * S * b, 512).contiguous(),
-                   "mine_mask": g["mine_mask"].view(Hh, 4, K, S, bg, 512)[:, :, :, :, sl].reshape(Hh, 4, K * S * b, 512).contiguous()}
+                   "mine_mask": g["mine_mask"].view(4, Hh, K, S, bg, 512)[:, :, :, :, sl].reshape(4, Hh, K * S * b, 512).contiguous()}
             rng = np.random.default_rng(rank)        # row permutations of the gradient-free estimator: any valid ones
             out["perms"] = torch.from_numpy(np.stack([rng.permutation(b) for _ in range(Hh * K * S)]).reshape(Hh, K, S, b).astype(np.int32)).cuda()
             return out

@@ -146,8 +146,8 @@ def _efe_noise(key, B, L, A, H, K, S):
     ns = NoiseStream(key)
     M, R = K * B, K * S * B
     n = {"policy_eps": np.zeros((H, M, A), np.float32), "reparam_eps": np.zeros((H, M, L), np.float32),
-         "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((H, 4, R, L), np.float32),
-         "proj_mask": np.zeros((H, R, 512), np.float32), "mine_mask": np.zeros((H, 4, R, 512), np.float32),
+         "mine_z_eps": np.zeros((H, R, L), np.float32), "mine_delta": np.zeros((4, H, R, L), np.float32),
+         "proj_mask": np.zeros((H, R, 512), np.float32), "mine_mask": np.zeros((4, H, R, 512), np.float32),
          "perms": np.zeros((H, K, S, B), np.int32)}
     for k in range(K):
         rs = slice(k * S * B, (k + 1) * S * B)
@@ -157,14 +157,14 @@ def _efe_noise(key, B, L, A, H, K, S):
             for s_ in range(S):
                 n["mine_z_eps"][t, k * S * B + s_ * B:k * S * B + (s_ + 1) * B] = ns.randn(B, L)
             for j in range(4):
-                n["mine_delta"][t, j, rs] = ns.randn(S * B, L)
+                n["mine_delta"][j, t, rs] = ns.randn(S * B, L)
             n["proj_mask"][t, rs] = ns.dropout_mask((S * B, 512), 0.1)
-            n["mine_mask"][t, 0, rs] = ns.dropout_mask((S * B, 512), 0.1)
-            n["mine_mask"][t, 1, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][0, t, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][1, t, rs] = ns.dropout_mask((S * B, 512), 0.1)
             for s_ in range(S):
                 n["perms"][t, k, s_] = ns.randperm(B)
-            n["mine_mask"][t, 2, rs] = ns.dropout_mask((S * B, 512), 0.1)
-            n["mine_mask"][t, 3, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][2, t, rs] = ns.dropout_mask((S * B, 512), 0.1)
+            n["mine_mask"][3, t, rs] = ns.dropout_mask((S * B, 512), 0.1)
     return n
 
 

@@ -209,7 +209,7 @@ int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.slab = slab;
     g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
     ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    prof.m = M; prof.n = N; prof.k = K; prof.layout = 0; prof.variant = 22;
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * ((M + 255) / 256 > 4 ? 4 : (M + 255) / 256) + act; prof.variant = 22;      // layout field: 8 BMT + act = the instantiation
     switch (act) {
         case ACT_GELU: return launch_mid_bm<ACT_GELU>(g, s);
         case ACT_SILU: return launch_mid_bm<ACT_SILU>(g, s);

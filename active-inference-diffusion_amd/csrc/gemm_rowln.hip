@@ -427,7 +427,8 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
     g.A = x; g.lda = ldx; g.W = W; g.ldw = K; g.bias = b; g.gamma = gamma; g.beta = beta; g.add = add; g.ldadd = ldadd; g.mask = mask; g.ldmask = ldmask; g.Y = y; g.ldy = ldy;
     g.M = M; g.K = K; g.eps = 1e-5f;
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    prof.m = M; prof.n = N; prof.k = K; prof.layout = 0; prof.variant = N == 1024 ? 20 : 21;
+    prof.m = M; prof.n = N; prof.k = K; prof.variant = N == 1024 ? 20 : 21;
+    prof.layout = act + 8 * (K % (N == 1024 ? 16 : 32) != 0) + 16 * (N == 1024 && K % 16 == 0 && g_rowln_dma);      // act, K-tail, DMA: the instantiation
     if (N == 1024) {
         if (act == ACT_SILU) return launch_rowln<1024, 16, ACT_SILU>(g, s);
         if (act == ACT_RELU) return launch_rowln<1024, 16, ACT_RELU>(g, s);

@@ -115,16 +115,20 @@ def kernel_name(variant, layout):
     """The template instantiation a (variant, layout) pair of aid_prof_dump names, spelled as rocprofv3 prints it (minus `void aid::` and
     the argument list)."""
     b = lambda x: "true" if x else "false"
+    # Linear -> LayerNorm -> act in one full-row-tile kernel (csrc/gemm_rowln.hip), its plain-epilogue form, and the reverse loop's
+    # one-workgroup-per-CU kernel (csrc/gemm_mid.hip): the `layout` column carries the remaining template arguments
+    if variant in (20, 21):
+        return f"gemm_rowln_kernel<{1024 if variant == 20 else 512}, {16 if variant == 20 else 32}, {layout & 7}, {b(layout & 8)}, 0, true, {b(layout & 16)}>"
+    if variant == 23:
+        return f"gemm_rowln_kernel<512, 32, {layout & 7}, {b(layout & 8)}, 0, false, false>"
+    if variant == 22:
+        return f"gemm_mid_kernel<{layout >> 3}, {layout & 7}>"
     a, k = b((layout & 3) >> 1), b(layout & 1)
     return {1: f"gemm_panel_kernel<{a}, {k}>", 2: f"gemm_ring_kernel<64, 64, 128, {a}, {k}>", 3: "gemm_smallk_kernel",
             4: f"gemm_tile_kernel<64, 64, {a}, {k}, true>", 5: f"gemm_tile_kernel<64, 64, {a}, {k}, false>",
             6: f"gemm_splitk_kernel<{a}, {k}, true>", 7: f"gemm_splitk_kernel<{a}, {k}, false>", 8: "gemm_thin_tn_kernel", 10: "gemm_skinny_kernel", 9: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 2>",
             11: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 1>", 14: f"gemm_panel128_kernel<{a}, {k}, 128>",
-            15: f"gemm_panel128_kernel<{a}, {k}, 64>",
-            # Linear -> LayerNorm -> act in one full-row-tile kernel (csrc/gemm_rowln.hip); the reverse loop's one-workgroup-per-CU kernel
-            # (csrc/gemm_mid.hip, every BM / activation instantiation folded into one row)
-            20: "gemm_rowln_kernel<1024, 16, ...>", 21: "gemm_rowln_kernel<512, 32, ...>", 22: "gemm_mid_kernel<...>",
-            23: "gemm_rowln_kernel<512, 32, ...> (plain epilogue)"}.get(variant, f"variant{variant}<{a}, {k}>")
+            15: f"gemm_panel128_kernel<{a}, {k}, 64>"}.get(variant, f"variant{variant}<{a}, {k}>")
 
 
 def per_kernel_table(path):
@@ -137,6 +141,8 @@ def per_kernel_table(path):
         e = agg.setdefault(kernel_name(int(r["variant"]), int(r["layout"])), {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         M, N, K = int(r["M"]), int(r["N"]), int(r["K"])
         e["launches"] += 1; e["ms"] += float(r["ms"]); e["flops"] += 2.0 * M * N * K; e["bytes"] += 4.0 * (M * K + N * K + M * N)
+        if int(r["variant"]) == 20:
+            e["bytes"] += 4.0 * M * N       # the 1024-wide decoder stage also reads its skip operand (h2 = stage(h1) + h1)
     return agg
 
 
@@ -400,7 +406,7 @@ def main():
     def entry(name, d):
         e = {"bound": "mfma", "kernel": "aid::" + name, "achieved": tf(d), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
              "frac": tf(d) * 1e12 / PEAK_F32_MFMA,
-             "traffic": traffic(name.split(", ...")[0].split("...")[0] if "..." in name else (name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name)),
+             "traffic": traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name),
              "launches_per_step": d["launches"], "ms_per_step": d["ms"], "flop_per_launch": d["flops"] / max(d["launches"], 1),
              "algorithmic_bytes_per_launch": d["bytes"] / max(d["launches"], 1),
              "us_per_launch": 1e3 * d["ms"] / max(d["launches"], 1)}
@@ -426,9 +432,9 @@ def main():
         "roofline": dominant,
         "roofline_second_kernel": second,
         "roofline_kernels": [entry(n, d) for n, d in ranked[:8]],
-        "roofline_big_family": {"kernel": "GEMM launches that ran a 64x64-tile kernel (>= 160 tiles: MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
+        "roofline_big_family": {"kernel": "GEMM launches that ran a full-row or 64x64-tile kernel (tall problems: MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
                                 "frac": tf(gt) * 1e12 / PEAK_F32_MFMA, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"]},
-        "roofline_small_family": {"kernel": "GEMM launches that ran a small-problem kernel (batch-256..768 layers of the reverse loops, ELBO, BPTT, thin heads); per-CU "
+        "roofline_small_family": {"kernel": "GEMM launches that ran a small-problem kernel (the 256..768-row layers of the reverse loops, ELBO, BPTT, thin heads); per-CU "
                                             "ingest / latency-bound (DESIGN.md section 5)", "achieved": tf(gs), "frac": tf(gs) * 1e12 / PEAK_F32_MFMA,
                                   "launches_per_step": gs["launches"], "ms_per_step": gs["ms"]},
         "roofline_gemm_family": {"kernel": "every fp32-MFMA GEMM launch of one train_step", "achieved": tf(g), "frac": tf(g) * 1e12 / PEAK_F32_MFMA,

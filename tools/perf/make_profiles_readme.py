@@ -1,29 +1,31 @@
 """Regenerates profiles/README.md from the committed rocprofv3 / bench artifacts (run from the repo root, no GPU needed)."""
 import csv, json, os
 P = "profiles"
-bench = json.loads(open(os.path.join(P, "r01_bench.json")).read().strip().splitlines()[-1])
-rows = list(csv.DictReader(open(os.path.join(P, "r01_train_step_kernel_stats.csv"))))
-pmc = json.load(open(os.path.join(P, "r01_pmc_summary.json")))
+R = "r02"          # the round whose artifacts this README describes (earlier rounds' files stay in profiles/ as history)
+bench = json.loads(open(os.path.join(P, R + "_bench.json")).read().strip().splitlines()[-1])
+rows = list(csv.DictReader(open(os.path.join(P, R + "_train_step_kernel_stats.csv"))))
+pmc = json.load(open(os.path.join(P, R + "_pmc_summary.json")))
 other = {}
-if os.path.exists(os.path.join(P, "r01_other_configs.jsonl")):
-    for line in open(os.path.join(P, "r01_other_configs.jsonl")):
+if os.path.exists(os.path.join(P, R + "_other_configs.jsonl")):
+    for line in open(os.path.join(P, R + "_other_configs.jsonl")):
         line = line.strip()
         if line.startswith("{"):
             d = json.loads(line); other[d["config"]] = d
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = []
 w = out.append
-w("# profiles/ — rocprofv3 evidence, round 1\n")
+w("# profiles/ — rocprofv3 evidence, round 2\n")
 w("Regenerate this file with `python tools/perf/make_profiles_readme.py`; collect the inputs on the GPU box with `bash tools/perf/pmc_bench.sh`\n"
-  "(kernel stats + one PMC counter group per pass) and `python bench.py > profiles/r01_bench.json`.\n")
+  "(kernel stats + one PMC counter group per pass) and `python bench.py > profiles/r02_bench.json`.\n")
 w("| file | what |\n|---|---|\n"
-  "| `r01_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags) |\n"
-  "| `r01_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline` |\n"
-  "| `r01_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (side stream off): the per-kernel averages that bench.py's single-stream live measurement is comparable with |\n"
-  "| `r01_pmc_summary.json` | per-kernel averages of the PMC passes over ONE train_step (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) |\n"
-  "| `gemm_big_r01.txt`, `gemm_shapes_r01.txt` | microbenchmarks of the GEMM kernel variants per shape (`tools/perf/big_gemm.py`, `gemm_shapes.py`); the dispatcher in `csrc/gemm_f32.hip` is set from them and from the in-situ chain `tools/perf/cold_chain.py` |\n"
-  "| `r01_gemm_big_stall_breakdown.txt` | SQ wave-state, LDS, L1 and L2 counters of `gemm_big_kernel` on the 25 600 x 1024 x 1024 MINE shape (`tools/perf/pmc_stall.sh`) and what they say |\n"
-  "| `r01_other_configs.jsonl` | cfg 3 (Hopper, B=1024) and cfg 4 (pixels, B=256) train_step timings (`tools/perf/other_configs.py`) |\n")
+  "| `r02_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags), extras included (`other_configs`, `small_batch`) |\n"
+  "| `r02_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras` |\n"
+  "| `r02_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (side stream off): the per-kernel averages that bench.py's single-stream live measurement is comparable with |\n"
+  "| `r02_pmc_summary.json` | per-kernel averages of the PMC passes over ONE train_step (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) |\n"
+  "| `r02_rowln_ablation.txt` | the full-row GEMM+LayerNorm kernel on the two estimator shapes with parts of it switched off (`tools/perf/rowln_bench.py`, `ROWLN_DBG`): where the distance to the MFMA peak goes |\n"
+  "| `r02_rowln_pmc.txt` | PMC passes of the same kernel alone (`tools/perf/pmc_rowln.sh`) |\n"
+  "| `r02_gemm_mid.txt` | the reverse loop's one-workgroup-per-CU GEMM per shape and split (`tools/perf/mid_bench.py`) |\n"
+  "| `r01_*`, `gemm_big_r01.txt`, `gemm_shapes_r01.txt` | round 1's artifacts, kept as history (the kernels they describe still serve cfg 3 / cfg 4 and the BPTT) |\n")
 w("## Bench line (cfg 2: B=256, H=5, K=10, S=10, N=50, D=512, fp32)\n")
 w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/step; whole-step algorithmic rate {bench['train_step_algorithmic_tflops']:.1f} TFLOP/s "
   f"= {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
@@ -35,10 +37,10 @@ for key in ("roofline", "roofline_second_kernel"):
 r = bench["roofline"]
 if r.get("traffic") and r.get("algorithmic_bytes_per_launch"):
     w(f"  PMC traffic vs algorithmic bytes of the dominant kernel (`roofline`): {r['traffic']/1e6:.0f} MB against {r['algorithmic_bytes_per_launch']/1e6:.0f} MB per launch "
-      f"({r['traffic']/r['algorithmic_bytes_per_launch']:.1f}x).  `FETCH_SIZE` counts what the eight per-XCD L2s pull from the fabric (Infinity Cache or HBM): every XCD "
-      "fetches its own copy of the weight operand, and an activation row tile is fetched once per group of 8 column tiles.  At "
-      f"{r['traffic']/1e6/r['us_per_launch']*1e6/1e6:.1f} TB/s the kernel is nowhere near the 8 TB/s roof, and the tile map that removes the replicated weight fetch "
-      "(N-partitioned across XCDs) was measured in situ: no gain (DESIGN.md, tried and rejected).")
+      f"({r['traffic']/r['algorithmic_bytes_per_launch']:.2f}x; algorithmic = A + W + skip operand read, output written, 4 B each).  `FETCH_SIZE` counts what the "
+      "eight per-XCD L2s pull from the fabric (Infinity Cache or HBM): the 4 MB weight matrix is fetched by every XCD and falls out of its 4 MB L2 now and then "
+      f"(L2 hit rate 93 %, `r02_rowln_pmc.txt`); the write side equals the algorithmic figure exactly.  At {r['traffic']/r['us_per_launch']/1e6:.2f} TB/s the kernel is far "
+      "from the 8 TB/s roof: it is bound by MFMA issue (pipe 79 % busy at the 2.08 GHz the chip holds under this load, `r02_pmc_summary.json`).")
 for key in ("roofline_big_family", "roofline_small_family"):
     r = bench[key]
     w(f"* `{key}`: {r['kernel']} — {r['achieved']:.1f} TFLOP/s = {100*r['frac']:.1f} % over {r['launches_per_step']} launches, {r['ms_per_step']:.1f} ms.")
@@ -50,7 +52,7 @@ if "cpu_baseline" in bench:
     c = bench["cpu_baseline"]
     w(f"* CPU baseline (oracle port, {c['cores']} host cores): {c['value']:.3f} steps/s ({c['sample']}) → GPU/CPU = {bench['speedup_vs_cpu_baseline']:.0f}×.")
 w("")
-noov = os.path.join(P, "r01_train_step_kernel_stats_no_overlap.csv")
+noov = os.path.join(P, R + "_train_step_kernel_stats_no_overlap.csv")
 if os.path.exists(noov):
     nrows = {r["Name"]: r for r in csv.DictReader(open(noov))}
     w("## Live HIP-event measurement (bench.py, one single-stream step) vs rocprofv3 (`bench.py --no-overlap`, whole process)\n")
@@ -72,11 +74,19 @@ w("| kernel | launches | avg µs | read MB/launch | write MB/launch | MFMA pipe 
 for k, v in pmc.items():
     w(f"| `{k[:60]}` | {v.get('launches_mfma','')} | {v.get('avg_us_mfma',0):.1f} | {v.get('fetch_bytes_per_launch_corrected',0)/1e6:.1f} | {v.get('write_bytes_per_launch',0)/1e6:.1f} | "
       f"{100*v.get('mfma_util',0):.1f} % | {v.get('eff_clock_GHz',0):.2f} |")
-w("\nThe effective-clock column reads high on dispatches shorter than ≈0.3 ms (guide, DVFS note); it is meaningful for `gemm_big_kernel` only.\n")
-if other:
-    w("## Other BASELINE configs (same build, 1x MI355X)\n")
-    for k, d in other.items():
-        extra = "".join(f", {a} {d[a]:.1f}" for a in ("encoder_fwd_ms", "encoder_bwd_ms") if a in d)
-        w(f"* {k}: {d['ms_per_step']:.1f} ms/step = {d['steps_per_s']:.2f} steps/s{extra}")
+w("\nThe effective-clock column reads high on dispatches shorter than ≈0.3 ms (guide, DVFS note); it is meaningful for the millisecond-long `gemm_rowln_kernel` rows only.\n")
+oc = bench.get("other_configs", {})
+if oc:
+    w("## Other BASELINE configs at full size (same build, same process as the bench line, outside its timed region)\n")
+    for k, d in oc.items():
+        w(f"* {k}: {d['ms_per_step']:.1f} ms/step = {d['steps_per_s']:.2f} steps/s, {d['algorithmic_tflops']:.1f} algorithmic TFLOP/s = {100*d['frac_of_f32_mfma_peak']:.1f} % of the fp32-MFMA peak")
+    w("")
+sb = bench.get("small_batch", {})
+if sb:
+    w("## Small-batch reverse loops (hipGraph replay; bound by streaming the score network's weights once per denoise step)\n")
+    for k, d in sb.items():
+        w(f"* {k}: {d['rows']} rows, {d['us_per_denoise_step']:.1f} µs per denoise step = {d['denoise_steps_per_s']:.0f} steps/s; "
+          f"{d['weight_bytes_per_step']/1e6:.1f} MB of weights per step -> {d['achieved_GBps']:.0f} GB/s = {100*d['achieved_GBps']/d['peak_GBps']:.1f} % of 8 TB/s")
+    w("")
 open(os.path.join(P, "README.md"), "w").write("\n".join(out) + "\n")
 print("\n".join(out)[:3000])

@@ -12,6 +12,7 @@ from oracle import aid_oracle as orc
 from oracle.noise import NoiseStream
 from oracle.weights import draw_params, param_specs
 from parity_noise import ParityNoise
+from tolerances import assert_metric
 
 
 class Box:
@@ -61,7 +62,7 @@ def test_state_dict_layout_and_golden_train_steps(golden_dir, tag):
             if k.startswith(f"ts{step}_metric/"):
                 name = k.split("/", 1)[1]
                 if name in m:
-                    np.testing.assert_allclose(m[name], g[k], rtol=5e-3, atol=5e-5, err_msg=f"step {step} {name}")
+                    assert_metric(name, float(m[name]), float(g[k]), f"step {step}")
         sd = ai.state_dict()
         for k in g.files:
             if k.startswith(f"ts{step}_param/"):
@@ -101,7 +102,7 @@ def test_train_step_full_width_vs_oracle():
     m_ref = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
     for k, v in m_ref.items():
         if k in m and isinstance(v, float):
-            np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=k)
+            assert_metric(k, float(m[k]), v)
     sd = ai.state_dict()
     for n, _ in specs:
         if n == "epistemic_estimator.running_mean":
@@ -167,7 +168,7 @@ def test_cross_step_prefetch_equals_reference_order():
         m_ref = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
         for k, v in m_ref.items():
             if k in m and isinstance(v, float):
-                np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=f"step {step} {k}")
+                assert_metric(k, float(m[k]), v, f"step {step}")
     sd = ai.state_dict()
     for n, _ in specs:
         if n == "epistemic_estimator.running_mean":

@@ -105,6 +105,7 @@ def test_encoder_batch16_vs_oracle(nat):
 # ------------------------------------------------------------------------------------------------- pixel-mode training pieces
 from oracle.weights import draw_params, param_specs
 from parity_noise import ParityNoise
+from tolerances import assert_metric
 
 
 def test_infonce_golden_and_oracle(nat, golden_dir):
@@ -203,7 +204,7 @@ def test_pixel_agent_train_step_vs_oracle():
     np.testing.assert_allclose(agent._last["next_latents"].cpu().numpy(), aux["next_latents"].numpy(), rtol=2e-3, atol=1e-4)
     for k, v in m_ref.items():
         if isinstance(v, float) and k in m:
-            np.testing.assert_allclose(m[k], v, rtol=5e-3, atol=5e-5, err_msg=k)
+            assert_metric(k, float(m[k]), v)
     assert "contrastive_loss" in m
     sd = {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}
     for n in st.p:

@@ -6,6 +6,7 @@ from aid_amd import _native as nat
 nat.lib()
 M, N, K = (int(v) for v in sys.argv[1:4])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
+if len(sys.argv) > 5: nat.lib().aid_rowln_debug(int(sys.argv[5]))      # 1-4: ablation variants, 16: register staging instead of LDS-DMA
 As = [torch.randn(M, K, device="cuda") for _ in range(2)]; W = torch.randn(N, K, device="cuda") / K ** 0.5
 b = torch.randn(N, device="cuda"); ga = torch.rand(N, device="cuda") + 0.5; be = torch.randn(N, device="cuda")
 for i in range(reps):

@@ -90,7 +90,9 @@ bool linear_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const
 int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b, int act, const float* mask, int ldmask, const float* add, int ldadd,
                 float* y, int ldy, int M, int N, int K, hipStream_t s);
 void gemm_force_kernel(int k);   // tests / benches only: process-wide kernel override, 0 = automatic selection
-int stream_hint_set(hipStream_t s, int flags);   // per-stream dispatch hints (bit 0: prefer low-LDS small-problem kernels)
+int stream_hint_set(hipStream_t s, int flags);   // per-stream dispatch hints (bit 0: prefer low-LDS small-problem kernels; bit 1: 512-wide full-row kernels
+                                                 // take 16-deep stages = 74 KB of LDS, so that another stream's 80 KB workgroups can share the CU)
+int stream_hint_flags(hipStream_t s);            // lock-free read of a stream's flags (0 when none were set)
 // y = x W^T + b with optional activation: the torch.nn.Linear forward.
 inline int linear_fwd(const float* x, int ldx, const float* W, const float* b, float* y, int ldy, int M, int N, int K,
                       int act, hipStream_t s, float* preact = nullptr, const float* residual = nullptr, int ldr = 0,

@@ -1092,6 +1092,7 @@ static inline int stream_hint_get(hipStream_t s) {
     }
     return 0;
 }
+int stream_hint_flags(hipStream_t s) { return stream_hint_get(s); }
 // TESTS / BENCHES ONLY (aid_gemm_force_kernel): a process-wide kernel override, deliberately not part of the product path and not thread-safe.
 static int g_force_kernel = 0;   // 0 auto, 1 panel32, 2 ring64, 4 tile64, 6 splitk, 9 big (PD 2), 11 big (PD 1), 14 panel128
 
@@ -1202,7 +1203,8 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     // barrier four times the MFMA work of the 64x64 tile, hand-over hidden in the MFMA stream (25 600 x 512 x 512: 108 vs 84 TFLOP/s)
     if (g_force_kernel == 0 && !g.a_kmajor && !g.b_kmajor && !g.preact && !g.dact_pre && !g.accumulate && !g.slab && g.ksplit <= 1 && g.alpha == 1.f &&
         linear_rows_ok(g.M, g.N, g.K, g.act, g.A, g.lda, g.B, g.ldb) ) {
-        prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.act + 8 * (g.K % 32 != 0); prof.variant = 23; prof.id = PROF_GEMM_TILE;
+        const bool d16 = g.K % 16 == 0 && (stream_hint_get(s) & 2);
+        prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.act + 8 * (g.K % (d16 ? 16 : 32) != 0) + 32 * d16; prof.variant = 23; prof.id = PROF_GEMM_TILE;
         return linear_rows(g.A, g.lda, g.B, g.ldb, g.bias, g.act, g.mask, g.ldc, g.residual, g.ldr, g.C, g.ldc, g.M, g.N, g.K, s);
     }
     prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor;

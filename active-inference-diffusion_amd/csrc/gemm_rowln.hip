@@ -364,8 +364,15 @@ static int launch_rowln_dbg(const RowLnArgs& g, hipStream_t s) {
     AID_LAUNCH_CHECK();
     return AID_OK;
 }
+// 512-wide kernels with 16-deep stages use 74 KB of LDS instead of 147 (and 140 VGPRs instead of 182), so a workgroup of the reverse loop's kernel
+// (gemm_mid: 80 KB, 4 waves) launched on another stream can share the CU instead of waiting for this one to retire.  Alone they are 0.2 % slower, with the
+// reverse loop running underneath the step is 0.7 ms shorter (tools/perf/README.md).  Chosen per STREAM: aid_stream_hint bit 1, which the agent sets on its
+// main stream while the side stream is in use.  aid_rowln_debug(34 / 35) forces it on / off process-wide for A/B timing.
+static int g_rowln_bkt16 = -1;
+static inline bool rowln_bkt16(hipStream_t s) { return g_rowln_bkt16 >= 0 ? g_rowln_bkt16 != 0 : (stream_hint_flags(s) & 2) != 0; }
 template <int BN, int BKT, int ACT>
 static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
+    if constexpr (BN == 512 && BKT == 32) { if (rowln_bkt16(s) && g.K % 16 == 0) return launch_rowln_t<512, 16, ACT, false>(g, s); }
     if constexpr (ACT == ACT_SILU) {
         switch (g_rowln_dbg) {
             case 1: return launch_rowln_dbg<BN, BKT, ACT, 1>(g, s);
@@ -389,6 +396,14 @@ static int launch_rows_plain(const RowLnArgs& g, int N, hipStream_t s) {
         attr_done = true;
     }
     const dim3 grid((g.M + 63) / 64, N / BN);
+    if (rowln_bkt16(s) && g.K % 16 == 0) {
+        constexpr size_t lds16 = sizeof(float) * 2 * (64 * 16 + (size_t)BN * 16);
+        static bool a16 = false;
+        if (!a16) { AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_kernel<BN, 16, ACT, false, 0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16)); a16 = true; }
+        hipLaunchKernelGGL((gemm_rowln_kernel<BN, 16, ACT, false, 0, false>), grid, dim3(512), lds16, s, g);
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
     if (g.K % BKT == 0) hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, false, 0, false>), grid, dim3(512), lds, s, g);
     else hipLaunchKernelGGL((gemm_rowln_kernel<BN, BKT, ACT, true, 0, false>), grid, dim3(512), lds, s, g);
     AID_LAUNCH_CHECK();
@@ -428,7 +443,8 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
     g.M = M; g.K = K; g.eps = 1e-5f;
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     prof.m = M; prof.n = N; prof.k = K; prof.variant = N == 1024 ? 20 : 21;
-    prof.layout = act + 8 * (K % (N == 1024 ? 16 : 32) != 0) + 16 * (N == 1024 && K % 16 == 0 && g_rowln_dma);      // act, K-tail, DMA: the instantiation
+    const bool d16 = N == 512 && K % 16 == 0 && rowln_bkt16(s);
+    prof.layout = act + 8 * (K % (N == 1024 || d16 ? 16 : 32) != 0) + 16 * (N == 1024 && K % 16 == 0 && g_rowln_dma) + 32 * d16;      // act, K-tail, DMA, 16-deep: the instantiation
     if (N == 1024) {
         if (act == ACT_SILU) return launch_rowln<1024, 16, ACT_SILU>(g, s);
         if (act == ACT_RELU) return launch_rowln<1024, 16, ACT_RELU>(g, s);
@@ -442,7 +458,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 }  // namespace aid
 
 using namespace aid;
-extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else g_rowln_dbg = mode; return AID_OK; }
+extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else if (mode == 34) g_rowln_bkt16 = 1; else if (mode == 35) g_rowln_bkt16 = 0; else if (mode == 36) g_rowln_bkt16 = -1; else g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                                  const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");

@@ -118,9 +118,9 @@ def kernel_name(variant, layout):
     # Linear -> LayerNorm -> act in one full-row-tile kernel (csrc/gemm_rowln.hip), its plain-epilogue form, and the reverse loop's
     # one-workgroup-per-CU kernel (csrc/gemm_mid.hip): the `layout` column carries the remaining template arguments
     if variant in (20, 21):
-        return f"gemm_rowln_kernel<{1024 if variant == 20 else 512}, {16 if variant == 20 else 32}, {layout & 7}, {b(layout & 8)}, 0, true, {b(layout & 16)}>"
+        return f"gemm_rowln_kernel<{1024 if variant == 20 else 512}, {16 if variant == 20 or layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, true, {b(layout & 16)}>"
     if variant == 23:
-        return f"gemm_rowln_kernel<512, 32, {layout & 7}, {b(layout & 8)}, 0, false, false>"
+        return f"gemm_rowln_kernel<512, {16 if layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, false, false>"
     if variant == 22:
         return f"gemm_mid_kernel<{layout >> 3}, {layout & 7}>"
     a, k = b((layout & 3) >> 1), b(layout & 1)
@@ -335,6 +335,8 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=device)
     from aid_amd import _native as nat
+    if os.environ.get("AID_ROWLN_DEBUG"):          # kernel A/B experiments (tools/perf/README.md); never set by the driver
+        nat.lib().aid_rowln_debug(int(os.environ["AID_ROWLN_DEBUG"]))
     agent = make_agent(device, seed=rank)
     if world > 1:
         agent.enable_data_parallel()

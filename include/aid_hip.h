@@ -89,8 +89,9 @@ int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float*
  * 10 skinny (M <= 32 rows: act() / collector batches), 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel. */
 int aid_gemm_force_kernel(int k);
 /* Dispatch hints are per STREAM (the library keeps no per-call global state): flags bit 0 = launches on `stream` prefer the 35 KB-LDS
- * small-problem GEMM variant, so that they co-reside with large GEMMs another stream is running (speed only, results identical).  Set it
- * once for a side stream; flags = 0 clears.  Launches on every other stream - e.g. a collector thread's inference stream
+ * small-problem GEMM variant, so that they co-reside with large GEMMs another stream is running (speed only, results identical); bit 1 = the
+ * 512-wide full-row kernels launched on `stream` take 16-deep stages (74 KB of LDS per workgroup instead of 147), so that another stream's
+ * 80 KB workgroups (the reverse loop's) can share their CUs.  Set it once per stream; flags = 0 clears.  Launches on every other stream - e.g. a collector thread's inference stream
  * (utils/async_collector.py:388,451) - are unaffected.  Thread-safe. */
 int aid_stream_hint(void* stream, int flags);
 

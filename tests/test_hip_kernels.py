@@ -450,3 +450,42 @@ def test_tall_linear_full_row_blocks(nat, M, N, K, act):
         nat.prof_enable(False); nat.prof_reset()
     assert [int(r["variant"]) for r in csv.DictReader(open(path))] == [23]          # the full-row kernel ran, not the 64x64 tile
     np.testing.assert_allclose(out.cpu().numpy(), ref.float().numpy(), rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("M,K", [(4100, 1024), (25600, 512), (2048, 80), (4096, 72)])
+def test_full_row_kernels_with_16_deep_stages_under_the_stream_hint(nat, M, K):
+    """aid_stream_hint bit 1: the 512-wide full-row kernels launched on that stream take 16-deep stages (74 KB of LDS, so that another stream's
+    workgroups can share the CU).  Same results as on an un-hinted stream - LayerNorm form with mask and skip, and the plain form through
+    aid_gemm_f32 - and the profile records which instantiation ran (layout bit 5); K = 72 is not a multiple of 16 and keeps the 32-deep kernel
+    with its K tail."""
+    import csv, tempfile
+    rng = np.random.default_rng(M + K)
+    N = 512
+    x = dev(rng.standard_normal((M, K))); W = dev(rng.standard_normal((N, K)) / np.sqrt(K)); b = dev(rng.standard_normal(N))
+    ga = dev(1 + 0.2 * rng.standard_normal(N)); be = dev(0.1 * rng.standard_normal(N)); add = dev(rng.standard_normal((M, N)))
+    mask = dev((rng.random((M, N)) >= 0.1) / 0.9)
+    want_ln = nat.linear_ln_act(x, W, b, ga, be, "silu", add, mask)
+    want_plain = torch.zeros(M, N, device="cuda"); plain_ok = M >= 4096
+    if plain_ok:
+        nat.gemm(x, W, want_plain, M, N, K, K, K, N, bias=b, act="relu", residual=add, ldr=N)
+    s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+    nat.stream_hint(s, 2)
+    nat.prof_enable(True); nat.prof_reset()
+    try:
+        with torch.cuda.stream(s):
+            got_ln = nat.linear_ln_act(x, W, b, ga, be, "silu", add, mask)
+            got_plain = torch.zeros(M, N, device="cuda")
+            if plain_ok:
+                nat.gemm(x, W, got_plain, M, N, K, K, K, N, bias=b, act="relu", residual=add, ldr=N)
+        torch.cuda.synchronize()
+        path = tempfile.mktemp(suffix=".csv"); nat.prof_dump(path)
+    finally:
+        nat.prof_enable(False); nat.prof_reset(); nat.stream_hint(s, 0)
+    rows = [(int(r["variant"]), int(r["layout"])) for r in csv.DictReader(open(path)) if int(r["variant"]) in (21, 23)]
+    deep16 = K % 16 == 0
+    assert rows[0][0] == 21 and bool(rows[0][1] & 32) == deep16, rows
+    if plain_ok:
+        assert rows[1][0] == 23 and bool(rows[1][1] & 32) == deep16, rows
+    # a different stage depth is a different summation order along K: equal to fp32 rounding, not bit for bit
+    np.testing.assert_allclose(got_ln.cpu().numpy(), want_ln.cpu().numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(got_plain.cpu().numpy(), want_plain.cpu().numpy(), rtol=2e-5, atol=2e-5)

@@ -64,6 +64,9 @@ def pixel():
 
 
 if __name__ == "__main__":
+    if os.environ.get("AID_ROWLN_DEBUG"):       # kernel A/B experiments (34 / 35: 16-deep 512-wide full-row kernels forced on / off)
+        from aid_amd import _native as nat
+        nat.lib().aid_rowln_debug(int(os.environ["AID_ROWLN_DEBUG"]))
     which = sys.argv[1:] or ["hopper", "pixel"]
     for w in which:
         {"hopper": hopper, "pixel": pixel}[w]()

@@ -183,7 +183,7 @@ static int launch_mid(const MidArgs& g, hipStream_t s) {
 }
 template <int ACT>
 static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
-    const int bmt = (g.M + 255) / 256;        // 8 row tiles: BM = 32 ceil(M / 256)
+    const int bmt = (g.M + 255) / 256;        // up to 1024 rows: 8 row tiles of BM = 32 ceil(M / 256); beyond: ceil(M / 128) tiles of 128 rows
     switch (bmt) {
         case 1: return launch_mid<1, ACT>(g, s);
         case 2: return launch_mid<2, ACT>(g, s);
@@ -194,7 +194,7 @@ static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
 
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
     const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
-    return al && M > 128 && M <= 1024 && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
+    return al && M > 128 && M <= MID_MAX_M && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
           
            (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU || act == ACT_RELU);
 }

@@ -48,7 +48,11 @@ int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const floa
 int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
                   const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
 
-// ---- mid-M GEMM of the reverse loop (gemm_mid.hip): 129..1024 rows, one workgroup per CU, optional split-K into raw slabs
+// ---- mid-M GEMM of the reverse loop (gemm_mid.hip): 129..1024 rows as exactly one workgroup per CU (8 row tiles), up to MID_MAX_M rows as 128-row
+// tiles (3 072 rows = the three merged belief updates of a batch-1024 step: 192 workgroups per 512-wide product); optional split-K into raw slabs
+constexpr int MID_MAX_M = 8192;
+// K slices for the 512-wide products of a DiT block at M rows: enough (column tile, slice) pairs for ~one workgroup per CU
+inline int mid_ksplit(int M) { return M <= 1024 ? 4 : (M <= 2048 ? 2 : 1); }
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s);

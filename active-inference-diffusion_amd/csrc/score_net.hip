@@ -141,12 +141,17 @@ static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const 
     const int D = n.D;
     if (!f || !f->slab || n.n_blocks < 1) return false;
     const ScoreBlockActs& b = a.blk[0];
-    return gemm_mid_ok(B, D, D, 4, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
-           gemm_mid_ok(B, D, 4 * D, 4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
+    const int KS = mid_ksplit(B);
+    return gemm_mid_ok(B, D, D, KS, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
+           gemm_mid_ok(B, D, 4 * D, KS, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
 static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
-    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = 4;
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = mid_ksplit(B), KSH = 4;
+    // the raw product of a 512-wide layer: KS slabs (KS == 1: the one "slab" is the kernel's ordinary output, no bias / activation)
+    auto product = [&](const float* x, int ldx, const float* W, int K) {
+        return gemm_mid(x, ldx, W, K, nullptr, ACT_NONE, nullptr, 0, KS == 1 ? f.slab : nullptr, D, KS == 1 ? nullptr : f.slab, B, D, K, KS, s);
+    };
     const bool lp_fused = f.wlp_t != nullptr && n.n_blocks >= 1;
     if (!lp_fused) AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     const float* pend_res = nullptr; const float* pend_bias = nullptr;      // a residual stream still waiting for its slabs
@@ -157,17 +162,17 @@ static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreAct
         if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
         else if (lp_fused) AID_TRY(adaln_lp(z, L, f.wlp_t, n.lp_b, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));      // h_in = a.h0 = z W_lp^T + b_lp
         else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
-        AID_TRY(gemm_mid(b.nx1, D, f.wov[i], D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D, D, KS, s));
+        AID_TRY(product(b.nx1, D, f.wov[i], D));
         AID_TRY(adaln_sum(b.h_in, D, f.slab, KS, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
         AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
-        AID_TRY(gemm_mid(b.u, 4 * D, w.mlp2_w, 4 * D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D, 4 * D, KS, s));
+        AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D));
         pend_res = b.h_mid; pend_bias = w.mlp2_b;                                                               // h_out = h_mid + u W2^T + b2
     }
     AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
     f.p0_slabs = false;
-    if (skip_last && gemm_mid_ok(B, D / 2, D, KS, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KS, f.slab, n.op0_b, n.op2_w)) {
+    if (skip_last && gemm_mid_ok(B, D / 2, D, KSH, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KSH, f.slab, n.op0_b, n.op2_w)) {
         // the head's first layer (N = D/2: 32 column tiles only) split four ways over K; bias, SiLU and the slab sum move into the reverse-step kernel
-        AID_TRY(gemm_mid(a.nxf, D, n.op0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D / 2, D, KS, s));
+        AID_TRY(gemm_mid(a.nxf, D, n.op0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D / 2, D, KSH, s));
         f.p0_slabs = true;
         return AID_OK;
     }
@@ -339,7 +344,7 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* mod_all = ws.f32((size_t)C * B * ldmod);
     ScoreFused fused;
     AID_TRY(score_fuse_attention(n, ws, fused, s));
-    if (B > 128 && B <= 1024) {      // mid-M pipeline (score_trunk_mid)
+    if (B > 128 && B <= MID_MAX_M) {      // mid-M pipeline (score_trunk_mid)
         fused.slab = ws.f32((size_t)4 * B * D); fused.wlp_t = ws.f32((size_t)L * D); AID_WS_OK(ws);
         AID_TRY(transpose_small(n.lp_w, fused.wlp_t, D, L, s));
     }

@@ -59,6 +59,12 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     main_shares_cus = True    # with the side stream in use, the main stream's 512-wide full-row kernels take 16-deep stages (74 KB of LDS) so that the
                               # reverse loop's 80 KB workgroups can share their CUs: -0.7 ms per cfg-2 step (alone those kernels are 0.2 % slower)
 
+    timeline = None           # perf diagnostics (tools/perf/timeline.py): a list to which train_step appends (label, event) pairs
+
+    def _mark(self, label, stream):
+        if self.timeline is not None:
+            ev = torch.cuda.Event(enable_timing=True); ev.record(stream); self.timeline.append((label, ev))
+
     def _hint_main_stream(self, main, flags: int):
         key = (main.cuda_stream, flags)
         if getattr(self, "_main_hint", None) != key:
@@ -112,6 +118,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         side = self._comm_stream() if self.overlap_streams else main
         ws = self._side_workspace() if self.overlap_streams else None
         self._hint_main_stream(main, 2 if (self.overlap_streams and self.main_shares_cus) else 0)
+        self._mark("start", main)
         if self.overlap_streams:
             side.wait_stream(main)
             for t_ in (obs, nrew, latents, next_obs):
@@ -119,6 +126,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         with torch.cuda.stream(side):
             self.score_optimizer.zero_grad()
             elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
+            self._mark("side: ELBO done", side)
             if self.overlap_streams:
                 if dp:
                     # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
@@ -131,6 +139,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
+        self._mark("main: EFE + policy step done", main)
         # 4. value (targets from a re-sampled next-latent belief) [+ the two belief updates of the next step]
         with torch.cuda.stream(side):
             if self.overlap_streams:
@@ -146,6 +155,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                                   "params": (self.score_optimizer.arena.step_count, ai.param_version), "B": B, "train": train}
             else:
                 next_latents = ai.denoise_only(next_obs, ws=ws)
+            self._mark("side: score step + reverse loop done", side)
         if self.overlap_streams:
             next_latents.record_stream(main)
             for v in elbo_info.values():
@@ -169,6 +179,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         self.dynamics_optimizer.zero_grad()
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
         self.dynamics_optimizer.step()
+        self._mark("main: value + dynamics done", main)
         self.total_steps += 1
         # one device->host read for every metric
         keys, vals = [], []

@@ -630,7 +630,7 @@ def stream_hint(stream: "torch.cuda.Stream", flags: int):
     """Per-stream dispatch hint (aid_stream_hint): bit 0 = small GEMMs launched on `stream` use the 35 KB-LDS panel variant so that they
     can share CUs with a large GEMM running on another stream; bit 1 = 512-wide full-row kernels launched on `stream` use 16-deep stages (74 KB
     of LDS) so that another stream's 80 KB workgroups can share their CUs (speed only).  State lives with the stream, not the process."""
-    check(lib().aid_stream_hint(C.c_void_p(stream.cuda_stream), int(flags)), "aid_stream_hint")
+    check(lib().aid_stream_hint(C.c_void_p(stream if isinstance(stream, int) else stream.cuda_stream), int(flags)), "aid_stream_hint")
 
 
 def gemm_force_kernel(k: int):

@@ -215,9 +215,7 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         # stream underneath those phases (in data-parallel runs the gradient all-reduces ride on that stream too).
         main = torch.cuda.current_stream()
         side = self._comm_stream() if self.overlap_streams else main
-        hint = (main.cuda_stream, 2 if (self.overlap_streams and self.main_shares_cus) else 0)
-        if getattr(self, "_main_hint", None) != hint:      # the estimator's 512-wide full-row kernels leave LDS for the side stream's workgroups (aid_stream_hint bit 1)
-            nat.stream_hint(main, hint[1]); self._main_hint = hint
+        self._hint_main_stream(main, 2 if (self.overlap_streams and self.main_shares_cus) else 0)      # aid_stream_hint bit 1, as in the state agent
         if self.overlap_streams:
             side.wait_stream(main)
         with torch.cuda.stream(side):
@@ -254,7 +252,6 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         return metrics
 
     overlap_streams = True    # False: every phase on the current stream, in order
-    main_shares_cus = True    # see DiffusionStateAgent.main_shares_cus
 
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:

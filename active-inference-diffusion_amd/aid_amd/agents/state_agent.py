@@ -56,20 +56,11 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             nat.stream_hint(self._comm, 1 if self.side_low_lds else 0)
         return self._comm
 
-    main_shares_cus = True    # with the side stream in use, the main stream's 512-wide full-row kernels take 16-deep stages (74 KB of LDS) so that the
-                              # reverse loop's 80 KB workgroups can share their CUs: -0.7 ms per cfg-2 step (alone those kernels are 0.2 % slower)
-
     timeline = None           # perf diagnostics (tools/perf/timeline.py): a list to which train_step appends (label, event) pairs
 
     def _mark(self, label, stream):
         if self.timeline is not None:
             ev = torch.cuda.Event(enable_timing=True); ev.record(stream); self.timeline.append((label, ev))
-
-    def _hint_main_stream(self, main, flags: int):
-        key = (main.cuda_stream, flags)
-        if getattr(self, "_main_hint", None) != key:
-            nat.stream_hint(main, flags)
-            self._main_hint = key
 
     def enable_data_parallel(self):
         """Call once after torch.distributed.init_process_group: replicas start from rank 0's parameters."""

@@ -1075,7 +1075,11 @@ int stream_hint_set(hipStream_t s, int flags) {
     int free_slot = -1;
     for (int i = 0; i < 64; ++i) {
         if (g_stream_hints[i].used.load(std::memory_order_acquire)) {
-            if (g_stream_hints[i].stream.load(std::memory_order_relaxed) == (void*)s) { g_stream_hints[i].flags.store(flags, std::memory_order_release); return AID_OK; }
+            if (g_stream_hints[i].stream.load(std::memory_order_relaxed) == (void*)s) {
+                g_stream_hints[i].flags.store(flags, std::memory_order_release);
+                if (flags == 0) g_stream_hints[i].used.store(0, std::memory_order_release);      // cleared: the slot is free again
+                return AID_OK;
+            }
         } else if (free_slot < 0) free_slot = i;
     }
     if (flags == 0) return AID_OK;                 // nothing recorded for this stream and nothing to record

@@ -490,3 +490,15 @@ def test_full_row_kernels_with_16_deep_stages_under_the_stream_hint(nat, M, K):
     # a different stage depth is a different summation order along K: equal to fp32 rounding, not bit for bit
     np.testing.assert_allclose(got_ln.cpu().numpy(), want_ln.cpu().numpy(), rtol=2e-5, atol=2e-5)
     np.testing.assert_allclose(got_plain.cpu().numpy(), want_plain.cpu().numpy(), rtol=2e-5, atol=2e-5)
+
+
+def test_stream_hint_slots_are_freed_when_cleared(nat):
+    """The library's per-stream hint table has 64 slots; clearing a stream's flags frees its slot, so an agent that is driven from many
+    different streams over its lifetime (each set, then cleared when it moves on) never runs out."""
+    streams = [torch.cuda.Stream() for _ in range(80)]       # more distinct handles than the table has slots
+    for s in streams:
+        nat.stream_hint(s, 2); nat.stream_hint(s, 0)           # without the free, the 65th set would be refused
+    for s in streams[:60]:                                       # and 60 live hints still fit afterwards
+        nat.stream_hint(s, 1)
+    for s in streams[:60]:
+        nat.stream_hint(s, 0)

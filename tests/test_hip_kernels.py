@@ -495,7 +495,7 @@ def test_full_row_kernels_with_16_deep_stages_under_the_stream_hint(nat, M, K):
 def test_stream_hint_slots_are_freed_when_cleared(nat):
     """The library's per-stream hint table has 64 slots; clearing a stream's flags frees its slot, so an agent that is driven from many
     different streams over its lifetime (each set, then cleared when it moves on) never runs out."""
-    streams = [torch.cuda.Stream() for _ in range(80)]       # more distinct handles than the table has slots
+    streams = [0x7000000 + 64 * i for i in range(80)]           # more distinct handles than the table has slots (the table never dereferences them)
     for s in streams:
         nat.stream_hint(s, 2); nat.stream_hint(s, 0)           # without the free, the 65th set would be refused
     for s in streams[:60]:                                       # and 60 live hints still fit afterwards

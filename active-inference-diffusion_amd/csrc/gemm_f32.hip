@@ -1083,7 +1083,7 @@ int stream_hint_set(hipStream_t s, int flags) {
         } else if (free_slot < 0) free_slot = i;
     }
     if (flags == 0) return AID_OK;                 // nothing recorded for this stream and nothing to record
-    if (free_slot < 0) return AID_E_SHAPE;
+    AID_REQUIRE(free_slot >= 0, AID_E_SHAPE, "aid_stream_hint: all 64 slots hold live hints (clear a stream's flags to free its slot)");
     g_stream_hints[free_slot].stream.store((void*)s, std::memory_order_relaxed);
     g_stream_hints[free_slot].flags.store(flags, std::memory_order_relaxed);
     g_stream_hints[free_slot].used.store(1, std::memory_order_release);

@@ -91,6 +91,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         dp = parallel.is_dp()
         main = torch.cuda.current_stream()
         pre = self._take_prefetch(B)
+        la = self._take_lookahead(accepted=pre is not None)
         if pre is not None:
             batch, both = pre
         else:
@@ -98,7 +99,10 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             both = ai.denoise_pair(batch["observations"], batch["next_observations"])
         obs, actions, rewards = batch["observations"], batch["actions"], batch["rewards"]
         next_obs, dones = batch["next_observations"], batch["dones"]
-        nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
+        if la is not None:          # this step's normalised rewards and ELBO were computed at the end of the previous step (_lookahead_elbo)
+            nrew = la["nrew"]
+        else:
+            nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
         latents = both[:B]
         # 2. score / diffusion group.  The policy phase reads no score-network parameter and no ELBO result, and the value phase needs a
         # fresh belief over next_obs from the UPDATED score network (state_agent.py:194-205).  So the whole chain
@@ -115,17 +119,22 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             for t_ in (obs, nrew, latents, next_obs):
                 t_.record_stream(side)
         with torch.cuda.stream(side):
-            self.score_optimizer.zero_grad()
-            elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
-            self._mark("side: ELBO done", side)
-            if self.overlap_streams:
-                if dp:
-                    # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
-                    # host order on one internal stream, so issued later it would queue behind the policy all-reduce (which waits for the
-                    # whole EFE phase) and the score step + reverse loop would lose their overlap with the EFE.
-                    self.score_optimizer.allreduce_grads(async_op=True)
+            if la is not None:
+                # commit what the look-ahead computed on shadow copies (enqueued behind it on the same stream); the score gradients are in the arena
+                self.reward_normalizer.state.copy_(la["rn_state"]); ai.time_importance_weights.copy_(la["tiw"]); ai._last_elbo = la["last_elbo"]
+                elbo_info = la["info"]
             else:
+                self.score_optimizer.zero_grad()
+                elbo_loss, elbo_info = ai.compute_diffusion_elbo(obs, nrew, latents, ws=ws)
+            self._mark("side: ELBO done", side)
+            if not self.overlap_streams:
                 self.score_optimizer.step()
+            elif dp and la is None:
+                # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
+                # host order on one internal stream, so issued later it would queue behind the policy all-reduce (which waits for the
+                # whole EFE phase) and the score step + reverse loop would lose their overlap with the EFE.  (A look-ahead ELBO issued its
+                # own right behind itself.)
+                self.score_optimizer.allreduce_grads(async_op=True)
         # 3. policy
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
@@ -148,7 +157,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                 next_latents = ai.denoise_only(next_obs, ws=ws)
             self._mark("side: score step + reverse loop done", side)
         if self.overlap_streams:
-            next_latents.record_stream(main)
+            next_latents.record_stream(main); nrew.record_stream(main)
             for v in elbo_info.values():
                 if torch.is_tensor(v):
                     v.record_stream(main)
@@ -171,6 +180,8 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
         self.dynamics_optimizer.step()
         self._mark("main: value + dynamics done", main)
+        if self.lookahead_elbo and self.overlap_streams and self._prefetch is not None:
+            self._lookahead_elbo(side, ws, dp, main)
         self.total_steps += 1
         # one device->host read for every metric
         keys, vals = [], []
@@ -194,6 +205,53 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     _prefetch = None
     _prefetch_backoff = 0          # train_steps to wait before trying again after an unused prefetch
     _prefetch_wait = 0
+
+    # -- look-ahead ELBO ----------------------------------------------------------------------------------------------------------
+    # With the next minibatch and its belief latents prefetched, everything the NEXT step's ELBO reads exists once this step's score update has
+    # run: the score parameters (no other update touches them in between), the minibatch, its latents, and the reward normaliser (whose next
+    # update is that minibatch's).  So the next step's ELBO forward + backward is enqueued on the side stream at the END of this step - where
+    # it runs next to the value / dynamics updates and the next step's rollout, all of which share CUs with it - instead of at the start of the
+    # next step underneath the estimator's 1024-wide kernel, which shares a CU with nothing: there its ~400 small dependent kernels queue behind
+    # 300-us workgroups (24 ms for 7.4 ms of work, tools/perf/timeline.py) and the reverse loop that follows them starts that much later.
+    # Results are those of the reference order: the draws are made in the same sequence (..., third belief, next indices, its two beliefs,
+    # its ELBO, ...), the two pieces of state the ELBO advances - reward normaliser, time-importance weights - are advanced on shadow copies and
+    # committed when the next step accepts the prefetch (same validity test), and discarded otherwise.
+    lookahead_elbo = True
+    _lookahead = None
+
+    def _lookahead_elbo(self, side, ws, dp, main):
+        ai, pre = self.active_inference, self._prefetch
+        nb, B = pre["batch"], pre["B"]
+        with torch.cuda.stream(side):
+            rew = nb["rewards"].contiguous().float()
+            rn = self.reward_normalizer.state.clone()
+            nrew = nat.reward_normalize_global(parallel.allgather_cat(rew), rew, rn) if dp else nat.reward_normalize(rew, rn)
+            tiw_live, last_live = ai.time_importance_weights, getattr(ai, "_last_elbo", None)
+            tiw = tiw_live.clone()
+            ai.time_importance_weights = tiw
+            try:
+                self.score_optimizer.zero_grad()
+                _, info = ai.compute_diffusion_elbo(nb["observations"], nrew, pre["latents"][:B], ws=ws)
+            finally:
+                ai.time_importance_weights = tiw_live
+                last, ai._last_elbo = ai._last_elbo, last_live
+            if dp:
+                self.score_optimizer.allreduce_grads(async_op=True)
+            self._mark("side: look-ahead ELBO of the next step done", side)
+        self._lookahead = {"pre": pre, "nrew": nrew, "rn_state": rn, "tiw": tiw, "info": info, "last_elbo": last}
+
+    def _take_lookahead(self, accepted: bool):
+        """The look-ahead ELBO of this step if its prefetch was accepted; otherwise it is dropped (its shadow state is never committed, its
+        gradients are overwritten by this step's own ELBO, a pending gradient mean is waited for and discarded)."""
+        la, self._lookahead = self._lookahead, None
+        if la is None:
+            return None
+        if accepted:
+            return la
+        if self.score_optimizer._pending is not None:
+            self.score_optimizer._pending.wait()
+        self.score_optimizer._pending, self.score_optimizer._reduced = None, False
+        return None
 
     def _want_prefetch(self) -> bool:
         self._prefetch = None

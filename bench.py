@@ -342,6 +342,8 @@ def main():
         agent.enable_data_parallel()
     if args.no_overlap:
         agent.overlap_streams = False
+    if os.environ.get("AID_NO_LOOKAHEAD"):          # A/B experiments only
+        agent.lookahead_elbo = False
 
     def sync():
         if world > 1:

@@ -1,18 +1,23 @@
-"""Where the two streams of a cfg-2 train_step are at which time: event marks recorded by DiffusionStateAgent (agent.timeline), ms from the step's start.
-Averaged over a few steps after warm-up."""
+"""Where the two streams of a cfg-2 train_step are at which time: event marks recorded by DiffusionStateAgent (agent.timeline), ms from the step's start,
+averaged over back-to-back steps (no synchronisation between them: the steady state bench.py times).  AID_NO_LOOKAHEAD=1: without the look-ahead ELBO."""
 import os, sys, collections
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R + "/active-inference-diffusion_amd"); sys.path.insert(0, R)
 import torch
 import bench
 agent = bench.make_agent(torch.device("cuda"))
+if os.environ.get("AID_NO_LOOKAHEAD"): agent.lookahead_elbo = False
 for _ in range(4): agent.train_step()
-acc = collections.OrderedDict(); n = 8
-for _ in range(n):
+n = 10; steps = []
+for _ in range(n + 1):
     agent.timeline = []
-    agent.train_step(); torch.cuda.synchronize()
-    t0 = agent.timeline[0][1]
-    for label, ev in agent.timeline[1:]:
-        acc[label] = acc.get(label, 0.0) + t0.elapsed_time(ev) / n
+    agent.train_step()
+    steps.append(agent.timeline)
 agent.timeline = None
+torch.cuda.synchronize()
+acc = collections.OrderedDict()
+for i in range(n):
+    t0 = steps[i][0][1]
+    for label, ev in steps[i][1:] + [("start of the next step", steps[i + 1][0][1])]:
+        acc[label] = acc.get(label, 0.0) + t0.elapsed_time(ev) / n
 for label, ms in acc.items():
     print(f"{ms:8.2f} ms  {label}")

@@ -165,6 +165,11 @@ def test_cross_step_prefetch_equals_reference_order():
     for step in range(3):
         m = agent.train_step()
         assert (agent._prefetch is not None) and (step == 0 or agent._prefetch_backoff == 0)
+        # the next step's ELBO has been enqueued on the prefetched minibatch (look-ahead) - on shadow state: what the agent shows between
+        # steps is the reference's state after `step + 1` updates, not one batch ahead
+        assert agent.lookahead_elbo and agent._lookahead is not None and agent._lookahead["pre"] is agent._prefetch
+        assert abs(agent.reward_normalizer.count - (1e-4 + (step + 1) * B)) < 1e-6
+        assert abs(float(agent._lookahead["rn_state"][2]) - (1e-4 + (step + 2) * B)) < 1e-6
         m_ref = orc.train_step(st, orc.replay_sample(store, cap, B, ns), ns, horizon=H)
         for k, v in m_ref.items():
             if k in m and isinstance(v, float):
@@ -174,11 +179,16 @@ def test_cross_step_prefetch_equals_reference_order():
         if n == "epistemic_estimator.running_mean":
             continue
         np.testing.assert_allclose(sd[n].cpu().numpy(), st.p[n].detach().numpy(), rtol=2e-3, atol=3e-6, err_msg=n)
+    np.testing.assert_allclose(agent.reward_normalizer.state.cpu().numpy(), [st.rms.mean, st.rms.var, st.rms.count], rtol=1e-6)   # fp32 rewards in, fp64 statistics
+    tiw_before = ai.time_importance_weights.clone()
     # guards
     agent.replay_buffer.add(store["observations"][0], store["actions"][0], 0.0, store["next_observations"][0], False)
     assert agent._take_prefetch(B) is None and agent._prefetch_wait == 1
-    agent.train_step()                                   # backoff: this step does not prefetch
-    assert agent._prefetch is None
+    assert agent._lookahead is not None
+    count_before = agent.reward_normalizer.count
+    agent.train_step()                                   # backoff: this step does not prefetch; the look-ahead ELBO is dropped, its shadow state never committed
+    assert agent._prefetch is None and agent._lookahead is None
+    assert abs(agent.reward_normalizer.count - (count_before + B)) < 1e-6 and not torch.equal(ai.time_importance_weights, tiw_before)
     agent.train_step(); assert agent._prefetch is not None
     ai.load_state_dict(ai.state_dict())
     assert agent._take_prefetch(B) is None

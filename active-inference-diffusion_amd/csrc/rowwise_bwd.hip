@@ -9,24 +9,37 @@ constexpr int RPB = 4;
 // whole chip instead of N/64 workgroups: stage 1 reduces 256-row slabs into a [slabs][N] partial buffer (a fixed piece of the
 // caller's workspace), stage 2 folds the slabs in order.  No atomics: bias gradients are bitwise reproducible.
 constexpr int SLAB = 256;
-__global__ void colsum_slab_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+// 1024 threads = 16 waves per 64-column block: a thread walks its rows four at a time with four independent accumulators, so 4 loads are in
+// flight per thread and a 256-row slab is 4 dependent steps instead of 64 (these kernels are pure latency at the 256 .. 2 560 rows of the
+// ELBO / BPTT backward passes: 10 - 18 us each before, ~70 launches per train_step).  Fixed order: wave partials are folded 0 .. 15.
+constexpr int CS_WAVES = 16;
+__global__ void __launch_bounds__(64 * CS_WAVES) colsum_slab_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
                                    const float* __restrict__ stats, float* __restrict__ part0, float* __restrict__ part1, int M, int N) {
     // part0[slab][c] = sum_r a[r,c] * (b ? xhat(b[r,c]) : 1) ; part1[slab][c] = sum_r a[r,c]   (part1 only with b)
-    __shared__ float r0[4][64], r1[4][64];
+    __shared__ float r0[CS_WAVES][64], r1[CS_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane, slab = blockIdx.y;
     const int rbeg = slab * SLAB, rend = min(M, rbeg + SLAB);
-    float s0 = 0.f, s1 = 0.f;
-    if (c < N) for (int r = rbeg + w; r < rend; r += 4) {
-        const float e = a[(size_t)r * lda + c];
-        if (b) { s0 += e * (b[(size_t)r * ldb + c] - stats[2 * r]) * stats[2 * r + 1]; s1 += e; }
-        else s0 += e;
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) for (int r = rbeg + w; r < rend; r += 4 * CS_WAVES) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * CS_WAVES;
+            if (rr < rend) {
+                const float e = a[(size_t)rr * lda + c];
+                if (b) { s0[u] += e * (b[(size_t)rr * ldb + c] - stats[2 * rr]) * stats[2 * rr + 1]; s1[u] += e; }
+                else s0[u] += e;
+            }
+        }
     }
-    r0[w][lane] = s0; r1[w][lane] = s1;
+    r0[w][lane] = (s0[0] + s0[1]) + (s0[2] + s0[3]); r1[w][lane] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
     __syncthreads();
     if (w == 0 && c < N) {
-        part0[(size_t)slab * N + c] = r0[0][lane] + r0[1][lane] + r0[2][lane] + r0[3][lane];
-        if (b) part1[(size_t)slab * N + c] = r1[0][lane] + r1[1][lane] + r1[2][lane] + r1[3][lane];
+        float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < CS_WAVES; ++i) { t0 += r0[i][lane]; t1 += r1[i][lane]; }
+        part0[(size_t)slab * N + c] = t0;
+        if (b) part1[(size_t)slab * N + c] = t1;
     }
 }
 __global__ void colsum_fold_kernel(const float* __restrict__ part, int slabs, float* __restrict__ out, int N, int accumulate) {
@@ -36,16 +49,21 @@ __global__ void colsum_fold_kernel(const float* __restrict__ part, int slabs, fl
     for (int i = 0; i < slabs; ++i) s += part[(size_t)i * N + c];
     out[c] = accumulate ? out[c] + s : s;
 }
-__global__ void colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int accumulate) {
-    __shared__ float red[4][64];
+__global__ void __launch_bounds__(64 * CS_WAVES) colsum_kernel(const float* __restrict__ a, int lda, float* __restrict__ out, int M, int N, int accumulate) {
+    __shared__ float red[CS_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s = 0.f;
-    if (c < N) for (int r = w; r < M; r += 4) s += a[(size_t)r * lda + c];
-    red[w][lane] = s;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) for (int r = w; r < M; r += 4 * CS_WAVES) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int rr = r + u * CS_WAVES; if (rr < M) s[u] += a[(size_t)rr * lda + c]; }
+    }
+    red[w][lane] = (s[0] + s[1]) + (s[2] + s[3]);
     __syncthreads();
     if (w == 0 && c < N) {
-        const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < CS_WAVES; ++i) v += red[i][lane];
         out[c] = accumulate ? out[c] + v : v;
     }
 }
@@ -55,14 +73,14 @@ int colsum(const float* a, int lda, float* out, int M, int N, int accumulate, hi
         const size_t mark = ws->mark();
         float* part = ws->f32((size_t)slabs * N);
         if (!ws->overflow) {
-            hipLaunchKernelGGL(colsum_slab_kernel, dim3((N + 63) / 64, slabs), dim3(256), 0, s, a, lda, (const float*)nullptr, 0,
+            hipLaunchKernelGGL(colsum_slab_kernel, dim3((N + 63) / 64, slabs), dim3(64 * CS_WAVES), 0, s, a, lda, (const float*)nullptr, 0,
                                (const float*)nullptr, part, (float*)nullptr, M, N);
             hipLaunchKernelGGL(colsum_fold_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, slabs, out, N, accumulate);
             AID_LAUNCH_CHECK(); ws->release(mark); return AID_OK;
         }
         ws->overflow = false; ws->release(mark);
     }
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, s, a, lda, out, M, N, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(64 * CS_WAVES), 0, s, a, lda, out, M, N, accumulate);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -95,30 +113,93 @@ __global__ void ln_bwd_rows_kernel(const float* __restrict__ dy, int lddy, const
         if (dx) dx[(size_t)row * lddx + c] = r * (g - sg - xh * sgx);
     }
 }
+// D = 64 NE known at compile time: every load of the row is issued up front (NE independent loads per operand instead of NE dependent
+// round trips) and x-hat / the effective gradient stay in registers between the two passes (no second read, no second act_grad).
+// Same per-lane accumulation order as the generic kernel: bit-identical results.
+template <int NE, int ACT>
+__global__ void __launch_bounds__(256) ln_bwd_rows_reg_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ x, int ldx,
+                                   const float* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mask, float* __restrict__ dx, int lddx, float* __restrict__ dyeff, int M) {
+    constexpr int D = 64 * NE;
+    const int lane = threadIdx.x & 63, row = blockIdx.x * RPB + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float mean = stats[2 * row], r = stats[2 * row + 1];
+    const float* xr = x + (size_t)row * ldx; const float* dyr = dy + (size_t)row * lddy;
+    float xh[NE], e[NE], g[NE], gm[NE], bt[NE], mk[NE];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        xh[i] = xr[c]; e[i] = dyr[c];
+        gm[i] = gamma ? gamma[c] : 1.f; bt[i] = gamma ? beta[c] : 0.f;
+        mk[i] = mask ? mask[(size_t)row * D + c] : 1.f;
+    }
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        xh[i] = (xh[i] - mean) * r;
+        if (mask) e[i] *= mk[i];
+        if (ACT != ACT_NONE) e[i] *= act_grad(gamma ? xh[i] * gm[i] + bt[i] : xh[i], ACT);
+        g[i] = gamma ? e[i] * gm[i] : e[i];
+        sg += g[i]; sgx += g[i] * xh[i];
+    }
+    sg = wave_sum(sg) / (float)D; sgx = wave_sum(sgx) / (float)D;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = lane + 64 * i;
+        if (dyeff) dyeff[(size_t)row * D + c] = e[i];
+        if (dx) dx[(size_t)row * lddx + c] = r * (g[i] - sg - xh[i] * sgx);
+    }
+}
+template <int NE>
+static void launch_ln_bwd_reg(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma, const float* beta, int act,
+                              const float* mask, float* dx, int lddx, float* dyeff, int M, hipStream_t s) {
+    const dim3 grid((M + RPB - 1) / RPB);
+    switch (act) {
+        case ACT_SILU: hipLaunchKernelGGL((ln_bwd_rows_reg_kernel<NE, ACT_SILU>), grid, dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, beta, mask, dx, lddx, dyeff, M); break;
+        case ACT_RELU: hipLaunchKernelGGL((ln_bwd_rows_reg_kernel<NE, ACT_RELU>), grid, dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, beta, mask, dx, lddx, dyeff, M); break;
+        default: hipLaunchKernelGGL((ln_bwd_rows_reg_kernel<NE, ACT_NONE>), grid, dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, beta, mask, dx, lddx, dyeff, M); break;
+    }
+}
 int ln_bwd_rows(const float* dy, int lddy, const float* x, int ldx, const float* stats, const float* gamma, const float* beta,
                 int act, const float* mask, float* dx, int lddx, float* dyeff, int M, int D, hipStream_t s) {
+    if (act == ACT_SILU || act == ACT_RELU || act == ACT_NONE) {
+        switch (D) {
+            case 256: launch_ln_bwd_reg<4>(dy, lddy, x, ldx, stats, gamma, beta, act, mask, dx, lddx, dyeff, M, s); AID_LAUNCH_CHECK(); return AID_OK;
+            case 512: launch_ln_bwd_reg<8>(dy, lddy, x, ldx, stats, gamma, beta, act, mask, dx, lddx, dyeff, M, s); AID_LAUNCH_CHECK(); return AID_OK;
+            case 1024: launch_ln_bwd_reg<16>(dy, lddy, x, ldx, stats, gamma, beta, act, mask, dx, lddx, dyeff, M, s); AID_LAUNCH_CHECK(); return AID_OK;
+            default: break;
+        }
+    }
     hipLaunchKernelGGL(ln_bwd_rows_kernel, dim3((M + RPB - 1) / RPB), dim3(256), 0, s, dy, lddy, x, ldx, stats, gamma, beta, act,
                        mask, dx, lddx, dyeff, M, D);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
-__global__ void ln_param_grad_kernel(const float* __restrict__ dyeff, const float* __restrict__ x, int ldx,
+__global__ void __launch_bounds__(64 * CS_WAVES) ln_param_grad_kernel(const float* __restrict__ dyeff, const float* __restrict__ x, int ldx,
                                      const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta,
                                      int M, int D) {
-    __shared__ float rg[4][64], rb[4][64];
+    __shared__ float rg[CS_WAVES][64], rb[CS_WAVES][64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float sg = 0.f, sb = 0.f;
-    if (c < D) for (int r = w; r < M; r += 4) {
-        const float e = dyeff[(size_t)r * D + c];
-        sg += e * (x[(size_t)r * ldx + c] - stats[2 * r]) * stats[2 * r + 1];
-        sb += e;
+    float sg[4] = {0.f, 0.f, 0.f, 0.f}, sb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < D) for (int r = w; r < M; r += 4 * CS_WAVES) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = r + u * CS_WAVES;
+            if (rr < M) {
+                const float e = dyeff[(size_t)rr * D + c];
+                sg[u] += e * (x[(size_t)rr * ldx + c] - stats[2 * rr]) * stats[2 * rr + 1];
+                sb[u] += e;
+            }
+        }
     }
-    rg[w][lane] = sg; rb[w][lane] = sb;
+    rg[w][lane] = (sg[0] + sg[1]) + (sg[2] + sg[3]); rb[w][lane] = (sb[0] + sb[1]) + (sb[2] + sb[3]);
     __syncthreads();
     if (w == 0 && c < D) {
-        dgamma[c] += rg[0][lane] + rg[1][lane] + rg[2][lane] + rg[3][lane];
-        dbeta[c] += rb[0][lane] + rb[1][lane] + rb[2][lane] + rb[3][lane];
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < CS_WAVES; ++i) { tg += rg[i][lane]; tb += rb[i][lane]; }
+        dgamma[c] += tg; dbeta[c] += tb;
     }
 }
 int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stats, float* dgamma, float* dbeta, int M, int D, hipStream_t s,
@@ -128,14 +209,14 @@ int ln_param_grad(const float* dyeff, const float* x, int ldx, const float* stat
         const size_t mark = ws->mark();
         float* p0 = ws->f32((size_t)slabs * D); float* p1 = ws->f32((size_t)slabs * D);
         if (!ws->overflow) {
-            hipLaunchKernelGGL(colsum_slab_kernel, dim3((D + 63) / 64, slabs), dim3(256), 0, s, dyeff, D, x, ldx, stats, p0, p1, M, D);
+            hipLaunchKernelGGL(colsum_slab_kernel, dim3((D + 63) / 64, slabs), dim3(64 * CS_WAVES), 0, s, dyeff, D, x, ldx, stats, p0, p1, M, D);
             hipLaunchKernelGGL(colsum_fold_kernel, dim3((D + 255) / 256), dim3(256), 0, s, p0, slabs, dgamma, D, 1);
             hipLaunchKernelGGL(colsum_fold_kernel, dim3((D + 255) / 256), dim3(256), 0, s, p1, slabs, dbeta, D, 1);
             AID_LAUNCH_CHECK(); ws->release(mark); return AID_OK;
         }
         ws->overflow = false; ws->release(mark);
     }
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(256), 0, s, dyeff, x, ldx, stats, dgamma, dbeta, M, D);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((D + 63) / 64), dim3(64 * CS_WAVES), 0, s, dyeff, x, ldx, stats, dgamma, dbeta, M, D);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 

@@ -197,6 +197,7 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         B = cfg.batch_size
         if len(self.replay_buffer) < B:
             return {}
+        ai.concurrent_belief_loops = self.overlap_streams       # one stream only when asked for one (profiling)
         batch = self.replay_buffer.sample(B)
         actions, rewards, dones = batch["actions"], batch["rewards"], batch["dones"]
         enc_obs, ctx_a = self.encode_observation(batch["observations"], keep_for_backward=True, slot="a")
@@ -255,7 +256,9 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
 
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:
-            self._comm = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its small dependent kernels get workgroup slots as the big GEMMs of the main stream retire (-1.5 % per step)
+            # the process-wide side stream (aid_amd/streams.py: a process has four hardware queues, so every agent shares the same three extra streams)
+            from ..streams import side_stream
+            self._comm = side_stream(self.device)
         return self._comm
 
 

@@ -50,7 +50,9 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
 
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:
-            self._comm = torch.cuda.Stream(device=self.device, priority=-1)   # high priority: its small dependent kernels get workgroup slots as the big GEMMs of the main stream retire (-1.5 % per step)
+            # the process-wide side stream (aid_amd/streams.py: a process has four hardware queues, so every agent shares the same three extra streams)
+            from ..streams import side_stream
+            self._comm = side_stream(self.device)
             # everything this stream launches runs underneath the EFE's 25 600-row GEMMs: its small GEMMs take the 35 KB-LDS variant so
             # that they co-reside (a property of the stream, aid_stream_hint - no process-wide dispatch state)
             nat.stream_hint(self._comm, 1 if self.side_low_lds else 0)
@@ -60,7 +62,8 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
 
     def _mark(self, label, stream):
         if self.timeline is not None:
-            ev = torch.cuda.Event(enable_timing=True); ev.record(stream); self.timeline.append((label, ev))
+            import time as _t
+            ev = torch.cuda.Event(enable_timing=True); ev.record(stream); self.timeline.append((label, ev, _t.perf_counter()))
 
     def enable_data_parallel(self):
         """Call once after torch.distributed.init_process_group: replicas start from rank 0's parameters."""
@@ -90,6 +93,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             return {}
         dp = parallel.is_dp()
         main = torch.cuda.current_stream()
+        ai.concurrent_belief_loops = self.overlap_streams and self.concurrent_belief_loops     # one stream only when asked for one (profiling)
         pre = self._take_prefetch(B)
         la = self._take_lookahead(accepted=pre is not None)
         if pre is not None:
@@ -129,11 +133,12 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             self._mark("side: ELBO done", side)
             if not self.overlap_streams:
                 self.score_optimizer.step()
-            elif dp and la is None:
+            elif dp:
                 # Issue the 109 MB gradient mean NOW, before the policy phase's collectives: a process group runs its collectives in
                 # host order on one internal stream, so issued later it would queue behind the policy all-reduce (which waits for the
-                # whole EFE phase) and the score step + reverse loop would lose their overlap with the EFE.  (A look-ahead ELBO issued its
-                # own right behind itself.)
+                # whole EFE phase) and the score step + reverse loop would lose their overlap with the EFE.  (Also for a look-ahead ELBO:
+                # issued right behind it at the end of the previous step, the collective made the host wait for the look-ahead to finish
+                # before the next step could start - one-rank RCCL run, tools/perf/dp_one_rank_time.py.)
                 self.score_optimizer.allreduce_grads(async_op=True)
         # 3. policy
         self.policy_optimizer.zero_grad()
@@ -218,6 +223,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     # committed when the next step accepts the prefetch (same validity test), and discarded otherwise.
     lookahead_elbo = True
     _lookahead = None
+    concurrent_belief_loops = True     # the belief updates of a step as separate concurrent reverse loops (DiffusionActiveInference._denoise_chains)
 
     def _lookahead_elbo(self, side, ws, dp, main):
         ai, pre = self.active_inference, self._prefetch
@@ -235,23 +241,16 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             finally:
                 ai.time_importance_weights = tiw_live
                 last, ai._last_elbo = ai._last_elbo, last_live
-            if dp:
-                self.score_optimizer.allreduce_grads(async_op=True)
             self._mark("side: look-ahead ELBO of the next step done", side)
         self._lookahead = {"pre": pre, "nrew": nrew, "rn_state": rn, "tiw": tiw, "info": info, "last_elbo": last}
 
     def _take_lookahead(self, accepted: bool):
         """The look-ahead ELBO of this step if its prefetch was accepted; otherwise it is dropped (its shadow state is never committed, its
-        gradients are overwritten by this step's own ELBO, a pending gradient mean is waited for and discarded)."""
+        gradients are overwritten by this step's own ELBO)."""
         la, self._lookahead = self._lookahead, None
         if la is None:
             return None
-        if accepted:
-            return la
-        if self.score_optimizer._pending is not None:
-            self.score_optimizer._pending.wait()
-        self.score_optimizer._pending, self.score_optimizer._reduced = None, False
-        return None
+        return la if accepted else None
 
     def _want_prefetch(self) -> bool:
         self._prefetch = None

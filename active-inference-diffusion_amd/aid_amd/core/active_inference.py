@@ -310,8 +310,9 @@ class DiffusionActiveInference(nn.Module):
             run = lambda: nat.denoise_loop(tab, self.latent_diffusion.coefs(), buf["obs"], N, buf["z"], buf["eps"], buf["mask"], train=train, ws=buf["ws"])
             run(); torch.cuda.synchronize()                       # warm-up outside capture: one-time function attributes, workspace growth
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                buf["out"] = run()
+            from ..streams import side_stream
+            with torch.cuda.graph(graph, stream=side_stream(self.device)):     # capture on the process's side stream: torch would otherwise take a fresh one
+                buf["out"] = run()                                              # (a process has four hardware queues, aid_amd/streams.py)
             g = cache[key] = (graph, buf)
         graph, buf = g
         buf["obs"].copy_(observation)
@@ -342,6 +343,10 @@ class DiffusionActiveInference(nn.Module):
         N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
         if noises is None:
             noises = [self.noise.belief(o.shape[0], self.latent_dim, self.config.hidden_dim, N, train) for o in obs_list]
+        if self.concurrent_belief_loops and len(obs_list) > 1 and all(128 < o.shape[0] <= self.CHAIN_MAX_ROWS for o in obs_list):
+            streams = self._chain_streams_for(len(obs_list))
+            if streams is not None:
+                return self._denoise_chains(obs_list, noises, ws, N, train, streams)
         noise = {}
         if noises[0] is not None:
             for k, dim in (("z_init", 0), ("step_noise", 1), ("drop_masks", 1)):
@@ -351,6 +356,55 @@ class DiffusionActiveInference(nn.Module):
         return nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), obs, N, noise.get("z_init"),
                                 noise.get("step_noise"), noise.get("drop_masks"), train=train, seed=self.noise.seed,
                                 offset=self.noise.next_offset(), ws=ws or self._ws)
+
+    # Independent belief updates of up to CHAIN_MAX_ROWS rows each run as separate reverse loops on separate streams instead of one merged loop: a
+    # 256-row layer of the loop is a 48 KB-LDS workgroup per CU, so three chains share every CU and each chain's kernel boundaries (drain, launch,
+    # ramp: ~4 us of every ~13 us kernel in a dependent chain) are covered by the other two.  3 x 256 rows: 21.1 ms against 25.4 ms merged for the
+    # 50-step loop alone, 53.4 against 57.3 ms for the cfg-2 train_step (tools/perf/README.md).  Same results: the rows of a loop never interact.
+    # The extra streams are the process-wide pair of aid_amd/streams.py (a process has four hardware queues; a fifth stream would serialise with one of
+    # the others, which for two dependent chains is a 2x cliff).
+    concurrent_belief_loops = True
+    CHAIN_MAX_ROWS = 512
+    MAX_CHAINS = 3
+
+    def _chain_streams_for(self, n: int):
+        """[calling stream, extra streams...] for n concurrent loops, or None when they cannot be had."""
+        if n > self.MAX_CHAINS:
+            return None
+        from ..streams import chain_streams
+        first = torch.cuda.current_stream()
+        extra = [st for st in chain_streams(first.device) if st.cuda_stream != first.cuda_stream]
+        if len(extra) < n - 1:
+            return None
+        if getattr(self, "_chain_ws", None) is None:
+            self._chain_ws = [nat.Workspace(self.device) for _ in range(self.MAX_CHAINS - 1)]
+            for st in extra:
+                nat.stream_hint(st, 1)          # like the agent's side stream: small GEMMs take the low-LDS variants
+        return [first] + extra[:n - 1]
+
+    def _denoise_chains(self, obs_list, noises, ws, N, train, streams) -> torch.Tensor:
+        first = streams[0]
+        wss = [ws or self._ws] + self._chain_ws[:len(streams) - 1]
+        obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
+        offs = [self.noise.next_offset() for _ in obs_list]
+        for st in streams[1:]:
+            st.wait_stream(first)
+        outs = []
+        for o, nz, st, w, off in zip(obs_list, noises, streams, wss, offs):
+            nz = nz or {}
+            with torch.cuda.stream(st):
+                if st is not first:
+                    o.record_stream(st)
+                    for v in nz.values():
+                        if torch.is_tensor(v): v.record_stream(st)
+                out = nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), o, N, nz.get("z_init"), nz.get("step_noise"),
+                                       nz.get("drop_masks"), train=train, seed=self.noise.seed, offset=off, ws=w)
+            if st is not first:
+                out.record_stream(first)
+            outs.append(out)
+        for st in streams[1:]:
+            first.wait_stream(st)
+        return torch.cat(outs, dim=0)
 
     def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
         """Two independent belief updates (state_agent.py:135-140) as one 2B-row loop.  Returns [2B, L] (rows of obs_a first)."""

@@ -16,8 +16,8 @@ agent.timeline = None
 torch.cuda.synchronize()
 acc = collections.OrderedDict()
 for i in range(n):
-    t0 = steps[i][0][1]
-    for label, ev in steps[i][1:] + [("start of the next step", steps[i + 1][0][1])]:
-        acc[label] = acc.get(label, 0.0) + t0.elapsed_time(ev) / n
-for label, ms in acc.items():
-    print(f"{ms:8.2f} ms  {label}")
+    t0, h0 = steps[i][0][1], steps[i][0][2]
+    for label, ev, ht in steps[i][1:] + [("start of the next step",) + tuple(steps[i + 1][0][1:])]:
+        a = acc.setdefault(label, [0.0, 0.0]); a[0] += t0.elapsed_time(ev) / n; a[1] += 1e3 * (ht - h0) / n
+for label, (ms, hms) in acc.items():
+    print(f"{ms:8.2f} ms on the GPU   (enqueued by the host at {hms:7.2f} ms)  {label}")

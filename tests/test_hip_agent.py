@@ -305,3 +305,37 @@ def test_optimizer_checkpoint_layout_matches_reference(golden_dir, mode):
         sd = opt.state_dict()
         assert sd["param_groups"][0]["params"] == list(range(len(ref))) and sd["state"] == {}        # nothing stepped yet
     assert agent.value_optimizer.state_dict()["param_groups"][0]["weight_decay"] == 1e-2 and agent.score_optimizer.state_dict()["param_groups"][0]["weight_decay"] == 1e-5
+
+
+def test_concurrent_belief_loops_equal_the_merged_loop():
+    """Three independent belief updates as three concurrent reverse loops (DiffusionActiveInference._denoise_chains: one stream each, the
+    process-wide chain streams of aid_amd/streams.py) against the one merged loop over the concatenated rows, on the same explicit noise:
+    the rows of a loop never interact, so the latents agree to fp32 rounding (a layer's tile height follows the row count, its K order
+    does not).  Also: the chains are skipped (merged loop) when an entry is too small or too large for them."""
+    from aid_amd import streams
+    O, A, D, N, H, B = 17, 6, 64, 4, 2, 160
+    agent = _agent(O, A, D, N, H, B, cap=256)
+    ai = agent.active_inference
+    rng = np.random.default_rng(5)
+    obs = [torch.from_numpy(rng.standard_normal((B, O)).astype(np.float32)).cuda() for _ in range(3)]
+    pn = ParityNoise(31)
+    noises = [pn.belief(B, ai.latent_dim, D, N, True) for _ in range(3)]
+    ai.concurrent_belief_loops = False
+    merged = ai.denoise_many(obs, noises)
+    ai.concurrent_belief_loops = True
+    assert ai._chain_streams_for(3) is not None and len(streams.chain_streams()) == 2
+    chains = ai.denoise_many(obs, noises)
+    torch.cuda.synchronize()
+    assert chains.shape == merged.shape == (3 * B, ai.latent_dim)
+    np.testing.assert_allclose(chains.cpu().numpy(), merged.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # from a side stream: the calling stream is chain 0, the process's two chain streams carry the others
+    side = streams.side_stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        again = ai.denoise_many(obs, noises)
+    torch.cuda.current_stream().wait_stream(side)
+    assert torch.equal(again, chains)
+    # entries outside (128, CHAIN_MAX_ROWS] rows, or more entries than chains: one merged loop
+    small = [o[:64] for o in obs]
+    assert not all(128 < o.shape[0] <= ai.CHAIN_MAX_ROWS for o in small)
+    assert ai._chain_streams_for(4) is None

@@ -364,7 +364,7 @@ class DiffusionActiveInference(nn.Module):
     # The extra streams are the process-wide pair of aid_amd/streams.py (a process has four hardware queues; a fifth stream would serialise with one of
     # the others, which for two dependent chains is a 2x cliff).
     concurrent_belief_loops = True
-    CHAIN_MAX_ROWS = 512
+    CHAIN_MAX_ROWS = 1024
     MAX_CHAINS = 3
 
     def _chain_streams_for(self, n: int):

@@ -30,6 +30,7 @@ def hopper():
     agent = aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=8192))
     rng = np.random.default_rng(0); n = 4096
     agent.replay_buffer.add_batch(rng.standard_normal((n, O)), rng.uniform(-1, 1, (n, A)), rng.standard_normal(n), rng.standard_normal((n, O)), rng.random(n) < 0.01)
+    if os.environ.get("AID_CHAIN_MAX_ROWS"): agent.active_inference.CHAIN_MAX_ROWS = int(os.environ["AID_CHAIN_MAX_ROWS"])      # A/B: chains for larger updates
     dt, m = timed_steps(agent)
     print(json.dumps({"config": "cfg3 hopper B=1024 H=5 N=50", "ms_per_step": dt * 1e3, "steps_per_s": 1 / dt, "rows_per_s": B / dt,
                       "finite": bool(all(np.isfinite(v) for v in m.values()))}))

@@ -10,10 +10,15 @@ rollout + policy BPTT, value and dynamics updates, four fused clip/AdamW/EMA ste
 parallel: every rank owns a replay shard and a 256-row minibatch, gradients are averaged with one RCCL all-reduce per
 optimiser group.  `value` = batch-256 train steps per second summed over ranks.
 
-Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the kernel family with the largest share of GPU time, measured live with
-HIP events through aid_prof_*; `roofline_second_kernel`, `roofline_gemm_family` = every GEMM launch, `roofline_hbm` = the optimiser
-kernel), `cpu_baseline`
-(the oracle's train_step timed on the host cores, rank 0, N=1 only).
+    python bench.py --gpus N                                  (N>1 without a launcher: starts its own N ranks before touching the GPU)
+
+Prints ONE JSON line (rank 0).  Extra objects: `roofline` (the kernel instantiation with the largest share of GPU time, measured live with
+HIP events through aid_prof_* in one single-stream step outside the timed region; `roofline_second_kernel`, `roofline_kernels`,
+`roofline_gemm_family` = every GEMM launch, `roofline_hbm` = the optimiser kernel), `cpu_baseline` (the oracle's train_step timed on the host
+cores, rank 0, N=1 only) and, at N=1, `other_configs` (BASELINE configs[2] / [3] at full size) and `small_batch` (act() / collector loops).
+
+Environment hooks (diagnostics and A/B measurements only; the driver sets none of them): AID_BENCH_REHEARSAL=gloo|dry (multi-rank glue on one
+GPU / on the CPU), AID_BENCH_SKIP, AID_ROWLN_DEBUG (aid_rowln_debug code), AID_NO_LOOKAHEAD, AID_HIP_LIB (another build of the library).
 """
 import argparse
 import json

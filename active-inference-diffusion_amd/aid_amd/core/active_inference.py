@@ -382,23 +382,70 @@ class DiffusionActiveInference(nn.Module):
                 nat.stream_hint(st, 1)          # like the agent's side stream: small GEMMs take the low-LDS variants
         return [first] + extra[:n - 1]
 
+    # Each chain is replayed from a hipGraph (captured once per chain slot, row count, step count and mode): a 50-step loop is ~1 700 launches, three of
+    # them ~21 ms of host time per train_step - and while the side stream is still busy with the look-ahead ELBO its queue back-pressures the host, so
+    # chains two and three used to reach the GPU ten and more milliseconds after the first (tools/perf/timeline.py).  Inputs live in persistent buffers;
+    # the randomness is drawn by Philox fills (or copied from the explicit tensors of a parity test) before the replay, so the graph holds no RNG state;
+    # weights are read in place, so optimiser steps need no re-capture.
+    graph_belief_loops = True
+
+    def _chain_graph(self, slot: int, rows: int, N: int, train: bool, stream):
+        from ..streams import chain_streams
+        tab = self.latent_score_network.table()
+        stream = chain_streams(stream.device)[0]          # captured on a chain stream (never the default stream), replayed on whichever stream runs the chain
+        key = (slot, rows, N, train, ctypes_addressof(tab))
+        cache = self.__dict__.setdefault("_chain_graphs", {})
+        g = cache.get(key)
+        if g is None:
+            if len(cache) > 12:
+                cache.clear()
+            L, D = self.latent_dim, self.config.hidden_dim
+            with torch.cuda.stream(stream):
+                buf = {"obs": torch.zeros(rows, self.latent_score_network.observation_dim, device=self.device), "z": torch.zeros(rows, L, device=self.device),
+                       "eps": torch.zeros(N, rows, L, device=self.device), "mask": torch.ones(N, rows, D, device=self.device) if train else None,
+                       "ws": nat.Workspace(self.device)}
+                run = lambda: nat.denoise_loop(tab, self.latent_diffusion.coefs(), buf["obs"], N, buf["z"], buf["eps"], buf["mask"], train=train, ws=buf["ws"])
+                run()                                                 # warm-up outside capture: one-time function attributes, workspace growth
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=stream):
+                buf["out"] = run()
+            g = cache[key] = (graph, buf)
+        return g
+
     def _denoise_chains(self, obs_list, noises, ws, N, train, streams) -> torch.Tensor:
         first = streams[0]
         wss = [ws or self._ws] + self._chain_ws[:len(streams) - 1]
         obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
         offs = [self.noise.next_offset() for _ in obs_list]
+        graphs = [self._chain_graph(i, o.shape[0], N, train, st) for i, (o, st) in enumerate(zip(obs_list, streams))] if self.graph_belief_loops else None
         for st in streams[1:]:
             st.wait_stream(first)
         outs = []
-        for o, nz, st, w, off in zip(obs_list, noises, streams, wss, offs):
+        for i, (o, nz, st, w, off) in enumerate(zip(obs_list, noises, streams, wss, offs)):
             nz = nz or {}
             with torch.cuda.stream(st):
                 if st is not first:
                     o.record_stream(st)
                     for v in nz.values():
                         if torch.is_tensor(v): v.record_stream(st)
-                out = nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), o, N, nz.get("z_init"), nz.get("step_noise"),
-                                       nz.get("drop_masks"), train=train, seed=self.noise.seed, offset=off, ws=w)
+                if graphs is not None:
+                    graph, buf = graphs[i]
+                    buf["obs"].copy_(o)
+                    for k, name, kind in (("z_init", "z", 0), ("step_noise", "eps", 0), ("drop_masks", "mask", 1)):
+                        if buf[name] is None:
+                            continue
+                        if nz.get(k) is not None:
+                            buf[name].copy_(nz[k])
+                        elif kind == 0:
+                            nat.fill_normal(buf[name], self.noise.seed, self.noise.next_offset(buf[name].numel()))
+                        else:
+                            nat.fill_dropout_mask(buf[name], 0.1, self.noise.seed, self.noise.next_offset(buf[name].numel()))
+                    graph.replay()
+                    out = buf["out"]
+                else:
+                    out = nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), o, N, nz.get("z_init"), nz.get("step_noise"),
+                                           nz.get("drop_masks"), train=train, seed=self.noise.seed, offset=off, ws=w)
             if st is not first:
                 out.record_stream(first)
             outs.append(out)

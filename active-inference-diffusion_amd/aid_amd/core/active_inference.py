@@ -418,7 +418,14 @@ class DiffusionActiveInference(nn.Module):
         wss = [ws or self._ws] + self._chain_ws[:len(streams) - 1]
         obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
         offs = [self.noise.next_offset() for _ in obs_list]
-        graphs = [self._chain_graph(i, o.shape[0], N, train, st) for i, (o, st) in enumerate(zip(obs_list, streams))] if self.graph_belief_loops else None
+        graphs = None
+        if self.graph_belief_loops:
+            try:
+                graphs = [self._chain_graph(i, o.shape[0], N, train, st) for i, (o, st) in enumerate(zip(obs_list, streams))]
+            except RuntimeError as e:          # capture refused (e.g. another capture in flight): same kernels, launched one by one
+                import warnings
+                warnings.warn(f"aid_amd: hipGraph capture of the belief-update loops failed ({e}); launching them directly from now on")
+                self.graph_belief_loops = False
         for st in streams[1:]:
             st.wait_stream(first)
         outs = []

@@ -325,6 +325,26 @@ def score_forward(table: AidScoreNet, z_t, t, obs, continuous: bool, drop_mask=N
     return out
 
 
+def gradient_penalty(table: AidScoreNet, z, t, obs, continuous: bool, drop_mask=None, ws: Workspace = None):
+    """-> (penalty device scalar, g [B,L] = d(sum score)/dz)"""
+    B = z.shape[0]
+    pen = torch.empty((), device=z.device, dtype=torch.float32)
+    g = torch.empty(B, table.L, device=z.device, dtype=torch.float32)
+    ws = ws or Workspace(z.device)
+    buf = ws.get(lib().aid_elbo_step_workspace(C.byref(table), None, B))
+    check(lib().aid_gradient_penalty(C.byref(table), B, _ptr(z), _ptr(t), T_CONTINUOUS if continuous else T_DISCRETE, _ptr(obs), _ptr(drop_mask),
+                                     _ptr(pen), _ptr(g), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_gradient_penalty")
+    return pen, g
+
+
+def mse(a, b):
+    """F.mse_loss over two [M,N] tensors -> device scalar"""
+    a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)
+    out = torch.empty((), device=a.device, dtype=torch.float32)
+    check(lib().aid_mse(_ptr(a2), a2.shape[1], _ptr(b2), b2.shape[1], a2.shape[0], a2.shape[1], _ptr(out), _stream()), "aid_mse")
+    return out
+
+
 def denoise_loop(table: AidScoreNet, coefs, obs, n_steps: int, z_init=None, step_noise=None, drop_masks=None, train=True,
                  seed=0, offset=0, keep_traj=False, ws: Workspace = None):
     B = obs.shape[0]
@@ -452,10 +472,10 @@ def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizo
     return efe, info
 
 
-def lambda_returns(rewards, next_values, dones, gamma=0.99, lam=0.95, n_steps=5):
+def lambda_returns(rewards, next_values, dones, gamma=0.99, lam=0.95, n_steps=5, exclude_immediate_rewards=False):
     out = torch.empty_like(rewards)
-    check(lib().aid_lambda_returns(_ptr(rewards), _ptr(next_values), _ptr(dones), rewards.shape[0], C.c_float(gamma), C.c_float(lam), n_steps,
-                                   _ptr(out), _stream()), "aid_lambda_returns")
+    check(lib().aid_lambda_returns_ex(_ptr(rewards), _ptr(next_values), _ptr(dones), rewards.shape[0], C.c_float(gamma), C.c_float(lam), n_steps,
+                                      int(bool(exclude_immediate_rewards)), _ptr(out), _stream()), "aid_lambda_returns")
     return out
 
 

@@ -72,6 +72,46 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         self.active_inference.arenas["score"].reset_ema()
         self.active_inference.noise.seed += 7919 * parallel.rank()   # independent device-RNG streams per rank
         self.active_inference.param_version += 1
+        self._dp_vote = {"phase": "warm", "n": 0, "t0": None, "ms": {}} if self.dp_autotune_schedule else None
+
+    # -- data parallel: which belief-loop schedule to run -----------------------------------------------------------------------------
+    # A process has four hardware queues (aid_amd/streams.py).  Main + side + two chain streams use all four; RCCL's internal stream is a
+    # fifth, and a reverse loop that ends up sharing a queue with the estimator's stream costs 2x (98-108 ms against 54 per cfg-2 step).
+    # With ONE rank on real RCCL the concurrent chains still paid (54.9 against 61.5 ms merged, tools/perf/dp_one_rank_time.py), but how
+    # many streams an N-rank communicator uses is RCCL's business.  So a data-parallel agent MEASURES: after DP_VOTE_WARM warm-up steps it
+    # times DP_VOTE_STEPS steps with the concurrent chains and as many with the merged loop (host clock around a device sync, each
+    # rank; the slowest rank's time counts: one MAX all-reduce per arm), keeps the faster schedule for the rest of the run and says so
+    # once.  Both schedules give the same results (tests/test_hip_agent.py::test_concurrent_belief_loops_equal_the_merged_loop), every rank
+    # takes the same arm at the same step (the step counter of the vote is advanced identically on all ranks, the choice is made on the
+    # all-reduced times), and nothing is re-executed.
+    dp_autotune_schedule = True
+    DP_VOTE_WARM, DP_VOTE_STEPS = 3, 3
+    dp_schedule_choice = None          # "chains" | "merged" once decided (logged by bench.py)
+
+    def _dp_schedule_vote(self) -> bool:
+        """-> run this step's belief updates as concurrent chains?"""
+        v = getattr(self, "_dp_vote", None)
+        if v is None or not self.concurrent_belief_loops or not self.overlap_streams:
+            return self.concurrent_belief_loops if self.dp_schedule_choice is None else self.dp_schedule_choice == "chains"
+        import time as _t
+        order = ("warm", "chains", "merged")
+        limit = self.DP_VOTE_WARM if v["phase"] == "warm" else self.DP_VOTE_STEPS
+        if v["n"] == limit:                                  # a phase has run its steps: close it, open the next
+            torch.cuda.synchronize(self.device)
+            now = _t.perf_counter()
+            if v["phase"] != "warm":
+                v["ms"][v["phase"]] = parallel.agree_max_float((now - v["t0"]) * 1e3 / limit, device=self.device)
+            if v["phase"] == "merged":
+                self.dp_schedule_choice = "chains" if v["ms"]["chains"] <= v["ms"]["merged"] else "merged"
+                if parallel.rank() == 0:
+                    print(f"[aid_amd] data parallel, {parallel.world()} ranks: belief loops as concurrent chains {v['ms']['chains']:.2f} ms/step, "
+                          f"merged {v['ms']['merged']:.2f} ms/step (slowest rank) -> {self.dp_schedule_choice}", flush=True)
+                self.dp_schedule_ms = dict(v["ms"])
+                self._dp_vote = None
+                return self.dp_schedule_choice == "chains"
+            v["phase"], v["n"], v["t0"] = order[order.index(v["phase"]) + 1], 0, _t.perf_counter()
+        v["n"] += 1
+        return v["phase"] != "merged"
 
     # ------------------------------------------------------------------------------------------------
     def train_step(self) -> Dict[str, float]:
@@ -93,9 +133,16 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             return {}
         dp = parallel.is_dp()
         main = torch.cuda.current_stream()
-        ai.concurrent_belief_loops = self.overlap_streams and self.concurrent_belief_loops     # one stream only when asked for one (profiling)
-        pre = self._take_prefetch(B)
+        pre = self._take_prefetch(B)           # data parallel: a collective decision (one 6-int all-reduce), see _take_prefetch
+        had_la = self._lookahead is not None
         la = self._take_lookahead(accepted=pre is not None)
+        chains = self._dp_schedule_vote() if dp else self.concurrent_belief_loops
+        ai.concurrent_belief_loops = self.overlap_streams and chains     # one stream only when asked for one (profiling)
+        if had_la and not self.overlap_streams:
+            # overlap_streams was switched off since the previous step: the look-ahead ELBO may still be running on the (real) side stream,
+            # writing the score gradients and its shadow state, while everything below - the commit of that state and the score step if it
+            # was accepted, zero_grad and this step's own ELBO if not - now runs on `main`
+            main.wait_stream(self._comm_stream())
         if pre is not None:
             batch, both = pre
         else:
@@ -185,7 +232,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
         self.dynamics_optimizer.step()
         self._mark("main: value + dynamics done", main)
-        if self.lookahead_elbo and self.overlap_streams and self._prefetch is not None:
+        if self._agreed["lookahead"] and self.overlap_streams and self._prefetch is not None:
             self._lookahead_elbo(side, ws, dp, main)
         self.total_steps += 1
         # one device->host read for every metric
@@ -252,9 +299,13 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             return None
         return la if accepted else None
 
+    # What this step does about prefetching, as agreed by all ranks (one rank: its own switches).  Written by _take_prefetch at the start of
+    # every train_step and read by everything further down that gates a collective.
+    _agreed = {"prefetch": True, "lookahead": True}
+
     def _want_prefetch(self) -> bool:
         self._prefetch = None
-        if not self.prefetch_next_batch:
+        if not self._agreed["prefetch"]:
             return False
         if self._prefetch_wait > 0:
             self._prefetch_wait -= 1
@@ -262,18 +313,31 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         return True
 
     def _take_prefetch(self, B: int):
-        """The prefetched (minibatch, latents) if they are exactly what this step would compute, else None."""
+        """The prefetched (minibatch, latents) if they are exactly what this step would compute, else None.
+
+        Data parallel: accepting or rejecting changes which collectives the step issues (an accepted look-ahead ELBO has already run its
+        all-gathers; a rejected one makes the step run them again before the score all-reduce; the look-ahead itself issues three more), so
+        the decision must not be rank-local: a rank whose replay buffer was touched between two steps would pair its all-gather with the
+        other ranks' all-reduce.  Every rank therefore contributes its local verdict AND the state of its prefetch state machine (back-off
+        counters, the two switches) to ONE element-wise MIN over ranks (`parallel.agree_min`) and all of them act on the result: accept only
+        if every rank would, wait as long as the most cautious rank, prefetch / look ahead only if every rank has it switched on.  After
+        the call the state machines are identical on all ranks, so `_want_prefetch` and the look-ahead further down need no second exchange."""
         pre, self._prefetch = self._prefetch, None
-        if pre is None:
-            return None
         ai = self.active_inference
-        ok = (pre["buffer"] == (id(self.replay_buffer), self.replay_buffer.version) and pre["B"] == B and
+        ok = (pre is not None and pre["buffer"] == (id(self.replay_buffer), self.replay_buffer.version) and pre["B"] == B and
               pre["params"] == (self.score_optimizer.arena.step_count, ai.param_version) and pre["train"] == ai.latent_score_network.training)
+        had = pre is not None
+        want_pre, want_la = bool(self.prefetch_next_batch), bool(self.lookahead_elbo and self.overlap_streams)
+        if parallel.is_dp():
+            v = parallel.agree_min([ok, -int(had), -self._prefetch_wait, -self._prefetch_backoff, want_pre, want_la], device=self.device)
+            ok, had, self._prefetch_wait, self._prefetch_backoff, want_pre, want_la = bool(v[0]), bool(-v[1]), -v[2], -v[3], bool(v[4]), bool(v[5])
+        self._agreed = {"prefetch": want_pre, "lookahead": want_la}
         if ok:
             self._prefetch_backoff = 0
             return pre["batch"], pre["latents"]
-        self._prefetch_backoff = min(64, max(1, 2 * self._prefetch_backoff))
-        self._prefetch_wait = self._prefetch_backoff
+        if had:         # a prefetch that (some rank) could not use: back off
+            self._prefetch_backoff = min(64, max(1, 2 * self._prefetch_backoff))
+            self._prefetch_wait = self._prefetch_backoff
         return None
 
     def invalidate_prefetch(self):

@@ -246,8 +246,10 @@ class DiffusionActiveInference(nn.Module):
             fd = self._fd_tab.get(self.feature_decoder)
             m = None
             if self.feature_decoder.training:
-                m = torch.empty(latent.shape[0], self.config.hidden_dim, device=self.device)
-                nat.fill_dropout_mask(m, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(m.numel()))
+                m = masks
+                if m is None:
+                    m = torch.empty(latent.shape[0], self.config.hidden_dim, device=self.device)
+                    nat.fill_dropout_mask(m, self.epistemic_dropout_rate, self.noise.seed, self.noise.next_offset(m.numel()))
             return nat.feature_decoder_forward(fd, latent, m, self._ws)
         if self.observation_decoder.training and masks is None:
             D, B = self.config.hidden_dim, latent.shape[0]
@@ -271,16 +273,25 @@ class DiffusionActiveInference(nn.Module):
         train = self.latent_score_network.training
         if noise is None:
             noise = self.noise.belief(B, L, self.config.hidden_dim, N, train) or {}
-        if self.is_pixel_observation:   # diagnostics through the feature decoder are not computed on this path
-            latent = self.denoise_only(observation, noise)
-            self.current_latent, self.latent_trajectory = latent, [latent]
+        tab, coefs = self.latent_score_network.table(), self.latent_diffusion.coefs()
+        if self.is_pixel_observation or self.store_trajectory:
+            # the loop itself (optionally keeping all N+1 iterates), then the diagnostics of :286-299 as separate small launches
+            out = nat.denoise_loop(tab, coefs, observation, N, noise.get("z_init"), noise.get("step_noise"), noise.get("drop_masks"), train=train,
+                                   seed=self.noise.seed, offset=self.noise.next_offset(), keep_traj=self.store_trajectory, ws=self._ws)
+            latent, traj = out if self.store_trajectory else (out, None)
+            if self.is_pixel_observation:      # :292-295: decode to FEATURE space, compare with the encoder features
+                pred = self.decode_observation(latent, decode_to_pixels=False, masks=noise.get("fd_mask"))
+            else:
+                pred = self.decode_observation(latent, masks=noise.get("dec_masks"))
+            self.current_latent = latent
+            self.latent_trajectory = list(traj.unbind(0)) if traj is not None else [latent]
             return {"latent": latent, "latent_mean": latent.mean(0), "latent_std": latent.std(0) if B > 1 else torch.zeros_like(latent[0]),
-                    "trajectory_length": N + 1, "reconstruction_error": torch.zeros((), device=self.device), "observation": observation,
+                    "trajectory_length": N + 1, "reconstruction_error": nat.mse(pred, observation), "observation": observation,
                     "raw_observation": raw_observation}
-        latent, stats = nat.belief_update(self.latent_score_network.table(), self.decoder_table(), self.latent_diffusion.coefs(), observation, N,
+        latent, stats = nat.belief_update(tab, self.decoder_table(), coefs, observation, N,
                                           noise.get("z_init"), noise.get("step_noise"), noise.get("drop_masks"), noise.get("dec_masks"),
                                           train=train, seed=self.noise.seed, offset=self.noise.next_offset(), ws=self._ws)
-        self.current_latent, self.latent_trajectory = latent, [latent]
+        self.current_latent, self.latent_trajectory = latent, [latent]      # store_trajectory = False: the iterates are not kept (N+1 x [B,L])
         return {"latent": latent, "latent_mean": stats[:L], "latent_std": stats[L:2 * L], "trajectory_length": N + 1,
                 "reconstruction_error": stats[2 * L], "observation": observation, "raw_observation": raw_observation}
 
@@ -300,6 +311,7 @@ class DiffusionActiveInference(nn.Module):
         g = cache.get(key)
         if g is None:
             if len(cache) > 8:
+                torch.cuda.synchronize(self.device)      # a replay of an evicted graph may still be in flight on another stream
                 cache.clear()
             buf = {"obs": torch.empty(B, self.latent_score_network.observation_dim, device=self.device), "z": torch.empty(B, L, device=self.device),
                    "eps": torch.empty(N, B, L, device=self.device), "mask": torch.empty(N, B, D, device=self.device) if train else None,
@@ -386,7 +398,10 @@ class DiffusionActiveInference(nn.Module):
     # them ~21 ms of host time per train_step - and while the side stream is still busy with the look-ahead ELBO its queue back-pressures the host, so
     # chains two and three used to reach the GPU ten and more milliseconds after the first (tools/perf/timeline.py).  Inputs live in persistent buffers;
     # the randomness is drawn by Philox fills (or copied from the explicit tensors of a parity test) before the replay, so the graph holds no RNG state;
-    # weights are read in place, so optimiser steps need no re-capture.
+    # weights are read in place, so optimiser steps need no re-capture.  With device Philox randomness the graph path and the direct path draw from
+    # different counter offsets (the graph path fills whole buffers before the replay, the direct path draws inside aid_denoise_loop): same
+    # distribution, not the same numbers - a run that falls back after a refused capture is not bit-reproducible against one that did not.
+    # With explicit noise tensors (parity tests) both paths consume exactly those tensors.
     graph_belief_loops = True
 
     def _chain_graph(self, slot: int, rows: int, N: int, train: bool, stream):
@@ -398,6 +413,9 @@ class DiffusionActiveInference(nn.Module):
         g = cache.get(key)
         if g is None:
             if len(cache) > 12:
+                # the graphs' buffers were allocated on chain stream 0 and are replayed on the side / main / chain-1 streams without
+                # record_stream: nothing may be in flight when the allocator gets them back
+                torch.cuda.synchronize(self.device)
                 cache.clear()
             L, D = self.latent_dim, self.config.hidden_dim
             with torch.cuda.stream(stream):
@@ -617,16 +635,27 @@ class DiffusionActiveInference(nn.Module):
         self._last_elbo = {"t": t, "per_sample_losses": per}
         return metrics[8], info
 
-    def _compute_gradient_penalty(self, *a, **k):
-        raise NotImplementedError("the gradient penalty (value and double backward) is part of aid_elbo_step")
+    def _compute_gradient_penalty(self, noisy_latents: torch.Tensor, t: torch.Tensor, observations: torch.Tensor, drop_mask=None) -> torch.Tensor:
+        """active_inference.py:709-729 as a value: mean_b (||d(sum score)/dz_b|| - 1)^2, a device scalar.  The training path does not call
+        this: aid_elbo_step computes the same number (its `grad_penalty` metric) AND its double backward in one pass; there is no autograd
+        graph here, so the returned scalar cannot be back-propagated.  `t` in [0, 1] takes the score network's continuous-time branch,
+        anything else the discrete one (score_networks.py:143-150, decided for the whole batch as the reference does)."""
+        f = lambda x: x.to(self.device).float().contiguous()
+        z, t, obs = f(noisy_latents), f(t).reshape(-1), f(observations)
+        cont = bool(((t >= 0) & (t <= 1)).all())
+        if drop_mask is None and self.latent_score_network.training:
+            drop_mask = torch.empty(z.shape[0], self.config.hidden_dim, device=self.device)
+            nat.fill_dropout_mask(drop_mask, 0.1, self.noise.seed, self.noise.next_offset(drop_mask.numel()))
+        pen, _ = nat.gradient_penalty(self.latent_score_network.table(), z, t, obs, cont, drop_mask if self.latent_score_network.training else None,
+                                      ws=self._ws)
+        return pen
 
     # ------------------------------------------------------------------------------------------ A11
     def compute_lambda_returns(self, rewards, values, next_values, dones, lambda_: float = 0.95, n_steps: int = 5,
                                exclude_immediate_rewards: bool = False) -> torch.Tensor:
-        if exclude_immediate_rewards:
-            raise NotImplementedError("exclude_immediate_rewards=True is never used by the reference (state_agent.py:198-205)")
         f = lambda x: x.to(self.device).float().contiguous()
-        return nat.lambda_returns(f(rewards), f(next_values), f(dones), self.config.discount_factor, lambda_, n_steps)
+        return nat.lambda_returns(f(rewards), f(next_values), f(dones), self.config.discount_factor, lambda_, n_steps,
+                                  exclude_immediate_rewards=exclude_immediate_rewards)
 
     # ------------------------------------------------------------------------------------------ act
     def act(self, observation: torch.Tensor, deterministic: bool = False, raw_observation: Optional[torch.Tensor] = None):

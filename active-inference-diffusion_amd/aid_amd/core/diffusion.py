@@ -72,10 +72,10 @@ class LatentDiffusionProcess(nn.Module):
                                    deterministic: bool = False, noise: Optional[dict] = None, seed: int = 0, offset: int = 0,
                                    keep_trajectory: bool = True) -> List[torch.Tensor]:
         """diffusion.py:176-206.  Returns the list of N+1 iterates (or [z_final] when keep_trajectory=False)."""
-        if deterministic:
-            raise NotImplementedError("deterministic=True is never used by the reference (active_inference.py:278)")
-        noise = noise or {}
+        noise = dict(noise or {})
         N = self.config.num_diffusion_steps
+        if deterministic:   # p_sample returns the posterior mean at every step (diffusion.py:232-233): a zero step-noise tensor, same kernel
+            noise["step_noise"] = torch.zeros(N, batch_size, self.latent_dim, device=observation.device)
         out = nat.denoise_loop(score_network.table(), self.coefs(), observation.contiguous().float(), N, noise.get("z_init"),
                                noise.get("step_noise"), noise.get("drop_masks"), train=score_network.training, seed=seed, offset=offset,
                                keep_traj=keep_trajectory, ws=self.workspace())

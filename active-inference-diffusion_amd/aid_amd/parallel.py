@@ -45,6 +45,30 @@ def allreduce_mean_(flat: torch.Tensor, async_op: bool = False):
     return h if async_op else None
 
 
+def agree_min(values, device=None) -> List[int]:
+    """Element-wise MIN over ranks of a short list of host integers (one tiny all-reduce).  This is how rank-local DECISIONS that gate
+    collectives are made collective: every rank contributes what it would do alone and all of them act on the minimum, so the sequence of
+    collectives a step issues can never differ between ranks (a MAX is the MIN of the negated value).  RCCL needs a device tensor
+    (`device`); gloo takes a host tensor.  Without a process group the values come back unchanged."""
+    vals = [int(v) for v in values]
+    if not is_dp():
+        return vals
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor(vals, dtype=torch.int64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return [int(v) for v in t.tolist()]
+
+
+def agree_max_float(value: float, device=None) -> float:
+    """MAX over ranks of one host float (step-time votes of the start-up schedule check)."""
+    if not is_dp():
+        return float(value)
+    on_gpu = dist.get_backend() == "nccl"
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device if on_gpu else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def allgather_cat(x: torch.Tensor) -> torch.Tensor:
     """Concatenate a same-shaped tensor from every rank along dim 0, rank-major."""
     if not is_dp():

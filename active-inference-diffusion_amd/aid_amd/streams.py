@@ -5,8 +5,11 @@ two streams on one queue execute in submission order.  For long dependent kernel
 stream shares the queue of the stream running the estimator waits behind every one of its kernels (measured: 98 - 108 ms per cfg-2 train_step
 instead of 54, depending only on how many streams had been used before; tools/perf/README.md).  So everything in aid_amd that wants a stream
 besides the caller's takes it from here: ONE side stream and TWO chain streams per device for the whole process, created once, handed to every
-agent - with the caller's stream that is exactly four.  (A process that uses further streams of its own, or RCCL's internal stream in
-data-parallel runs, is over the limit; the agents then keep their belief updates in one merged loop: `concurrent_belief_loops`.)"""
+agent - with the caller's stream that is exactly four.  A process that uses further streams of its own is over the limit and should set
+`agent.concurrent_belief_loops = False` (belief updates as one merged loop: side + main only).  RCCL's internal stream in data-parallel runs is
+such a fifth stream: measured with one rank on real RCCL the chains still paid (54.9 against 61.5 ms merged), but an N-rank communicator may use
+more, so a data-parallel state agent does not assume either way - it times both schedules during its first steps and keeps the faster one
+(`DiffusionStateAgent._dp_schedule_vote`)."""
 from __future__ import annotations
 
 from typing import Dict, List

@@ -382,6 +382,34 @@ size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec,
     return n + (1 << 16);
 }
 
+int aid_mse(const float* a, int lda, const float* b, int ldb, int M, int N, float* out, void* stream) {
+    AID_REQUIRE(a && b && out, AID_E_NULL, "aid_mse: null argument");
+    AID_REQUIRE(M > 0 && N > 0 && lda >= N && ldb >= N, AID_E_SHAPE, "aid_mse: M=%d N=%d lda=%d ldb=%d", M, N, lda, ldb);
+    return mse_scalar(a, lda, b, ldb, M, N, out, (hipStream_t)stream);
+}
+
+int aid_gradient_penalty(const AidScoreNet* net, int B, const float* z, const float* t, int t_mode, const float* obs, const float* drop_mask,
+                         float* penalty_out, float* grad_out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_TRY(score_validate(net));
+    AID_REQUIRE(z && t && obs && penalty_out, AID_E_NULL, "aid_gradient_penalty: null argument");
+    AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_gradient_penalty: B=%d", B);
+    AID_REQUIRE(t_mode == AID_T_CONTINUOUS || t_mode == AID_T_DISCRETE, AID_E_SHAPE, "aid_gradient_penalty: t_mode=%d", t_mode);
+    hipStream_t s = (hipStream_t)stream;
+    const AidScoreNet& n = *net;
+    const int D = n.D, L = n.L;
+    Workspace ws(wsp, ws_bytes);
+    float* gvec = grad_out ? grad_out : ws.f32((size_t)B * L);
+    float* wvec = ws.f32((size_t)B * L);
+    ScoreActs ag;
+    AID_TRY(score_acts_alloc(n, B, true, ws, ag)); AID_WS_OK(ws);
+    AID_TRY(score_time_embed(n, B, t, t_mode, ag, s));
+    AID_TRY(score_obs_stage0(n, B, obs, ag, s));
+    AID_TRY(score_cond(n, B, drop_mask, ag.temb, D, ag, s));
+    AID_TRY(score_trunk(n, B, z, ag, true, s));
+    AID_TRY(score_reverse(n, nullptr, B, ag, nullptr, z, nullptr, nullptr, t, t_mode, 0.f, gvec, nullptr, ws, s));   // g = d(sum s)/dz
+    return gp_weights(gvec, wvec, penalty_out, B, L, s);
+}
+
 int aid_sample_time(const float* time_importance, int first_call, int B, uint64_t seed, uint64_t offset, float* t_out, void* wsp,
                     size_t ws_bytes, void* stream) {
     AID_REQUIRE(time_importance && t_out, AID_E_NULL, "aid_sample_time: null argument");

@@ -8,7 +8,7 @@ namespace aid {
 // One thread per minibatch position; float32 accumulation order mirrors the reference's tensor arithmetic
 // (python-float scalars are rounded to float32 when they meet a tensor).  O(B * n^2), n <= 5.
 __global__ void lambda_returns_kernel(const float* __restrict__ r, const float* __restrict__ nv, const float* __restrict__ done,
-                                      int B, float gamma, double lam, int n_steps, float* __restrict__ out) {
+                                      int B, float gamma, double lam, int n_steps, int excl, float* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= B) return;
     float rets[16];
@@ -17,7 +17,7 @@ __global__ void lambda_returns_kernel(const float* __restrict__ r, const float* 
     for (int n = 1; n < nmax && cnt < 16; ++n) {
         float ret = 0.f, disc = 1.0f;
         for (int k = 0; k < n; ++k) {
-            ret = ret + disc * r[idx + k];
+            if (!(excl && k == 0)) ret = ret + disc * r[idx + k];       // exclude_immediate_rewards (:674-675)
             const float nd = done[idx + k] != 0.f ? 0.f : gamma;
             disc = disc * nd;
         }
@@ -31,7 +31,8 @@ __global__ void lambda_returns_kernel(const float* __restrict__ r, const float* 
         wr = wr + (float)lw * rets[cnt - 1]; ls += lw;
         out[idx] = wr / (float)(ls + 1e-8);
     } else {
-        out[idx] = r[idx] + (done[idx] != 0.f ? 0.f : gamma) * nv[idx];
+        const float boot = (done[idx] != 0.f ? 0.f : gamma) * nv[idx];
+        out[idx] = excl ? boot : r[idx] + boot;
     }
 }
 
@@ -317,13 +318,18 @@ using namespace aid;
 
 extern "C" {
 
-int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam, int n_steps,
-                       float* out, void* stream) {
+int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+                          int n_steps, int exclude_immediate_rewards, float* out, void* stream) {
     AID_REQUIRE(rewards && next_values && dones && out, AID_E_NULL, "aid_lambda_returns: null tensor");
     AID_REQUIRE(B > 0 && n_steps >= 1 && n_steps <= 16, AID_E_SHAPE, "aid_lambda_returns: B=%d n_steps=%d", B, n_steps);
     hipLaunchKernelGGL(lambda_returns_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards, next_values, dones, B, gamma,
-                       (double)lam, n_steps, out);
+                       (double)lam, n_steps, exclude_immediate_rewards ? 1 : 0, out);
     AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+                       int n_steps, float* out, void* stream) {
+    return aid_lambda_returns_ex(rewards, next_values, dones, B, gamma, lam, n_steps, 0, out, stream);
 }
 
 size_t aid_small_net_workspace(int B, int D) { return sizeof(float) * (size_t)B * (64 * (size_t)D + 1024) + (1 << 16); }

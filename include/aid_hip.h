@@ -265,6 +265,18 @@ int aid_time_importance_update(float* time_importance, const float* t, const flo
 int aid_sample_time(const float* time_importance, int first_call, int B, uint64_t seed, uint64_t offset, float* t_out, void* ws,
                     size_t ws_bytes, void* stream);
 size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec, int B);
+
+/* DiffusionActiveInference._compute_gradient_penalty (aid/core/active_inference.py:709-729) as a stand-alone value:
+ * g = d(sum score(z, t, obs))/dz, penalty = mean_b (||g_b||_2 - 1)^2 -> penalty_out (device scalar); grad_out (optional) [B,L] receives g.
+ * The same forward + input-gradient pass aid_elbo_step runs for its metric 5 (which also back-propagates the penalty: that part
+ * stays inside aid_elbo_step).  drop_mask: [B,D] scaled keep mask of the obs encoder's Dropout(0.1) or NULL (eval).
+ * Workspace: aid_elbo_step_workspace(net, NULL, B). */
+int aid_gradient_penalty(const AidScoreNet* net, int B, const float* z, const float* t, int t_mode, const float* obs, const float* drop_mask,
+                         float* penalty_out, float* grad_out, void* ws, size_t ws_bytes, void* stream);
+
+/* F.mse_loss(a, b) over [M,N] row-major operands with leading dimensions lda / ldb -> out (device scalar): the reconstruction
+ * diagnostic of update_belief_via_diffusion's pixel branch (aid/core/active_inference.py:292-299). */
+int aid_mse(const float* a, int lda, const float* b, int ldb, int M, int N, float* out, void* stream);
 int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDiffusionParams* dp,
                   const AidDiffusionParams* dgrads, const AidDecoderNet* dec, const AidRewardNet* rew, int B,
                   const float* obs, const float* rewards, const float* latents, const AidElboNoise* noise,
@@ -379,6 +391,9 @@ int aid_random_shift(const float* x, const int32_t* shift_h, const int32_t* shif
  * gradients, MSE dynamics loss with gradients.  dones: [B] floats (0/1).  loss_out: device scalar. */
 int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
                        int n_steps, float* out, void* stream);
+/* exclude_immediate_rewards != 0: the k = 0 reward of every n-step return is left out (active_inference.py:649-653, 674-675, 701-702) */
+int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+                          int n_steps, int exclude_immediate_rewards, float* out, void* stream);
 size_t aid_value_step_workspace(const AidValueNet* val, int B);
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
                    const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,

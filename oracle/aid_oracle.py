@@ -201,7 +201,7 @@ def p_sample(tab: Dict[str, Tensor], z_t: Tensor, t: int, score: Tensor, eps: Op
 
 
 def generate_latent_trajectory(p: Params, tab: Dict[str, Tensor], obs: Tensor, noise,
-                               train: bool = True, keep: bool = False):
+                               train: bool = True, keep: bool = False, deterministic: bool = False):
     """Draw order: randn[B,L]; then per step t=N-1..0: score dropout mask [B,D] (train), randn[B,L]
     if t>0.  Integer t is fed to the score net as float (t in {0,1} takes the continuous branch,
     D8)."""
@@ -212,7 +212,7 @@ def generate_latent_trajectory(p: Params, tab: Dict[str, Tensor], obs: Tensor, n
     for t in reversed(range(N)):
         tb = torch.full((B,), float(t))
         s = score_forward(p, z, tb, obs, noise, train)
-        eps = _t(noise.randn(B, L)) if t > 0 else None
+        eps = _t(noise.randn(B, L)) if (t > 0 and not deterministic) else None      # diffusion.py:232: deterministic => posterior mean, no draw
         z = p_sample(tab, z, t, s, eps)
         if keep:
             traj.append(z)
@@ -301,16 +301,23 @@ def predict_next_latent(p: Params, z: Tensor, a: Tensor) -> Tuple[Tensor, Tensor
     return mean, torch.full_like(mean, float(np.log(0.1)))
 
 
-def update_belief_via_diffusion(p: Params, tab, obs: Tensor, noise, train: bool = True) -> Dict[str, Tensor]:
-    """active_inference.py:256-312.  Draw order: trajectory draws, then 3 decoder masks."""
-    z = generate_latent_trajectory(p, tab, obs, noise, train)
+def update_belief_via_diffusion(p: Params, tab, obs: Tensor, noise, train: bool = True, pixel: bool = False, keep: bool = False) -> Dict[str, Tensor]:
+    """active_inference.py:256-312.  Draw order: trajectory draws, then 3 decoder masks (state mode) or the feature decoder's one
+    mask (pixel mode, :292-295: the belief is decoded to FEATURE space and compared with the encoder features it was conditioned on)."""
+    z = generate_latent_trajectory(p, tab, obs, noise, train, keep=keep)
+    traj = None
+    if keep:
+        z, traj = z
     B = obs.shape[0]
     if B == 1:
         mean, std = z.squeeze(0), torch.zeros_like(z.squeeze(0))
     else:
         mean, std = z.mean(0), z.std(0)
-    rec = F.mse_loss(decode_observation(p, z, noise, train), obs)
-    return {"latent": z, "latent_mean": mean, "latent_std": std, "reconstruction_error": rec}
+    rec = F.mse_loss(feature_decoder(p, z, noise, train) if pixel else decode_observation(p, z, noise, train), obs)
+    out = {"latent": z, "latent_mean": mean, "latent_std": std, "reconstruction_error": rec}
+    if keep:
+        out["trajectory"] = traj
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -614,7 +621,7 @@ def expected_free_energy(p: Params, latent: Tensor, noise, running_mean: float, 
 # A11  lambda-returns                                   aid/core/active_inference.py:638-707
 # ---------------------------------------------------------------------------------------------
 def lambda_returns(rewards: np.ndarray, next_values: np.ndarray, dones: np.ndarray,
-                   gamma: float = 0.99, lam: float = 0.95, n_steps: int = 5) -> np.ndarray:
+                   gamma: float = 0.99, lam: float = 0.95, n_steps: int = 5, exclude_immediate_rewards: bool = False) -> np.ndarray:
     """Minibatch order is treated as time.  fp32 tensor arithmetic in the reference: each partial
     sum is a float32 tensor op, python-float scalars (discount, weights) are fp64 -> we mirror
     that with np.float32 accumulators and python-float scalars."""
@@ -632,7 +639,8 @@ def lambda_returns(rewards: np.ndarray, next_values: np.ndarray, dones: np.ndarr
             for k in range(n):
                 if idx + k < B:
                     dv = disc if disc_t is None else disc_t
-                    ret = np.float32(ret + np.float32(np.float32(dv) * r[idx + k]))
+                    if not (exclude_immediate_rewards and k == 0):      # active_inference.py:674-675
+                        ret = np.float32(ret + np.float32(np.float32(dv) * r[idx + k]))
                     nd = np.float32(np.float32(gamma * (1.0 - float(d[idx + k]))))
                     disc_t = np.float32(np.float32(dv) * nd)
             if idx + n < B and not d[idx + n - 1]:
@@ -649,6 +657,8 @@ def lambda_returns(rewards: np.ndarray, next_values: np.ndarray, dones: np.ndarr
             wr = np.float32(wr + np.float32(np.float32(lw) * rets[-1]))
             ls += lw
             out[idx] = np.float32(wr / np.float32(ls + 1e-8))
+        elif exclude_immediate_rewards:                                      # :701-702
+            out[idx] = np.float32(np.float32(gamma * (1.0 - float(d[idx]))) * nv[idx])
         else:
             out[idx] = np.float32(r[idx] + np.float32(np.float32(gamma * (1.0 - float(d[idx]))) * nv[idx]))
     return out

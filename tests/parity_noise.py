@@ -44,13 +44,14 @@ class ParityNoise(NoiseSource):
                 masks[t] = ns.dropout_mask((B, D), 0.1)
             if t > 0:
                 eps[t] = ns.randn(B, L)
+        fd = None
         if self.pixel:
             dec = None
             if train:
-                ns.dropout_mask((B, D), 0.2)            # feature-decoder mask of the (skipped) reconstruction diagnostic
+                fd = dev(ns.dropout_mask((B, D), 0.2))  # feature-decoder mask of the reconstruction diagnostic (active_inference.py:292-295)
         else:
             dec = [dev(ns.dropout_mask((B, w), 0.2)) for w in (2 * D, 2 * D, D)] if train else None   # decode_observation masks
-        return {"z_init": dev(z0), "step_noise": dev(eps), "drop_masks": dev(masks) if train else None, "dec_masks": dec}
+        return {"z_init": dev(z0), "step_noise": dev(eps), "drop_masks": dev(masks) if train else None, "dec_masks": dec, "fd_mask": fd}
 
     def elbo(self, B, L, D, first_call, time_importance):
         ns = self.ns

@@ -17,6 +17,73 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _replicas_identical(agent, rank):
+    torch.cuda.synchronize()
+    for name, a in agent.active_inference.arenas.items():
+        mine = a.flat.detach().clone()
+        other = mine.clone(); dist.broadcast(other, src=0)
+        assert torch.equal(mine, other), f"arena {name} diverged on rank {rank}"
+    for x in (agent.reward_normalizer.state, agent.active_inference.time_importance_weights):
+        mine = x.clone(); other = mine.clone(); dist.broadcast(other, src=0)
+        assert torch.equal(mine, other)
+
+
+def _scenario_worker(rank, world, port, q, scenario):
+    """`diverge`: the cross-step prefetch + look-ahead ELBO under data parallelism when ONE rank's replay buffer changes between two steps
+    (an asynchronous collector adding a transition): the accept decision is collective, so both ranks drop the prefetch and the look-ahead
+    together, back off together and pick the prefetch up again together - no hang, replicas bit-identical.
+    `chains`: more than 128 rows per rank, so the belief updates run as hipGraph-replayed concurrent chains under DP, through the
+    start-up vote between the chain and the merged schedule (one step each here); every rank lands on the same choice."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    try:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import aid_amd
+        from aid_amd import parallel
+
+        class Box:
+            def __init__(self, shape): self.shape = shape
+        torch.manual_seed(200 + rank)
+        rng = np.random.default_rng(17 + rank)
+        O, A = 17, 6
+        B, H, cap = (8, 2, 64) if scenario == "diverge" else (136, 1, 512)
+        cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=H, latent_dim=O, hidden_dim=64)
+        cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=4)
+        class Env: observation_space, action_space = Box((O,)), Box((A,))
+        agent = aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=cap))
+        agent.replay_buffer.add_batch(rng.standard_normal((cap // 2, O)).astype(np.float32), rng.uniform(-1, 1, (cap // 2, A)).astype(np.float32),
+                                      rng.standard_normal(cap // 2).astype(np.float32), rng.standard_normal((cap // 2, O)).astype(np.float32),
+                                      np.zeros(cap // 2, bool))
+        agent.DP_VOTE_WARM, agent.DP_VOTE_STEPS = 1, 1
+        agent.enable_data_parallel()
+        assert agent.prefetch_next_batch and agent.lookahead_elbo
+        if scenario == "diverge":
+            for step in range(6):
+                if step == 3 and rank == 1:
+                    agent.replay_buffer.add(rng.standard_normal(O), rng.uniform(-1, 1, A), 0.5, rng.standard_normal(O), False)
+                m = agent.train_step()
+                assert all(np.isfinite(v) for v in m.values()), (step, m)
+                if step == 3:      # rank 0 alone would have accepted; both dropped it and sit out one step
+                    assert agent._prefetch is None and agent._lookahead is None and agent._prefetch_backoff == 1, (rank, step)
+                else:
+                    assert agent._prefetch is not None and agent._lookahead is not None, (rank, step)
+        else:
+            for step in range(5):
+                m = agent.train_step()
+                assert all(np.isfinite(v) for v in m.values()), (step, m)
+            assert agent.dp_schedule_choice in ("chains", "merged") and agent._dp_vote is None
+            assert len(agent.active_inference.__dict__.get("_chain_graphs", {})) >= 3         # the chain arm ran from captured graphs
+            choice = parallel.agree_min([agent.dp_schedule_choice == "chains"]) + parallel.agree_min([-(agent.dp_schedule_choice == "chains")])
+            assert choice[0] == -choice[1]
+        _replicas_identical(agent, rank)
+        q.put((rank, "ok"))
+    except Exception:
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q, pixel):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     try:
@@ -82,5 +149,22 @@ def test_agent_data_parallel_two_ranks(pixel):
     for p in procs: p.start()
     res = [q.get(timeout=600) for _ in procs]
     for p in procs: p.join(60)
+    for r, msg in res:
+        assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+@pytest.mark.parametrize("scenario", ["diverge", "chains"])
+def test_dp_prefetch_decisions_are_collective(scenario):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue(); port = _free_port()
+    procs = [ctx.Process(target=_scenario_worker, args=(r, 2, port, q, scenario)) for r in range(2)]
+    for p in procs: p.start()
+    try:
+        res = [q.get(timeout=300) for _ in procs]          # a mismatched collective shows up here as a timeout, not a hang of the suite
+    finally:
+        for p in procs:
+            p.join(30)
+            if p.is_alive():
+                p.kill()
     for r, msg in res:
         assert msg == "ok", f"rank {r}:\n{msg}"

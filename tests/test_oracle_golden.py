@@ -232,3 +232,30 @@ def test_fokker_planck_full_covariance_golden(golden_dir):
             np.testing.assert_allclose(prec, g[f"{name}_prec{t}"], rtol=1e-6, atol=1e-9 * np.abs(prec).max())
             np.testing.assert_allclose(orc.gaussian_entropy_full(cov), float(g[f"{name}_entropy{t}"]), rtol=1e-9)
             np.testing.assert_allclose(cond, float(g[f"{name}_cond{t}"]), rtol=1e-6)
+
+
+def test_round3_surface_goldens(golden_dir):
+    """The functions pinned in round 3 (oracle/gen_golden_r3.py ran the reference): lambda-returns without the immediate reward (bit-exact),
+    the stand-alone gradient penalty, the deterministic reverse trajectory, pixel-mode update_belief_via_diffusion."""
+    from oracle.weights import draw_feature_decoder
+    g = np.load(os.path.join(golden_dir, "r3_surface.npz"))
+    O, A, D, N, B = (int(x) for x in g["dims"])
+    p = draw_params(param_specs(O, A, O, D, N), int(g["weights_key"]), orc.schedule_tables(N))
+    for tag in "abc":
+        r, nv, d, ns_ = g[f"lam_{tag}_r"], g[f"lam_{tag}_nv"], g[f"lam_{tag}_d"], int(g[f"lam_{tag}_n_steps"])
+        np.testing.assert_array_equal(orc.lambda_returns(r, nv, d, float(g["gamma"]), 0.95, ns_, exclude_immediate_rewards=True), g[f"lam_{tag}_excl"])
+        np.testing.assert_array_equal(orc.lambda_returns(r, nv, d, float(g["gamma"]), 0.95, ns_), g[f"lam_{tag}_incl"])
+        assert not np.array_equal(g[f"lam_{tag}_excl"], g[f"lam_{tag}_incl"])
+    for tag, train, tt in (("train_cont", True, T(g["t_cont"])), ("eval_cont", False, T(g["t_cont"])), ("eval_disc", False, torch.full((B,), 3.0))):
+        v = orc.gradient_penalty(p, T(g["z"]), tt, T(g["obs"]), NoiseStream(int(g["gp_key"])), train)
+        np.testing.assert_allclose(float(v), float(g[f"gp_{tag}"]), rtol=1e-5)
+    _, tr = orc.generate_latent_trajectory(p, orc.schedule_tables(N), T(g["obs"]), NoiseStream(int(g["det_key"])), False, keep=True, deterministic=True)
+    np.testing.assert_allclose(np.stack([x.numpy() for x in tr]), g["det_traj"], rtol=1e-5, atol=1e-6)
+    L, A2, Dp, Np, Bp = (int(x) for x in g["pix_dims"])
+    pp = draw_params(param_specs(L, A2, L, Dp, Np), int(g["pix_weights_key"]), orc.schedule_tables(Np))
+    pp.update(draw_feature_decoder(L, Dp, int(g["pix_fdec_key"])))
+    for tag, train in (("train", True), ("eval", False)):
+        out = orc.update_belief_via_diffusion(pp, orc.schedule_tables(Np), T(g["pix_feats"]), NoiseStream(int(g[f"pix_{tag}_key"])), train, pixel=True, keep=True)
+        np.testing.assert_allclose(out["latent"].numpy(), g[f"pix_{tag}_latent"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(float(out["reconstruction_error"]), float(g[f"pix_{tag}_rec"]), rtol=1e-5)
+        np.testing.assert_allclose(np.stack([x.numpy() for x in out["trajectory"]]), g[f"pix_{tag}_traj"], rtol=1e-4, atol=1e-6)

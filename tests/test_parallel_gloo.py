@@ -14,6 +14,48 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _prefetch_state_machine(rank):
+    """DiffusionStateAgent's accept / back-off logic for the cross-step prefetch is collective under data parallelism (every collective of
+    the look-ahead ELBO hangs off it): driven here on a bare instance (no GPU: only the host-side state machine) through the sequence
+      step 0: both ranks hold a valid prefetch                    -> both accept
+      step 1: rank 1's replay buffer changed in between            -> BOTH reject and back off one step
+      step 2: back-off                                             -> neither prefetches
+      step 3: rank 0 has prefetching switched off                  -> neither prefetches nor looks ahead
+    and after every step the two state machines must be identical."""
+    from types import SimpleNamespace as NS
+    from aid_amd.agents.state_agent import DiffusionStateAgent
+    ag = object.__new__(DiffusionStateAgent)
+    ag.device = "cpu"
+    ag.replay_buffer = NS(version=3)
+    ag.score_optimizer = NS(arena=NS(step_count=7))
+    ag.active_inference = NS(param_version=1, latent_score_network=NS(training=True))
+    mk = lambda: {"batch": "b", "latents": "l", "buffer": (id(ag.replay_buffer), ag.replay_buffer.version), "params": (7, 1), "B": 8, "train": True}
+    state = lambda: (ag._prefetch_wait, ag._prefetch_backoff, ag._agreed["prefetch"], ag._agreed["lookahead"])
+    def same_everywhere(x):
+        v = [int(a) for a in x]
+        lo, hi = parallel.agree_min(v), [-a for a in parallel.agree_min([-a for a in v])]
+        assert lo == hi, (x, lo, hi)
+    from aid_amd import parallel
+    ag._prefetch = mk()
+    assert ag._take_prefetch(8) == ("b", "l") and ag._want_prefetch(); same_everywhere(state())
+    ag._prefetch = mk()
+    if rank == 1:
+        ag.replay_buffer.version += 1
+    assert ag._take_prefetch(8) is None                      # rank 0 alone would have accepted
+    assert (ag._prefetch_wait, ag._prefetch_backoff) == (1, 1); same_everywhere(state())
+    assert not ag._want_prefetch()                           # the back-off step, on both ranks
+    assert ag._take_prefetch(8) is None and ag._prefetch_backoff == 1      # nothing was prefetched anywhere: no further back-off
+    assert ag._want_prefetch(); same_everywhere(state())
+    if rank == 0:
+        ag.prefetch_next_batch = False
+    ag._prefetch = mk()
+    ag._take_prefetch(8)
+    assert not ag._agreed["prefetch"] and not ag._want_prefetch(); same_everywhere(state())
+    ag.prefetch_next_batch, ag.overlap_streams = True, rank == 0          # rank 1 runs single-stream: no look-ahead anywhere
+    ag._take_prefetch(8)
+    assert ag._agreed == {"prefetch": True, "lookahead": False}
+
+
 def _worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -53,6 +95,11 @@ def _worker(rank, world, port, q):
         r = torch.from_numpy(rng.standard_normal(B).astype(np.float32))
         allr = parallel.allgather_cat(r[rank * half:(rank + 1) * half].contiguous())
         assert torch.equal(allr, r)
+        # collective decisions: element-wise MIN of host integers, MAX of a host float
+        assert parallel.agree_min([1, -rank, 5 + rank]) == [1, -1, 5]
+        assert parallel.agree_min([rank == 0]) == [0]
+        assert parallel.agree_max_float(1.5 + rank) == 2.5
+        _prefetch_state_machine(rank)
         q.put((rank, "ok"))
     except Exception as e:   # surface the failure in the parent
         import traceback

@@ -474,7 +474,7 @@ def efe_step(pol, pgrads, dyn, rew, val, dec, epi, latents, running_mean, horizo
 
 def lambda_returns(rewards, next_values, dones, gamma=0.99, lam=0.95, n_steps=5, exclude_immediate_rewards=False):
     out = torch.empty_like(rewards)
-    check(lib().aid_lambda_returns_ex(_ptr(rewards), _ptr(next_values), _ptr(dones), rewards.shape[0], C.c_float(gamma), C.c_float(lam), n_steps,
+    check(lib().aid_lambda_returns_ex(_ptr(rewards), _ptr(next_values), _ptr(dones), rewards.shape[0], C.c_float(gamma), C.c_double(lam), n_steps,
                                       int(bool(exclude_immediate_rewards)), _ptr(out), _stream()), "aid_lambda_returns")
     return out
 
@@ -488,7 +488,7 @@ def value_step(val, vgrads, latents, next_latents, rewards, dones, gamma=0.99, l
     ws = ws or Workspace(latents.device)
     buf = ws.get(lib().aid_value_step_workspace(C.byref(val), B))
     check(lib().aid_value_step_ex(C.byref(val), C.byref(vgrads), B, Bx, _ptr(latents), _ptr(next_latents), _ptr(rewards), _ptr(dones), C.c_float(gamma),
-                                  C.c_float(lam), n_steps, _ptr(targets), _ptr(loss), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+                                  C.c_double(lam), n_steps, _ptr(targets), _ptr(loss), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
           "aid_value_step_ex")
     return loss, targets
 

@@ -318,18 +318,18 @@ using namespace aid;
 
 extern "C" {
 
-int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, double lam,
                           int n_steps, int exclude_immediate_rewards, float* out, void* stream) {
     AID_REQUIRE(rewards && next_values && dones && out, AID_E_NULL, "aid_lambda_returns: null tensor");
     AID_REQUIRE(B > 0 && n_steps >= 1 && n_steps <= 16, AID_E_SHAPE, "aid_lambda_returns: B=%d n_steps=%d", B, n_steps);
     hipLaunchKernelGGL(lambda_returns_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream, rewards, next_values, dones, B, gamma,
-                       (double)lam, n_steps, exclude_immediate_rewards ? 1 : 0, out);
+                       lam, n_steps, exclude_immediate_rewards ? 1 : 0, out);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
 int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
                        int n_steps, float* out, void* stream) {
-    return aid_lambda_returns_ex(rewards, next_values, dones, B, gamma, lam, n_steps, 0, out, stream);
+    return aid_lambda_returns_ex(rewards, next_values, dones, B, gamma, (double)lam, n_steps, 0, out, stream);
 }
 
 size_t aid_small_net_workspace(int B, int D) { return sizeof(float) * (size_t)B * (64 * (size_t)D + 1024) + (1 << 16); }
@@ -337,13 +337,13 @@ size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 
 size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B) { return dyn ? aid_small_net_workspace(B, dyn->D) : 0; }
 
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
-                   const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out, float* loss_out,
+                   const float* rewards, const float* dones, float gamma, double lam, int n_steps, float* targets_out, float* loss_out,
                    void* wsp, size_t ws_bytes, void* stream) {
     return aid_value_step_ex(val, vgrads, B, B, latents, next_latents, rewards, dones, gamma, lam, n_steps, targets_out, loss_out, wsp, ws_bytes, stream);
 }
 
 int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, int Bx, const float* latents, const float* next_latents,
-                      const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out, float* loss_out,
+                      const float* rewards, const float* dones, float gamma, double lam, int n_steps, float* targets_out, float* loss_out,
                       void* wsp, size_t ws_bytes, void* stream) {
     AID_REQUIRE(val && vgrads && latents && next_latents && rewards && dones && loss_out, AID_E_NULL, "aid_value_step: null argument");
     AID_REQUIRE(B > 0 && Bx >= B && Bx <= B + 64, AID_E_SHAPE, "aid_value_step: B=%d B_ext=%d", B, Bx);
@@ -355,7 +355,7 @@ int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, 
     ValueSave sv, sv2;
     AID_TRY(value_fwd(*val, B, latents, val->L, t0, v, sv, ws, s));
     { const size_t mk = ws.mark(); AID_TRY(value_fwd(*val, Bx, next_latents, val->L, t1, nv, sv2, ws, s)); ws.release(mk); }
-    AID_TRY(aid_lambda_returns(rewards, nv, dones, Bx, gamma, lam, n_steps, tg, stream));   // rows >= B: halo, their targets are unused
+    AID_TRY(aid_lambda_returns_ex(rewards, nv, dones, Bx, gamma, lam, n_steps, 0, tg, stream));   // rows >= B: halo, their targets are unused
     hipLaunchKernelGGL(huber_kernel, dim3(1), dim3(1024), 0, s, v, tg, B, dv, loss_out);
     AID_LAUNCH_CHECK();
     AID_TRY(value_bwd(*val, vgrads, B, t0, sv, dv, nullptr, 0, ws, s));

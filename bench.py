@@ -180,6 +180,104 @@ def small_batch_loops(agent):
     return out
 
 
+def roofline_phases(agent):
+    """Per-phase roofline of one cfg-2 train_step (">= 50 % of the relevant roofline per phase"; phases of
+    agents/state_agent.py:110-243).  Every phase is run IN ISOLATION, outside the timed region, on the streams the product runs it on
+    (the ELBO, the rollout + BPTT, the estimator, the optimiser and the value / dynamics updates on the current stream; the reverse loops as
+    hipGraph replays of one 256-row chain and of three concurrent 256-row chains), and timed with HIP events recorded on the launching stream
+    (median of 3).  `flop` = sum of 2 M N K over the GEMM launches the library counted for one call of the phase (aid_prof_*): the work
+    actually executed, i.e. after the W_o W_v collapse and the shared-t hoisting; `frac` = flop / ms / fp32-MFMA peak.  The estimator is
+    the difference between the whole aid_efe_step and the same call with skip_epistemic (it is one launch sequence inside that call).
+    tools/perf/phase_profile.py runs the same phases under rocprofv3 (profiles/r03_phase_*_kernel_stats.csv)."""
+    from aid_amd import _native as nat
+    ai, cfg = agent.active_inference, agent.config
+    B, N = cfg.batch_size, cfg.diffusion.num_diffusion_steps
+    dev = agent.device
+    torch.cuda.synchronize()
+    agent.invalidate_prefetch(); agent._lookahead = None      # the calls below overwrite the score gradients a pending look-ahead left in the arena
+    batch = agent.replay_buffer.sample(B)
+    obs, actions, next_obs, dones = batch["observations"], batch["actions"], batch["next_observations"], batch["dones"]
+    nrew = torch.randn(B, device=dev)
+    latents = ai.denoise_only(obs).contiguous()
+    next_latents = ai.denoise_only(next_obs).contiguous()
+    train = ai.latent_score_network.training
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    def counted(fn):
+        torch.cuda.synchronize(); nat.prof_enable(True); nat.prof_reset()
+        fn(); torch.cuda.synchronize()
+        fl = nat.prof_read(nat.PROF_GEMM)["flops"] + nat.prof_read(nat.PROF_GEMM_TILE)["flops"]
+        n = nat.prof_read(nat.PROF_GEMM)["launches"] + nat.prof_read(nat.PROF_GEMM_TILE)["launches"]
+        nat.prof_enable(False); nat.prof_reset()
+        return fl, int(n)
+
+    def elbo():
+        agent.score_optimizer.zero_grad(); ai.compute_diffusion_elbo(obs, nrew, latents)
+
+    def efe(skip):
+        agent.policy_optimizer.zero_grad()
+        return nat.efe_step(ai.policy_network.table(), ai.policy_network.grad_table(), ai.latent_dynamics.table(), ai.reward_table(), ai.value_network.table(),
+                            ai.decoder_table(), ai.epistemic_table(), latents, ai._running_mean, cfg.efe_horizon, 10, 10, train=ai.training,
+                            skip_epistemic=skip, epistemic_weight=cfg.epistemic_weight, pragmatic_weight=cfg.pragmatic_weight,
+                            consistency_weight=cfg.consistency_weight, discount=cfg.discount_factor, temperature=float(cfg.preference_temperature),
+                            seed=ai.noise.seed, offset=ai.noise.next_offset(), ws=ai._ws)
+
+    def one_chain():
+        return ai._denoise_chains([obs], [None], None, N, train, [torch.cuda.current_stream()])
+
+    def three_chains():
+        return ai.denoise_many([next_obs, obs, next_obs])
+
+    def value_dyn():
+        agent.value_optimizer.zero_grad(); agent.dynamics_optimizer.zero_grad()
+        nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones, cfg.discount_factor, 0.95, 5, ws=ai._ws)
+        nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
+
+    was = ai.concurrent_belief_loops
+    ai.concurrent_belief_loops = True
+    out = {}
+
+    def phase(name, ms, flop, launches, what, streams):
+        tfl = flop / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[name] = {"ms": ms, "flop": flop, "gemm_launches": launches, "achieved": tfl, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "bound": "mfma",
+                     "frac": tfl * 1e12 / PEAK_F32_MFMA, "what": what, "streams": streams}
+    try:
+        fl, n = counted(elbo)
+        phase("elbo", timed(elbo), fl, n, "compute_diffusion_elbo forward + backward + gradient-penalty double backward, 256 rows (state_agent.py:142-158)", "current stream")
+        fl_r, n_r = counted(lambda: efe(True))
+        ms_r = timed(lambda: efe(True))
+        phase("rollout_bptt", ms_r, fl_r, n_r, "EFE rollout (K=10 trajectories x H=5) + BPTT into the policy, estimator skipped (state_agent.py:160-181)", "current stream")
+        fl_t, n_t = counted(lambda: efe(False))
+        ms_t = timed(lambda: efe(False))
+        phase("estimator", ms_t - ms_r, fl_t - fl_r, n_t - n_r, "gradient-free epistemic estimator over H*K*S*B = 128 000 sample rows + 4 perturbed copies: whole aid_efe_step "
+              f"({ms_t:.2f} ms) minus the same call with skip_epistemic ({ms_r:.2f} ms)", "current stream")
+        fl_c, n_c = counted(lambda: ai.denoise_only(obs, ws=ai._ws))        # direct launches of the same 256-row loop (a graph replay is not counted)
+        phase("reverse_loop_one_chain", timed(one_chain), fl_c, n_c, f"one {N}-step reverse-diffusion loop at {B} rows, hipGraph replay (core/diffusion.py:176-206)", "current stream")
+        phase("reverse_loops_three_chains", timed(three_chains), 3 * fl_c, 3 * n_c, f"the three belief updates of a train_step as three concurrent {B}-row loops "
+              "(hipGraph replays): the schedule the timed steps run", "current + two chain streams")
+        fl_v, n_v = counted(value_dyn)
+        phase("value_dynamics", timed(value_dyn), fl_v, n_v, "value step (two value forwards, lambda-returns, Huber, backward) + dynamics step at 256 rows: a latency "
+              "chain of ~60 small launches, 2 GFLOP", "current stream")
+        nbytes = agent.score_optimizer.arena.flat.numel() * 4.0 * 10.0
+        ms_o = timed(lambda: agent.score_optimizer.step(reduce=False))
+        out["optimiser_score"] = {"ms": ms_o, "bytes": nbytes, "achieved": nbytes / (ms_o * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "bound": "hbm",
+                                  "frac": nbytes / (ms_o * 1e-3) / 8e12, "what": "global-norm clip + AdamW + EMA over the 27.15 M-parameter score arena "
+                                  "(5 reads + 4 writes + the norm pass's read per parameter = 40 B)", "streams": "current stream"}
+    finally:
+        ai.concurrent_belief_loops = was
+        agent.invalidate_prefetch(); agent._lookahead = None
+        torch.cuda.synchronize()
+    return out
+
+
 def other_configs(device):
     """BASELINE configs[2] and configs[3] at full size (timed outside the headline's timed region): ms per train_step and the algorithmic
     FLOP rate against the fp32-MFMA peak.  Algorithmic FLOPs: cfg 3 = SURVEY 8(d)'s 18.1 TFLOP (Hopper dims, B = 1024, shared-t hoisting);
@@ -356,17 +454,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(max(args.warmup, 2)):      # >= 2: the zero-initialised score head makes step-1 gradients degenerate
+    warm = max(args.warmup, 2)                # >= 2: the zero-initialised score head makes step-1 gradients degenerate
+    for _ in range(warm):
         agent.train_step()
+    # data parallel: the agent times its two belief-loop schedules during its first steps and keeps the faster one (state_agent.py,
+    # _dp_schedule_vote); those steps are warm-up too - the timed region runs ONE schedule.  Same count on every rank (the vote is collective).
+    while world > 1 and getattr(agent, "_dp_vote", None) is not None and warm < 16:
+        agent.train_step(); warm += 1
     sync(); t0 = time.perf_counter()
     for _ in range(args.steps):
         agent.train_step()
+    torch.cuda.synchronize(); own = time.perf_counter() - t0          # this rank's own time, before the closing barrier
     sync(); elapsed = time.perf_counter() - t0
+    dp_info = None
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=device if not rehearsal else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt)
+        # what a SCALE record can be checked against: the ranks the communicator really has (counted by an all-reduce of ones on the
+        # backend the gradients use), every rank's own time for the K steps, and the schedule the data-parallel agent settled on
+        ones = torch.ones(1, device=device if not rehearsal else "cpu"); dist.all_reduce(ones)
+        mine = torch.tensor([1e3 * own / args.steps], device=device if not rehearsal else "cpu", dtype=torch.float64)
+        allms = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(allms, mine)
+        dp_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(), "per_rank_ms_per_step": [float(x) for x in allms],
+                   "belief_loop_schedule": getattr(agent, "dp_schedule_choice", None), "belief_loop_schedule_ms": getattr(agent, "dp_schedule_ms", None)}
     # ---- outside the timed region: denoise-only rate and the live GEMM roofline (event-bracketed launches)
     SKIP = set(os.environ.get("AID_BENCH_SKIP", "").split(","))      # diagnostics only
     ai = agent.active_inference
@@ -377,20 +489,35 @@ def main():
     for _ in range(reps):
         ai.denoise_only(obs)
     torch.cuda.synchronize(); dn = (time.perf_counter() - t1) / reps
-    # event-bracketed launches need one stream: the side-stream overlap of train_step is switched off for this one step
-    agent.overlap_streams = False
-    agent.train_step(); torch.cuda.synchronize()
-    nat.prof_enable("prof" not in SKIP); nat.prof_reset()
-    agent.train_step(); torch.cuda.synchronize()
-    gt = nat.prof_read(nat.PROF_GEMM_TILE); gs = nat.prof_read(nat.PROF_GEMM); o = nat.prof_read(nat.PROF_OPTIM)
+    # ---- per-launch HIP events (aid_prof_*: recorded on the stream each kernel is launched on) over one train_step, twice:
+    # (a) in the schedule the timed steps run - side stream + three concurrent 256-row chains - with the chains launched directly instead of
+    #     replayed from their hipGraphs (a replay cannot carry per-kernel events); a kernel's duration there includes whatever time-slicing with
+    #     the other streams' kernels it suffered, exactly as a rocprofv3 kernel trace of the timed steps shows it;
+    # (b) single-stream, every phase in order on one stream: the isolated per-kernel figures.
     import tempfile
-    dump = args.dump_launches or os.path.join(tempfile.gettempdir(), f"aid_launches_{os.getpid()}.csv")
-    nat.prof_dump(dump)
-    per_kernel = per_kernel_table(dump)
-    if not args.dump_launches:
-        os.remove(dump)
-    nat.prof_enable(False); nat.prof_reset()
+
+    def profiled_step(tag):
+        agent.train_step(); torch.cuda.synchronize()          # one unprofiled step in this configuration first (prefetch / look-ahead state settles)
+        nat.prof_enable("prof" not in SKIP); nat.prof_reset()
+        agent.train_step(); torch.cuda.synchronize()
+        r = {"gt": nat.prof_read(nat.PROF_GEMM_TILE), "gs": nat.prof_read(nat.PROF_GEMM), "o": nat.prof_read(nat.PROF_OPTIM)}
+        dump = (args.dump_launches + "." + tag) if args.dump_launches else os.path.join(tempfile.gettempdir(), f"aid_launches_{os.getpid()}_{tag}.csv")
+        nat.prof_dump(dump)
+        r["per_kernel"] = per_kernel_table(dump)
+        if not args.dump_launches:
+            os.remove(dump)
+        nat.prof_enable(False); nat.prof_reset()
+        return r
+    prof_ov = None
+    if not args.no_overlap:
+        ai.graph_belief_loops = False
+        prof_ov = profiled_step("overlapped")
+        ai.graph_belief_loops = True
+    agent.overlap_streams = False
+    prof_ss = profiled_step("single_stream")
+    gt, gs, o, per_kernel = prof_ss["gt"], prof_ss["gs"], prof_ss["o"], prof_ss["per_kernel"]
     agent.overlap_streams = not args.no_overlap
+    phases = roofline_phases(agent) if ("phases" not in SKIP and world == 1) else None      # isolated calls: no collectives, one GPU only
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:      # outside the timed region, one GPU only
         extras["other_configs"] = other_configs(device)
@@ -401,21 +528,27 @@ def main():
     steps_per_s = args.steps / elapsed
     g = {k: gt[k] + gs[k] for k in gt}
     tf = lambda d: (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0
-    pmc = {}
-    try:   # HBM-side bytes per launch from the committed rocprofv3 PMC passes (profiles/README.md: how they were taken and corrected)
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_summary.json")))
-    except Exception:
-        pass
+    # HBM-side bytes per launch come from the committed rocprofv3 PMC passes, not from this run (profiles/README.md: how they were taken and
+    # corrected): r03_pmc_chain_summary.json = one 256-row reverse loop alone (the kernels of the concurrent chains), r02_pmc_summary.json = one
+    # single-stream train_step (the tall kernels; unchanged since).  Every roofline object names its source in `traffic_source`.
+    pmc = []
+    for fn in ("r03_pmc_chain_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+        try:
+            pmc.append((fn, json.load(open(os.path.join(ROOT, "profiles", fn)))))
+        except Exception:
+            pass
     def traffic(prefix):
-        for k, v in pmc.items():
-            if k.startswith(prefix) and "fetch_bytes_per_launch_corrected" in v:
-                return v["fetch_bytes_per_launch_corrected"] + v.get("write_bytes_per_launch", 0.0)
-        return None
+        for fn, tab in pmc:
+            for k, v in tab.items():
+                if k.startswith(prefix) and "fetch_bytes_per_launch_corrected" in v:
+                    return v["fetch_bytes_per_launch_corrected"] + v.get("write_bytes_per_launch", 0.0), "profiles/" + fn
+        return None, None
     # One entry per kernel instantiation (= one row of the rocprofv3 --stats summary), ordered by its share of the profiled step.
     def entry(name, d):
+        tr, src = traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name)
         e = {"bound": "mfma", "kernel": "aid::" + name, "achieved": tf(d), "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s",
              "frac": tf(d) * 1e12 / PEAK_F32_MFMA,
-             "traffic": traffic(name.rsplit(",", 1)[0] if name.startswith("gemm_panel128") else name),
+             "traffic": tr, "traffic_source": src,
              "launches_per_step": d["launches"], "ms_per_step": d["ms"], "flop_per_launch": d["flops"] / max(d["launches"], 1),
              "algorithmic_bytes_per_launch": d["bytes"] / max(d["launches"], 1),
              "us_per_launch": 1e3 * d["ms"] / max(d["launches"], 1)}
@@ -424,12 +557,26 @@ def main():
         return e
     ranked = sorted(per_kernel.items(), key=lambda kv: -kv[1]["ms"])
     mfma_ranked = [kv for kv in ranked if kv[0] != "gemm_smallk_kernel"]
-    dominant = entry(*mfma_ranked[0]); second = entry(*mfma_ranked[1]) if len(mfma_ranked) > 1 else None
-    dominant["note"] = ("the kernel instantiation with the largest share of GPU time; achieved = sum(2MNK) / sum(HIP-event durations) of its launches in "
-                        "one single-stream train_step (compare us_per_launch with AverageNs of the same name in profiles/*_kernel_stats_no_overlap.csv)")
+    ss_dominant = entry(*mfma_ranked[0]); ss_second = entry(*mfma_ranked[1]) if len(mfma_ranked) > 1 else None
+    ss_dominant["note"] = ("largest share of GPU time in the SINGLE-STREAM step; achieved = sum(2MNK) / sum(HIP-event durations) of its launches "
+                           "(compare us_per_launch with AverageNs of the same name in profiles/*_kernel_stats_no_overlap.csv)")
+    ov_entries = None
+    if prof_ov is not None:
+        ov_ranked = [kv for kv in sorted(prof_ov["per_kernel"].items(), key=lambda kv: -kv[1]["ms"]) if kv[0] != "gemm_smallk_kernel"]
+        ov_entries = [entry(n, d) for n, d in ov_ranked[:8]]
+        for e in ov_entries:
+            e["profiled"] = "overlapped schedule: side stream + three concurrent 256-row chains (chains launched directly so that every kernel carries events)"
+    if ov_entries:
+        dominant, second = ov_entries[0], (ov_entries[1] if len(ov_entries) > 1 else None)
+        dominant["note"] = ("the GEMM kernel instantiation with the largest share of kernel time in the schedule the timed steps run (side stream + three concurrent "
+                            "256-row belief chains); achieved = sum(2MNK) / sum(HIP-event durations on the launching stream) of its launches in one such step - a "
+                            "duration includes the time-slicing with the other streams' kernels, as in profiles/r03_train_step_kernel_stats.csv (AverageNs of the "
+                            "same name).  Its isolated figure is in roofline_single_stream_kernels / roofline_phases.reverse_loop_one_chain.")
+    else:
+        dominant, second = ss_dominant, ss_second
     out = {
         "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
-        "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 2), "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+        "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU over gloo; not a result)",
         "config": {"workload": "HalfCheetah-v4 state obs (O=17,A=6,L=17), batch=256/GPU, EFE horizon=5, K=10, S=10, 50 denoise steps, hidden=512 "
                                "(BASELINE configs[1]); full DiffusionStateAgent.train_step", "global_batch": BATCH * world,
@@ -440,7 +587,10 @@ def main():
         "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
         "roofline": dominant,
         "roofline_second_kernel": second,
-        "roofline_kernels": [entry(n, d) for n, d in ranked[:8]],
+        "roofline_kernels": ov_entries if ov_entries else [entry(n, d) for n, d in ranked[:8]],
+        "roofline_single_stream": ss_dominant,
+        "roofline_single_stream_kernels": [entry(n, d) for n, d in ranked[:8]],
+        "roofline_phases": phases,
         "roofline_big_family": {"kernel": "GEMM launches that ran a full-row or 64x64-tile kernel (tall problems: MINE, hoisted conditioning, rollout)", "achieved": tf(gt),
                                 "frac": tf(gt) * 1e12 / PEAK_F32_MFMA, "launches_per_step": gt["launches"], "ms_per_step": gt["ms"]},
         "roofline_small_family": {"kernel": "GEMM launches that ran a small-problem kernel (the 256..768-row layers of the reverse loops, ELBO, BPTT, thin heads); per-CU "
@@ -452,10 +602,12 @@ def main():
                          "achieved": (o["bytes"] / (o["ms"] * 1e-3) / 1e9) if o["ms"] > 0 else None, "peak": 8000.0, "unit": "GB/s",
                          "frac": (o["bytes"] / (o["ms"] * 1e-3) / 8e12) if o["ms"] > 0 else None},
     }
-    for e in [out["roofline"], out["roofline_second_kernel"], *out["roofline_kernels"], out["roofline_big_family"], out["roofline_small_family"],
-              out["roofline_gemm_family"], out["roofline_hbm"]]:
+    for e in [out["roofline"], out["roofline_second_kernel"], *out["roofline_kernels"], out["roofline_single_stream"], *out["roofline_single_stream_kernels"],
+              out["roofline_big_family"], out["roofline_small_family"], out["roofline_gemm_family"], out["roofline_hbm"]]:
         if e is not None:
-            e["profiled"] = "single-stream"      # the event-bracketed step outside the timed region (the timed steps run two streams)
+            e.setdefault("profiled", "single-stream")      # an event-bracketed step outside the timed region, every phase in order on one stream
+    if dp_info is not None:
+        out["data_parallel"] = dp_info
     if extras:
         out.update(extras)
     if world == 1 and not args.no_cpu_baseline:

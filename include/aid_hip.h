@@ -391,19 +391,21 @@ int aid_random_shift(const float* x, const int32_t* shift_h, const int32_t* shif
  * gradients, MSE dynamics loss with gradients.  dones: [B] floats (0/1).  loss_out: device scalar. */
 int aid_lambda_returns(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
                        int n_steps, float* out, void* stream);
-/* exclude_immediate_rewards != 0: the k = 0 reward of every n-step return is left out (active_inference.py:649-653, 674-675, 701-702) */
-int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, float lam,
+/* exclude_immediate_rewards != 0: the k = 0 reward of every n-step return is left out (active_inference.py:649-653, 674-675, 701-702).
+ * `lam` is a double here and in aid_value_step[_ex]: the reference forms the weights (1 - lambda) lambda^i from a Python float (fp64) and only
+ * then rounds them to float32; a float 0.95f already differs in the weights' last bit (aid_lambda_returns keeps its float argument). */
+int aid_lambda_returns_ex(const float* rewards, const float* next_values, const float* dones, int B, float gamma, double lam,
                           int n_steps, int exclude_immediate_rewards, float* out, void* stream);
 size_t aid_value_step_workspace(const AidValueNet* val, int B);
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
-                   const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,
+                   const float* rewards, const float* dones, float gamma, double lam, int n_steps, float* targets_out,
                    float* loss_out, void* ws, size_t ws_bytes, void* stream);
 /* aid_value_step with a lambda-return HALO: next_latents / rewards / dones hold B_ext >= B rows; the first B are this call's minibatch,
  * rows B..B_ext-1 continue the sequence (data parallel: the first n_steps rows of the next rank's shard), so that the windows of the
  * last rows see the same neighbours as in one global batch (compute_lambda_returns treats minibatch order as time, :638-707).
  * Targets, Huber loss (mean over B) and gradients are those of the first B rows. */
 int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, int B_ext, const float* latents, const float* next_latents,
-                      const float* rewards, const float* dones, float gamma, float lam, int n_steps, float* targets_out,
+                      const float* rewards, const float* dones, float gamma, double lam, int n_steps, float* targets_out,
                       float* loss_out, void* ws, size_t ws_bytes, void* stream);
 size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B);
 int aid_dynamics_step(const AidDynamicsNet* dyn, const AidDynamicsNet* dgrads, int B, const float* latents, const float* actions,

@@ -433,7 +433,7 @@ class DiffusionActiveInference(nn.Module):
 
     def _denoise_chains(self, obs_list, noises, ws, N, train, streams) -> torch.Tensor:
         first = streams[0]
-        wss = [ws or self._ws] + self._chain_ws[:len(streams) - 1]
+        wss = [ws or self._ws] + (getattr(self, "_chain_ws", None) or [])[:len(streams) - 1]
         obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
         offs = [self.noise.next_offset() for _ in obs_list]
         graphs = None

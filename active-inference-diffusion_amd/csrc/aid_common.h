@@ -116,6 +116,21 @@ inline int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx,
     return gemm_f32(g, s);
 }
 
+// ---- grouped weight gradients (gemm_group.hip): the dW / db leaves of a backward pass are recorded while the adjoint chain runs and computed
+// by ONE launch at the end of the pass.  The operands a recorded problem points at must stay untouched until flush().
+constexpr int GROUP_MAX_SEG = 2, GROUP_MAX_PROB = 36;                 // 36 x 112 B + 8 B: the table travels in the kernel arguments (< 4 KB)
+struct GroupSeg { const float* a; const float* b; int lda, ldb, m, _pad; };              // a = dY [m, N], b = X [m, K]
+struct GroupProb { float* C; float* db; int ldc, N, K, nseg, tile0, tiles_k, vec, _pad; GroupSeg seg[GROUP_MAX_SEG]; };   // C [N, K] += sum_s a_s^T b_s
+struct GroupArgs { int nprob, _pad; GroupProb p[GROUP_MAX_PROB]; };
+struct GradQueue {
+    GroupArgs args; hipStream_t s; double flop;
+    explicit GradQueue(hipStream_t st) : s(st), flop(0.0) { args.nprob = 0; args._pad = 0; }
+    // dW[N, K] (row stride ldc) += dy^T x over M rows; db[N] += colsum(dy) when db != null.  A call with the same dW as the previous one
+    // (and no db) becomes a second segment of that problem.
+    int add(float* dW, int ldc, int N, int K, const float* dy, int lddy, const float* x, int ldx, int M, float* db);
+    int flush();
+};
+
 // ---- profiling hooks (bench.py reads them through aid_prof_*) ---------------------------------
 enum ProfKernel : int { PROF_GEMM = 0, PROF_ROWWISE = 1, PROF_OPTIM = 2, PROF_GEMM_TILE = 3, PROF_COUNT = 4 };
 struct ProfScope {

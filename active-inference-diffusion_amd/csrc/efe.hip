@@ -306,7 +306,7 @@ size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec,
     if (!pol || !cfg || B <= 0 || (!dec && !cfg->skip_epistemic)) return 0;
     const size_t M = (size_t)cfg->K * B, R = M * cfg->S, D = pol->D, H = cfg->H;
     size_t n = dec ? mine_ws_bytes(*dec, (int)(H * cfg->K), cfg->S, B) : 0;     // the estimator runs over all H horizon steps in one pass
-    n += sizeof(float) * H * M * (40 * D + 64 + pol->L);                       // per-step saved activations (policy, dynamics, reward, value)
+    n += sizeof(float) * H * M * (48 * D + 128 + 2 * pol->L);                   // per-step saved activations (policy, dynamics, reward, value) + the policy adjoints the deferred weight gradients read
     n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
     n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
     n += sizeof(int32_t) * H * R + (1 << 20);
@@ -364,7 +364,13 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
     AID_REQUIRE(H <= 16, AID_E_SHAPE, "aid_efe_step: horizon %d > 16", H);
     float* acc = ws.f32(M); float* prag = ws.f32(M); float* cons = ws.f32(M);
     float* mine_all = ws.f32((size_t)H * K * 4);
-    float* lat_rep = ws.f32((size_t)M * L);
+    // [H+1][K*B][L]: slot 0 = the K copies of the belief latents, slot t + 1 = the state reached after horizon step t.  Slots 0..H-1 are the
+    // policy's inputs of the H forward passes, side by side: its first layer's weight gradient is one contraction over H*K*B rows.
+    float* cur_all = ws.f32((size_t)(H + 1) * M * L);
+    float* lat_rep = cur_all;
+    PolicySteps psteps;
+    const bool defer_grads = pgrads != nullptr;
+    if (defer_grads) AID_TRY(policy_steps_alloc(*pol, M, H, ws, psteps));
     float* next_mean_all = ws.f32((size_t)H * M * L);      // [H][K*B][L]: the estimator runs ONCE over the dynamics means of every horizon step
     AID_WS_OK(ws);
     LAUNCH1D(tile_rows_kernel, (size_t)M * L, s, latents, lat_rep, K, (size_t)B * L);   // latent.clone() per trajectory
@@ -372,7 +378,8 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
     const float* cur = lat_rep;
     for (int t = 0; t < H; ++t) {
         Step& q = st[t];
-        q.cur = (float*)cur; q.next_mean = next_mean_all + (size_t)t * M * L; q.nxt = ws.f32((size_t)M * L); q.V = ws.f32(M); q.tvec = ws.f32(M);
+        q.cur = (float*)cur; q.next_mean = next_mean_all + (size_t)t * M * L; q.nxt = cur_all + (size_t)(t + 1) * M * L; q.V = ws.f32(M); q.tvec = ws.f32(M);
+        if (defer_grads) q.ps = psteps.sv[t];
         AID_WS_OK(ws);
         AID_TRY(policy_fwd(*pol, M, cur, L, pol_eps + (size_t)t * M * A, q.ps, ws, s));
         AID_TRY(dynamics_fwd(*dyn, M, cur, L, q.ps.action, A, q.next_mean, q.ds, ws, s));
@@ -417,9 +424,14 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
         AID_TRY(value_bwd(*val, nullptr, M, q.tvec, q.vs, d_v, dz_v, L, ws, s));
         LAUNCH1D(add3_kernel, (size_t)M * L, s, have_carry ? carry : nullptr, dz_r, dz_v, dnxt, (size_t)M * L);
         AID_TRY(dynamics_bwd(*dyn, nullptr, M, q.ds, dnxt, dz_dyn, da, ws, s));
-        AID_TRY(policy_bwd(*pol, pgrads, M, q.cur, L, pol_eps + (size_t)t * M * A, q.ps, da, entc, t > 0 ? dz_pol : nullptr, L, ws, s));
+        AID_TRY(policy_bwd(*pol, pgrads, M, q.cur, L, pol_eps + (size_t)t * M * A, q.ps, da, entc, t > 0 ? dz_pol : nullptr, L, ws, s, &psteps, t));
         if (t > 0) { LAUNCH1D(add3_kernel, (size_t)M * L, s, (const float*)nullptr, dz_dyn, dz_pol, carry, (size_t)M * L); have_carry = true; }
     }
+    // the policy's weight / bias gradients: dW = sum_t adj_t^T x_t as ONE contraction per layer over the H*K*B rows of the [H][K*B][.] buffers,
+    // all nine layers in one grouped launch (45 launches inside the BPTT chain before)
+    GradQueue gq(s);
+    AID_TRY(policy_bptt_grads(*pol, *pgrads, psteps, cur_all, L, gq));
+    AID_TRY(gq.flush());
     return AID_OK;
 }
 

@@ -491,8 +491,15 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     hipLaunchKernelGGL(mean_scalar_kernel, dim3(1), dim3(1024), 0, s, per, B, metrics + 2);
     hipLaunchKernelGGL(mean_scalar_kernel, dim3(1), dim3(1024), 0, s, wts, B, metrics + 7);
     AID_LAUNCH_CHECK();
-    AID_TRY(score_reverse(n, grads, B, am, nullptr, zt, nullptr, d_score, t, AID_T_CONTINUOUS, 0.f, dz, dmod, ws, s));
-    AID_TRY(score_cond_backward(n, *grads, B, am, dmod, obs, smask, t, AID_T_CONTINUOUS, ws, s, d_obs));
+    // every weight / bias gradient of a pass is recorded while its adjoint chain runs and computed by one grouped launch at the end of the pass
+    GradQueue gq(s);
+    {
+        const size_t mk = ws.mark();
+        AID_TRY(score_reverse(n, grads, B, am, nullptr, zt, nullptr, d_score, t, AID_T_CONTINUOUS, 0.f, dz, dmod, ws, s, &gq));
+        AID_TRY(score_cond_backward(n, *grads, B, am, dmod, obs, smask, t, AID_T_CONTINUOUS, ws, s, d_obs, &gq));
+        AID_TRY(gq.flush());
+        ws.release(mk);
+    }
     hipLaunchKernelGGL(elbo_lambda_grad_kernel, dim3(1), dim3(1024), 0, s, dlamA, dz, latents, eps, t, dp->log_snr_min, dp->log_snr_max,
                        dgrads->log_snr_min, dgrads->log_snr_max, B, L);
     AID_LAUNCH_CHECK();
@@ -508,8 +515,13 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     AID_TRY(score_reverse(n, nullptr, B, ag, nullptr, zt, nullptr, nullptr, t, AID_T_CONTINUOUS, 0.f, gvec, nullptr, ws, s));   // g = d(sum s)/dz_t
     AID_TRY(gp_weights(gvec, wvec, metrics + 5, B, L, s));
     AID_TRY(score_tangent_forward(n, B, wvec, ag, tan, s));
-    AID_TRY(score_reverse(n, grads, B, ag, &tan, zt, wvec, nullptr, t, AID_T_CONTINUOUS, -cfg->gp_weight, nullptr, dmod, ws, s));
-    AID_TRY(score_cond_backward(n, *grads, B, ag, dmod, obs, gmask, t, AID_T_CONTINUOUS, ws, s, d_obs));
+    {
+        const size_t mk = ws.mark();
+        AID_TRY(score_reverse(n, grads, B, ag, &tan, zt, wvec, nullptr, t, AID_T_CONTINUOUS, -cfg->gp_weight, nullptr, dmod, ws, s, &gq));
+        AID_TRY(score_cond_backward(n, *grads, B, ag, dmod, obs, gmask, t, AID_T_CONTINUOUS, ws, s, d_obs, &gq));
+        AID_TRY(gq.flush());
+        ws.release(mk);
+    }
 
     // ---- prior / KL term, reward NLL, metrics, time-importance EMA
     hipLaunchKernelGGL(kl_prior_kernel, dim3(1), dim3(1024), 0, s, latents, peps, dp->prior_mean, dp->prior_log_std, t, cfg->kl_weight,

@@ -21,16 +21,19 @@ int lla_alloc(int M, int out, Workspace& ws, LlaSave& sv);
 int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, const float* x, int ldx, int M, LlaSave& sv, hipStream_t s,
             const float* add = nullptr, bool need_lin = true);
 // dy: gradient wrt sv.y [M,out].  Writes dx (optional, row stride lddx) ; accumulates parameter grads when gl/gln given.
+// dlin_keep (optional, [M,out]): the adjoint of the Linear output is left there and the weight / bias gradients are NOT computed: the caller
+// contracts them later (GradQueue: one grouped launch per backward pass, gemm_group.hip).
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
-            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s);
+            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep = nullptr);
 
 // y = act(x W^T + b) * mask            (Linear -> activation), pre-activation saved
 struct LaSave { float *pre, *y; };
 int la_alloc(int M, int out, bool need_pre, Workspace& ws, LaSave& sv);
 int la_fwd(const AidLinear& l, int act, const float* mask, const float* x, int ldx, int M, LaSave& sv, int ldy, hipStream_t s);
 // dy is overwritten (multiplied by act'(pre)*mask).
+// defer_params: dy (which then holds the adjoint of the Linear output) is the operand of a gradient the caller contracts later.
 int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, const float* x, int ldx, int M, const LaSave& sv,
-           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx = 0, Workspace* ws = nullptr);
+           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx = 0, Workspace* ws = nullptr, bool defer_params = false);
 
 // ---- observation decoder (state branch), aid/core/active_inference.py:237-242
 struct DecoderSave { LlaSave s0, s1, s2; float* h2; };
@@ -61,11 +64,24 @@ int value_bwd(const AidValueNet& v, const AidValueNet* g, int M, const float* t,
               int ldds, Workspace& ws, hipStream_t s);
 
 // ---- policy, aid/models/policy_networks.py:95-146
-struct PolicySave { LlaSave e0; float* h; LlaSave tr[3]; float* h2; LaSave m0, s0; float *mean, *lstd, *action, *ent, *logp; };
+struct PolicySave { LlaSave e0; float* h; LlaSave tr[3]; float* h2; LaSave m0, s0; float *mean, *lstd, *action, *ent, *logp; bool prealloc = false; };
 int policy_fwd(const AidPolicyNet& p, int M, const float* z, int ldz, const float* eps, PolicySave& sv, Workspace& ws, hipStream_t s);
+// The H forward passes of a rollout saved side by side: every saved tensor (and every adjoint a weight gradient reads) of step t is slice t of
+// ONE [H][M][width] buffer, so that the BPTT's parameter gradients dW = sum_t adj_t^T x_t are single contractions over H*M rows
+// (policy_bptt_grads) instead of H launches per layer.
+struct PolicySteps {
+    int H, M;
+    PolicySave sv[16];
+    float *dmean, *dlstd, *dm0, *ds0, *dtr[3], *de0, *dh;        // [H][M][.] adjoints of mean2 / lstd2 / mean0 / lstd0 / trunk i / enc0 outputs, enc3 output
+};
+int policy_steps_alloc(const AidPolicyNet& p, int M, int H, Workspace& ws, PolicySteps& ps);
+// record dW / db of every policy Linear over all H steps into q (z_all: [H][M][L] inputs of the H forward passes)
+int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q);
 // d_action [M,A] (may be null = 0), ent_coef[M] = dLoss/d(entropy_sum) per row (may be null), accumulates param grads; dz optional
+// steps / t (optional): write step t's adjoints into the PolicySteps slices and leave the Linear weight / bias gradients to policy_bptt_grads
+// (LayerNorm parameter gradients are still accumulated here).
 int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
-               const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s);
+               const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s, const PolicySteps* steps = nullptr, int t = 0);
 
 // ---- ConvDecoder + pixel estimator feature side (conv.hip)
 int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s);

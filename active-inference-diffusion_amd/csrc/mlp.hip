@@ -48,14 +48,14 @@ int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, con
     return AID_OK;
 }
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
-            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s) {
+            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep) {
     const size_t mark = ws.mark();
-    float* dlin = ws.f32((size_t)M * l.out);
+    float* dlin = dlin_keep ? dlin_keep : ws.f32((size_t)M * l.out);
     float* dyeff = gln ? ws.f32((size_t)M * l.out) : nullptr;
     AID_WS_OK(ws);
     AID_TRY(ln_bwd_rows(dy, l.out, sv.lin, l.out, sv.stats, ln.g, ln.b, act, mask, dlin, l.out, dyeff, M, l.out, s));
     if (gln) AID_TRY(ln_param_grad(dyeff, sv.lin, l.out, sv.stats, gln->g, gln->b, M, l.out, s, &ws));
-    if (gl) {
+    if (gl && !dlin_keep) {
         AID_TRY(linear_bwd_weight(dlin, l.out, x, ldx, gl->w, M, l.out, l.in, s, 1));
         if (gl->b) AID_TRY(colsum(dlin, l.out, gl->b, M, l.out, 1, s, &ws));
     }
@@ -73,11 +73,11 @@ int la_fwd(const AidLinear& l, int act, const float* mask, const float* x, int l
     return linear_fwd(x, ldx, l.w, l.b, sv.y, ldy, M, l.out, l.in, act, s, sv.pre, nullptr, 0, mask);
 }
 int la_bwd(const AidLinear& l, const AidLinear* gl, int act, const float* mask, const float* x, int ldx, int M, const LaSave& sv,
-           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx, Workspace* ws) {
+           float* dy, int lddy, float* dx, int lddx, hipStream_t s, int accumulate_dx, Workspace* ws, bool defer_params) {
     AID_REQUIRE(lddy == l.out, AID_E_SHAPE, "la_bwd: dy must be contiguous");
     if (mask) AID_TRY(mul_elem(dy, mask, dy, (size_t)M * l.out, s));
     if (act != ACT_NONE) AID_TRY(act_bwd_dual(sv.pre, dy, nullptr, nullptr, act, (size_t)M * l.out, s));
-    if (gl) {
+    if (gl && !defer_params) {
         AID_TRY(linear_bwd_weight(dy, l.out, x, ldx, gl->w, M, l.out, l.in, s, 1));
         if (gl->b) AID_TRY(colsum(dy, l.out, gl->b, M, l.out, 1, s, ws));
     }
@@ -267,12 +267,14 @@ __global__ void policy_sample_bwd_kernel(const float* __restrict__ lstd, const f
 
 int policy_fwd(const AidPolicyNet& p, int M, const float* z, int ldz, const float* eps, PolicySave& sv, Workspace& ws, hipStream_t s) {
     const int D = p.D, A = p.A, H = p.mean0.out;
-    lla_alloc(M, D, ws, sv.e0); sv.h = ws.f32((size_t)M * D);
-    for (int i = 0; i < 3; ++i) lla_alloc(M, D, ws, sv.tr[i]);
-    sv.h2 = ws.f32((size_t)M * D);
-    la_alloc(M, H, true, ws, sv.m0); la_alloc(M, H, true, ws, sv.s0);
-    sv.mean = ws.f32((size_t)M * A); sv.lstd = ws.f32((size_t)M * A); sv.action = ws.f32((size_t)M * A);
-    sv.ent = ws.f32(M); sv.logp = ws.f32(M);
+    if (!sv.prealloc) {
+        lla_alloc(M, D, ws, sv.e0); sv.h = ws.f32((size_t)M * D);
+        for (int i = 0; i < 3; ++i) lla_alloc(M, D, ws, sv.tr[i]);
+        sv.h2 = ws.f32((size_t)M * D);
+        la_alloc(M, H, true, ws, sv.m0); la_alloc(M, H, true, ws, sv.s0);
+        sv.mean = ws.f32((size_t)M * A); sv.lstd = ws.f32((size_t)M * A); sv.action = ws.f32((size_t)M * A);
+        sv.ent = ws.f32(M); sv.logp = ws.f32(M);
+    }
     AID_WS_OK(ws);
     AID_TRY(lla_fwd(p.enc0, p.enc_ln, ACT_RELU, nullptr, z, ldz, M, sv.e0, s));
     AID_TRY(linear_fwd(sv.e0.y, D, p.enc3.w, p.enc3.b, sv.h, D, M, D, D, ACT_NONE, s));
@@ -288,35 +290,99 @@ int policy_fwd(const AidPolicyNet& p, int M, const float* z, int ldz, const floa
     return AID_OK;
 }
 
+int policy_steps_alloc(const AidPolicyNet& p, int M, int H, Workspace& ws, PolicySteps& ps) {
+    AID_REQUIRE(H >= 1 && H <= 16, AID_E_SHAPE, "policy_steps_alloc: H=%d", H);
+    const int D = p.D, A = p.A, Hh = p.mean0.out;
+    ps.H = H; ps.M = M;
+    const size_t HM = (size_t)H * M;
+    auto slices = [&](size_t width, float* PolicySave::* field) {
+        float* base = ws.f32(HM * width);
+        for (int t = 0; t < H; ++t) ps.sv[t].*field = base ? base + (size_t)t * M * width : nullptr;
+    };
+    auto lla_slices = [&](size_t width, LlaSave PolicySave::* blk) {
+        float* lin = ws.f32(HM * width); float* st = ws.f32(HM * 2); float* y = ws.f32(HM * width);
+        for (int t = 0; t < H; ++t) {
+            LlaSave& b = ps.sv[t].*blk;
+            b.lin = lin ? lin + (size_t)t * M * width : nullptr; b.stats = st ? st + (size_t)t * M * 2 : nullptr; b.y = y ? y + (size_t)t * M * width : nullptr;
+        }
+    };
+    auto la_slices = [&](size_t width, LaSave PolicySave::* blk) {
+        float* pre = ws.f32(HM * width); float* y = ws.f32(HM * width);
+        for (int t = 0; t < H; ++t) { LaSave& b = ps.sv[t].*blk; b.pre = pre ? pre + (size_t)t * M * width : nullptr; b.y = y ? y + (size_t)t * M * width : nullptr; }
+    };
+    lla_slices(D, &PolicySave::e0); slices(D, &PolicySave::h);
+    {   // tr[3] is an array member: slice it by hand
+        for (int i = 0; i < 3; ++i) {
+            float* lin = ws.f32(HM * D); float* st = ws.f32(HM * 2); float* y = ws.f32(HM * D);
+            for (int t = 0; t < H; ++t) {
+                LlaSave& b = ps.sv[t].tr[i];
+                b.lin = lin ? lin + (size_t)t * M * D : nullptr; b.stats = st ? st + (size_t)t * M * 2 : nullptr; b.y = y ? y + (size_t)t * M * D : nullptr;
+            }
+        }
+    }
+    slices(D, &PolicySave::h2);
+    la_slices(Hh, &PolicySave::m0); la_slices(Hh, &PolicySave::s0);
+    slices(A, &PolicySave::mean); slices(A, &PolicySave::lstd); slices(A, &PolicySave::action); slices(1, &PolicySave::ent); slices(1, &PolicySave::logp);
+    for (int t = 0; t < H; ++t) ps.sv[t].prealloc = true;
+    ps.dmean = ws.f32(HM * A); ps.dlstd = ws.f32(HM * A); ps.dm0 = ws.f32(HM * Hh); ps.ds0 = ws.f32(HM * Hh);
+    for (int i = 0; i < 3; ++i) ps.dtr[i] = ws.f32(HM * D);
+    ps.de0 = ws.f32(HM * D); ps.dh = ws.f32(HM * D);
+    AID_WS_OK(ws);
+    return AID_OK;
+}
+
+int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q) {
+    const int D = p.D, A = p.A, Hh = p.mean0.out, R = ps.H * ps.M;
+    const PolicySave& s0 = ps.sv[0];                      // slice 0 = base of every [H][M][.] buffer
+    AID_TRY(q.add(g.mean2.w, Hh, A, Hh, ps.dmean, A, s0.m0.y, Hh, R, g.mean2.b));
+    AID_TRY(q.add(g.lstd2.w, Hh, A, Hh, ps.dlstd, A, s0.s0.y, Hh, R, g.lstd2.b));
+    AID_TRY(q.add(g.mean0.w, D, Hh, D, ps.dm0, Hh, s0.h2, D, R, g.mean0.b));
+    AID_TRY(q.add(g.lstd0.w, D, Hh, D, ps.ds0, Hh, s0.h2, D, R, g.lstd0.b));
+    AID_TRY(q.add(g.trunk[2].w, D, D, D, ps.dtr[2], D, s0.tr[1].y, D, R, g.trunk[2].b));
+    AID_TRY(q.add(g.trunk[1].w, D, D, D, ps.dtr[1], D, s0.tr[0].y, D, R, g.trunk[1].b));
+    AID_TRY(q.add(g.trunk[0].w, D, D, D, ps.dtr[0], D, s0.h, D, R, g.trunk[0].b));
+    AID_TRY(q.add(g.enc3.w, D, D, D, ps.dh, D, s0.e0.y, D, R, g.enc3.b));
+    AID_TRY(q.add(g.enc0.w, p.enc0.in, D, p.enc0.in, ps.de0, D, z_all, ldz, R, g.enc0.b));
+    return AID_OK;
+}
+
 int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
-               const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s) {
+               const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s, const PolicySteps* steps, int t) {
     const int D = p.D, A = p.A, H = p.mean0.out;
     const size_t mark = ws.mark();
-    float* dmean = ws.f32((size_t)M * A); float* dlstd = ws.f32((size_t)M * A);
-    float* dm0 = ws.f32((size_t)M * H); float* ds0 = ws.f32((size_t)M * H);
+    const bool defer = steps != nullptr && g != nullptr;
+    auto slot = [&](float* base, size_t width) { return base + (size_t)t * M * width; };
+    float* dmean = defer ? slot(steps->dmean, A) : ws.f32((size_t)M * A); float* dlstd = defer ? slot(steps->dlstd, A) : ws.f32((size_t)M * A);
+    float* dm0 = defer ? slot(steps->dm0, H) : ws.f32((size_t)M * H); float* ds0 = defer ? slot(steps->ds0, H) : ws.f32((size_t)M * H);
     float* dh2 = ws.f32((size_t)M * D); float* dA = ws.f32((size_t)M * D); float* dB = ws.f32((size_t)M * D);
+    float* dhk = defer ? slot(steps->dh, D) : nullptr;
     AID_WS_OK(ws);
     hipLaunchKernelGGL(policy_sample_bwd_kernel, dim3((M * A + 255) / 256), dim3(256), 0, s, sv.lstd, eps, d_action, ent_coef, dmean, dlstd, M, A);
     AID_LAUNCH_CHECK();
     // heads
-    if (g) {
+    if (g && !defer) {
         AID_TRY(linear_bwd_weight(dmean, A, sv.m0.y, H, g->mean2.w, M, A, H, s, 1)); AID_TRY(colsum(dmean, A, g->mean2.b, M, A, 1, s, &ws));
         AID_TRY(linear_bwd_weight(dlstd, A, sv.s0.y, H, g->lstd2.w, M, A, H, s, 1)); AID_TRY(colsum(dlstd, A, g->lstd2.b, M, A, 1, s, &ws));
     }
     AID_TRY(linear_bwd_data(dmean, A, p.mean2.w, H, dm0, H, M, A, s));
     AID_TRY(linear_bwd_data(dlstd, A, p.lstd2.w, H, ds0, H, M, A, s));
-    AID_TRY(la_bwd(p.mean0, g ? &g->mean0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.m0, dm0, H, dh2, D, s, 0, &ws));
-    AID_TRY(la_bwd(p.lstd0, g ? &g->lstd0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.s0, ds0, H, dh2, D, s, 1, &ws));
+    AID_TRY(la_bwd(p.mean0, g ? &g->mean0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.m0, dm0, H, dh2, D, s, 0, &ws, defer));
+    AID_TRY(la_bwd(p.lstd0, g ? &g->lstd0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.s0, ds0, H, dh2, D, s, 1, &ws, defer));
     // h2 = h + trunk(h)
-    AID_TRY(lla_bwd(p.trunk[2], p.trunk_ln[2], g ? &g->trunk[2] : nullptr, g ? &g->trunk_ln[2] : nullptr, ACT_RELU, nullptr, sv.tr[1].y, D, M, sv.tr[2], dh2, dA, D, ws, s));
-    AID_TRY(lla_bwd(p.trunk[1], p.trunk_ln[1], g ? &g->trunk[1] : nullptr, g ? &g->trunk_ln[1] : nullptr, ACT_RELU, nullptr, sv.tr[0].y, D, M, sv.tr[1], dA, dB, D, ws, s));
-    AID_TRY(lla_bwd(p.trunk[0], p.trunk_ln[0], g ? &g->trunk[0] : nullptr, g ? &g->trunk_ln[0] : nullptr, ACT_RELU, nullptr, sv.h, D, M, sv.tr[0], dB, dA, D, ws, s));
-    AID_TRY(add_inplace(dA, dh2, (size_t)M * D, s));   // dh
-    if (g) {
+    AID_TRY(lla_bwd(p.trunk[2], p.trunk_ln[2], g ? &g->trunk[2] : nullptr, g ? &g->trunk_ln[2] : nullptr, ACT_RELU, nullptr, sv.tr[1].y, D, M, sv.tr[2], dh2, dA, D, ws, s,
+                    defer ? slot(steps->dtr[2], D) : nullptr));
+    AID_TRY(lla_bwd(p.trunk[1], p.trunk_ln[1], g ? &g->trunk[1] : nullptr, g ? &g->trunk_ln[1] : nullptr, ACT_RELU, nullptr, sv.tr[0].y, D, M, sv.tr[1], dA, dB, D, ws, s,
+                    defer ? slot(steps->dtr[1], D) : nullptr));
+    float* dhv = defer ? dhk : dA;                       // dh = d(trunk input) + dh2 (the residual): kept per step when the gradients are deferred
+    AID_TRY(lla_bwd(p.trunk[0], p.trunk_ln[0], g ? &g->trunk[0] : nullptr, g ? &g->trunk_ln[0] : nullptr, ACT_RELU, nullptr, sv.h, D, M, sv.tr[0], dB, dhv, D, ws, s,
+                    defer ? slot(steps->dtr[0], D) : nullptr));
+    AID_TRY(add_inplace(dhv, dh2, (size_t)M * D, s));   // dh
+    if (g && !defer) {
         AID_TRY(linear_bwd_weight(dA, D, sv.e0.y, D, g->enc3.w, M, D, D, s, 1)); AID_TRY(colsum(dA, D, g->enc3.b, M, D, 1, s, &ws));
     }
-    AID_TRY(linear_bwd_data(dA, D, p.enc3.w, D, dB, D, M, D, s));
-    AID_TRY(lla_bwd(p.enc0, p.enc_ln, g ? &g->enc0 : nullptr, g ? &g->enc_ln : nullptr, ACT_RELU, nullptr, z, ldz, M, sv.e0, dB, dz, lddz, ws, s));
+    AID_TRY(linear_bwd_data(dhv, D, p.enc3.w, D, dB, D, M, D, s));
+    AID_TRY(lla_bwd(p.enc0, p.enc_ln, g ? &g->enc0 : nullptr, g ? &g->enc_ln : nullptr, ACT_RELU, nullptr, z, ldz, M, sv.e0, dB, dz, lddz, ws, s,
+                    defer ? slot(steps->de0, D) : nullptr));
     ws.release(mark);
     return AID_OK;
 }

@@ -502,3 +502,31 @@ def test_stream_hint_slots_are_freed_when_cleared(nat):
         nat.stream_hint(s, 1)
     for s in streams[:16]:
         nat.stream_hint(s, 0)
+
+
+def test_grouped_weight_gradients(nat):
+    """csrc/gemm_group.hip: every dW += dY^T X (and db += colsum dY) of a backward pass in one launch.  Ragged problems (N or K = 17, 6, 1: the
+    score head / latent projection / cte0 shapes), a contraction that is not a multiple of the 32-row stage, two segments into one gradient
+    (the two adjoint streams of the gradient-penalty pass), more problems than one launch holds (the queue flushes in between), accumulation
+    on top of existing gradients.  Reference: fp64 matmul."""
+    rng = np.random.default_rng(5)
+    shapes = [(256, 512, 512), (256, 2048, 512), (256, 512, 2048), (256, 17, 256), (256, 512, 17), (250, 128, 1), (37, 6, 256), (256, 13312, 512),
+              (512, 256, 256)] + [(64, 96, 40)] * 40
+    dW, dy, x, db, ref_w, ref_b = [], [], [], [], [], []
+    for (m, n, k) in shapes:
+        g, a = rng.standard_normal((m, n)).astype(np.float32), rng.standard_normal((m, k)).astype(np.float32)
+        w0, b0 = rng.standard_normal((n, k)).astype(np.float32), rng.standard_normal(n).astype(np.float32)
+        dW.append(torch.from_numpy(w0.copy()).cuda()); dy.append(torch.from_numpy(g).cuda()); x.append(torch.from_numpy(a).cuda())
+        db.append(torch.from_numpy(b0.copy()).cuda())
+        ref_w.append(w0.astype(np.float64) + g.astype(np.float64).T @ a.astype(np.float64)); ref_b.append(b0.astype(np.float64) + g.astype(np.float64).sum(0))
+    # a second segment for problem 1 (same dW object, listed right behind it; no bias contribution)
+    g2, a2 = rng.standard_normal((256, 2048)).astype(np.float32), rng.standard_normal((256, 512)).astype(np.float32)
+    dW.insert(2, dW[1]); dy.insert(2, torch.from_numpy(g2).cuda()); x.insert(2, torch.from_numpy(a2).cuda()); db.insert(2, None)
+    ref_w[1] = ref_w[1] + g2.astype(np.float64).T @ a2.astype(np.float64)
+    nat.gemm_group_tn(dW, dy, x, [d if d is not None else None for d in db])
+    torch.cuda.synchronize()
+    outs_w = [w for i, w in enumerate(dW) if i != 2]; outs_b = [b for i, b in enumerate(db) if i != 2]
+    for (m, n, k), w, b, rw, rb in zip(shapes, outs_w, outs_b, ref_w, ref_b):
+        tol = 2e-5 * np.sqrt(m) * (2 if (n, k) == (2048, 512) else 1)
+        np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=1e-5, atol=tol, err_msg=str((m, n, k)))
+        np.testing.assert_allclose(b.cpu().numpy(), rb, rtol=1e-5, atol=tol, err_msg=str((m, n, k)))

@@ -137,6 +137,7 @@ struct ProfScope {
     int id; hipStream_t s; bool on; hipEvent_t e0, e1; double flops, bytes; int m = 0, n = 0, k = 0, layout = 0, variant = 0;
     ProfScope(int id, hipStream_t s, double flops, double bytes);
     ~ProfScope();
+    void cancel();          // drop this record (the launch is accounted for by a nested scope)
 };
 
 // tanh(softplus(x)) = n / (n + 2) with n = e^x (e^x + 2): the same function as tanhf(log1pf(expf(x))) with one exponential and one division

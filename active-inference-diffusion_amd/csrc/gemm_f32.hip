@@ -25,6 +25,7 @@
 #include <atomic>
 #include <mutex>
 #include "aid_common.h"
+#include "rowwise.h"
 
 namespace aid {
 
@@ -1153,6 +1154,13 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
 }
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline bool mid_route_ok(const GemmArgs& g, bool vec) {
+    if (!vec || g.a_kmajor || g.dact_pre || g.mask || g.accumulate || g.slab || g.ksplit > 1 || g.alpha != 1.f) return false;
+    if (g.b_kmajor && (g.act != ACT_NONE || g.N % 64 != 0)) return false;
+    if (!gemm_mid_ok(g.M, g.N, g.K, 1, g.act, g.A, g.lda, g.B, g.ldb) || g.N % 64 != 0) return false;
+    if (g.M > 1024) { const long wg = (long)(g.M / 80) * (g.N / 64); return g.M % 80 == 0 && wg >= 192 && wg <= 512; }
+    return g.N >= 2048 && g.N <= 4096;       // 8 row tiles x >= 32 column tiles
+}
 // true when the automatic dispatcher sends this problem to gemm_tile_kernel (profiling label only)
 static inline bool routes_to_tile(const GemmArgs& g) {
     return g_force_kernel == 0 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 160;
@@ -1210,6 +1218,13 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         const bool d16 = g.K % 16 == 0 && (stream_hint_get(s) & 2);
         prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.act + 8 * (g.K % (d16 ? 16 : 32) != 0) + 32 * d16; prof.variant = 23; prof.id = PROF_GEMM_TILE;
         return linear_rows(g.A, g.lda, g.B, g.ldb, g.bias, g.act, g.mask, g.ldc, g.residual, g.ldr, g.C, g.ldc, g.M, g.N, g.K, s);
+    }
+    // layers that one-workgroup-per-CU tiles fit exactly (gemm_mid.hip): K*B = 2 560 rows x 512 columns of the rollout / BPTT as 80 x 64 tiles,
+    // 129..1024 rows x >= 2048 columns (the DiT MLP's wide layer in the ELBO passes) as 8 row tiles; forward (W [N][K]) and data-gradient
+    // (W [K][N]) forms, optional pre-activation output.  The profiler records them under gemm_mid's own entry.
+    if (g_force_kernel == 0 && mid_route_ok(g, vec)) {
+        prof.cancel();
+        return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, nullptr, g.M, g.N, g.K, 1, s);
     }
     prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor;
     int r;

@@ -32,10 +32,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct MidArgs {
     const float* A; int lda;              // [M][K]
-    const float* W; int ldw;              // [N][K]
+    const float* W; int ldw;              // [N][K], or [K][N] when the kernel is instantiated with BKM (dX = dY W: the weight as stored)
     const float* bias;                    // [N] or null (ignored in slab mode)
     const float* residual; int ldr;       // optional, added after the activation (ksplit == 1 only)
     float* C; int ldc;                    // ksplit == 1: output; else unused
+    float* preact;                        // optional second output (row stride ldc): the value before the activation (training forward)
     float* slab;                          // ksplit > 1: [ksplit][M][N] raw partial products
     int M, N, K, ksplit, act;
 };
@@ -50,17 +51,27 @@ template <int ACT> __device__ __forceinline__ float mid_act(float x) {
     else return x;
 }
 
-template <int BMT, int ACT>
+// Work decomposition: 4 waves as WM x WN; a wave owns BMF x NJ accumulator blocks of 16 x 16: BM = 16 BMF WM rows, BN = 16 NJ WN columns.
+//   <BMT, 2, 2, 2>: the reverse loop's 32 BMT x 64 tiles (8 row tiles at 129..1024 rows, 128-row tiles beyond)
+//   <5, 1, 4, 1>  : 80 x 64 tiles - the rollout / BPTT layers at K*B = 2 560 rows x 512 columns are then exactly 32 x 8 = 256 workgroups, one
+//                   per CU (the 64 x 64 tiling is 320 tiles: a quarter of the CUs run two)
+// BKM: the W operand is contraction-major ([K][N], n contiguous): the data gradient dX = dY W reads the weight as stored, without a
+// transposed copy.  Its stage is kept in LDS as it arrives ([64][BN + 4]: 16-B writes) and fragments are gathered with four 4-B reads per
+// k-group (16 consecutive n at one k: conflict-free), in the shadow of the MFMAs.
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) {
-    constexpr int NT = 256, BM = 32 * BMT, BN = MID_BN, BK = MID_BK, CPR = BK / 4;
-    constexpr int A_FL = BM * BK, B_FL = BN * BK;
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int NT = 256, BM = 16 * BMF * WM, BN = 16 * NJ * WN, BK = MID_BK, CPR = BK / 4;
+    constexpr int BLD = BN + 4;                                                   // row pitch of the contraction-major W image
+    constexpr int A_FL = BM * BK, B_FL = BKM ? BK * BLD : BN * BK;
     constexpr int PA = BM * CPR / NT, PB = BN * CPR / NT, NS = PA + PB;          // float4 pieces per thread per stage
+    static_assert(PA * NT == BM * CPR && PB * NT == BN * CPR, "tile does not split into whole pieces");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                 // [2][BM][BK]
-    float* Bs = smem + 2 * A_FL;      // [2][BN][BK]
+    float* Bs = smem + 2 * A_FL;      // [2][BN][BK]  or  [2][BK][BLD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+    const int wm = (wave / WN) * (BM / WM), wn = (wave % WN) * (BN / WN);
     // tile map: T = (column tile, K slice) pairs; whole rounds of 8 pairs go one per XCD group, each with its `tiles_m` row tiles
     int tm, tn, ky;
     {
@@ -74,56 +85,66 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
     }
     const int m0 = tm * BM, n0 = tn * BN;
     const int kper = g.K / g.ksplit, kbeg = ky * kper, nk = kper / BK;
-    f32x4 acc[BMT][2];
+    f32x4 acc[BMF][NJ];
 #pragma unroll
-    for (int i = 0; i < BMT; ++i)
+    for (int i = 0; i < BMF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // staging maps: piece p < PA is an A piece, else a W piece; thread f = tid + NT p covers (row f / 16, chunk f % 16)
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // staging maps: piece p < PA is an A piece, else a W piece; thread f = tid + NT p covers (row f / 16, chunk f % 16) of a k-contiguous
+    // operand, (k f / (BN / 4), column chunk f % (BN / 4)) of the contraction-major W
     const float* src[NS]; int dst[NS];
+    const size_t wstep = BKM ? (size_t)BK * g.ldw : (size_t)BK;                   // one K stage further along W
 #pragma unroll
     for (int p = 0; p < NS; ++p) {
         const int f = tid + NT * (p < PA ? p : p - PA), row = f / CPR, c = f % CPR;
         if (p < PA) { src[p] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + kbeg + 4 * c; dst[p] = mid_off(row, c); }
-        else        { src[p] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + kbeg + 4 * c; dst[p] = 2 * A_FL + mid_off(row, c); }
+        else if (!BKM) { src[p] = g.W + (size_t)min(n0 + row, g.N - 1) * g.ldw + kbeg + 4 * c; dst[p] = 2 * A_FL + mid_off(row, c); }
+        else { const int kk = f / (BN / 4), cq = f % (BN / 4); src[p] = g.W + (size_t)(kbeg + kk) * g.ldw + n0 + 4 * cq; dst[p] = 2 * A_FL + kk * BLD + 4 * cq; }
     }
     // Prefetch distance 2: while tile kt is contracted, tile kt + 2 is loaded into the register set tile kt + 1 does not use and tile kt + 1
     // (loaded a whole stage ago) is written to the other LDS buffer: a global load has 1.5 stages (~2 us) to arrive - the weights of a block
     // are cold every denoise step (56 MB stream through 32 MB of L2) and one wave per SIMD has nobody to hide a late load behind.  With one
     // workgroup per CU registers are free (122 + 40 of 512).  The loop is unrolled by two so both sets are named statically.
     f32x4 rg0[NS], rg1[NS];
-    auto load_piece = [&](f32x4 (&rg)[NS], int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + kt * BK); };
+    auto load_piece = [&](f32x4 (&rg)[NS], int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + (p < PA ? (size_t)kt * BK : (size_t)kt * wstep)); };
     auto store_piece = [&](const f32x4 (&rg)[NS], int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
-    constexpr int NG = BK / 16, MPG = 4 * BMT * 2, NM = NG * MPG, S0 = NM / 2;
+    constexpr int NG = BK / 16, MPG = 4 * BMF * NJ, NM = NG * MPG, S0 = NM / 2;
     constexpr int LSTEP = S0 / NS > 0 ? S0 / NS : 1, SSTEP = (NM - S0) / NS > 0 ? (NM - S0) / NS : 1;
     static_assert(S0 / NS >= 1, "more staging pieces than MFMA slots in half a stage");
+    // fragments of k-group gk: a lane's four values are k = 16 gk + 4 kq + {0..3} of its row / column
+    auto read_a = [&](const float* a_s, int gk, f32x4 (&av)[BMF]) {
+#pragma unroll
+        for (int i = 0; i < BMF; ++i) av[i] = *reinterpret_cast<const f32x4*>(a_s + 16 * i * BK + (((4 * gk + kq) ^ r16) << 2));
+    };
+    auto read_b = [&](const float* b_s, int gk, f32x4 (&bv)[NJ]) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if constexpr (!BKM) bv[j] = *reinterpret_cast<const f32x4*>(b_s + 16 * j * BK + (((4 * gk + kq) ^ r16) << 2));
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = b_s[(16 * gk + 4 * kq + e) * BLD + 16 * j];
+            }
+        }
+    };
     // contract LDS buffer `cur`; first half: load tile `kt_load` into `ld`; second half: write `st` (the tile after this one) to buffer cur ^ 1
     auto stage = [&](int cur, int kt_load, f32x4 (&ld)[NS], const f32x4 (&st)[NS]) {
         const float* a_s = As + cur * A_FL + (wm + r16) * BK;
-        const float* b_s = Bs + cur * B_FL + (wn + r16) * BK;
         // (row & 15) == r16 for every fragment row of this lane: the swizzle term is lane-constant
-        f32x4 av[2][BMT], bv[2][2];
-#pragma unroll
-        for (int i = 0; i < BMT; ++i) av[0][i] = *reinterpret_cast<const f32x4*>(a_s + 16 * i * BK + ((kq ^ r16) << 2));
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bv[0][j] = *reinterpret_cast<const f32x4*>(b_s + 16 * j * BK + ((kq ^ r16) << 2));
+        const float* b_s = BKM ? Bs + cur * B_FL + wn + r16 : Bs + cur * B_FL + (wn + r16) * BK;
+        f32x4 av[2][BMF], bv[2][NJ];
+        read_a(a_s, 0, av[0]); read_b(b_s, 0, bv[0]);
 #pragma unroll
         for (int gk = 0; gk < NG; ++gk) {
             const int pc = gk & 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int i = 0; i < BMT; ++i)
+                for (int i = 0; i < BMF; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int idx = ((gk * 4 + q) * BMT + i) * 2 + j;
+                    for (int j = 0; j < NJ; ++j) {
+                        const int idx = ((gk * 4 + q) * BMF + i) * NJ + j;
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[pc][i][q], bv[pc][j][q], acc[i][j], 0, 0, 0);
-                        if (q == 0 && i == 0 && j == 1 && gk + 1 < NG) {      // next k-group's fragments, early in this group
-#pragma unroll
-                            for (int i2 = 0; i2 < BMT; ++i2) av[pc ^ 1][i2] = *reinterpret_cast<const f32x4*>(a_s + 16 * i2 * BK + (((4 * (gk + 1) + kq) ^ r16) << 2));
-#pragma unroll
-                            for (int j2 = 0; j2 < 2; ++j2) bv[pc ^ 1][j2] = *reinterpret_cast<const f32x4*>(b_s + 16 * j2 * BK + (((4 * (gk + 1) + kq) ^ r16) << 2));
-                        }
+                        if (idx % MPG == (MPG > 1 ? 1 : 0) && gk + 1 < NG) { read_a(a_s, gk + 1, av[pc ^ 1]); read_b(b_s, gk + 1, bv[pc ^ 1]); }   // next k-group's fragments, early in this group
                         if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) { load_piece(ld, idx / LSTEP, kt_load); __builtin_amdgcn_sched_barrier(0); }
                         if (idx >= S0 && (idx - S0) % SSTEP == 0 && (idx - S0) / SSTEP < NS) { store_piece(st, (idx - S0) / SSTEP, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
                     }
@@ -148,9 +169,9 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
     }
     // ---- epilogue.  C/D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + {0..3}
 #pragma unroll
-    for (int i = 0; i < BMT; ++i)
+    for (int i = 0; i < BMF; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int col = n0 + wn + 16 * j + r16;
             const float bcol = (g.ksplit == 1 && g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
@@ -159,7 +180,9 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
                 if (row < g.M && col < g.N) {
                     if (g.ksplit > 1) g.slab[((size_t)ky * g.M + row) * g.N + col] = acc[i][j][e];
                     else {
-                        float v = mid_act<ACT>(acc[i][j][e] + bcol);
+                        float v = acc[i][j][e] + bcol;
+                        if (g.preact) g.preact[(size_t)row * g.ldc + col] = v;
+                        v = mid_act<ACT>(v);
                         if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                         g.C[(size_t)row * g.ldc + col] = v;
                     }
@@ -168,54 +191,69 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
         }
 }
 
-template <int BMT, int ACT>
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 static int launch_mid(const MidArgs& g, hipStream_t s) {
-    constexpr size_t lds = sizeof(float) * 2 * ((size_t)32 * BMT * MID_BK + (size_t)MID_BN * MID_BK);
+    constexpr int BM = 16 * BMF * WM, BN = 16 * NJ * WN;
+    constexpr size_t lds = sizeof(float) * 2 * ((size_t)BM * MID_BK + (BKM ? (size_t)MID_BK * (BN + 4) : (size_t)BN * MID_BK));
     static bool attr_done = false;
     if (lds > 65536 && !attr_done) {
-        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_mid_kernel<BMT, ACT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_mid_kernel<BMF, WM, WN, NJ, ACT, BKM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_done = true;
     }
-    const int tiles_m = (g.M + 32 * BMT - 1) / (32 * BMT), tiles_n = (g.N + MID_BN - 1) / MID_BN;
-    hipLaunchKernelGGL((gemm_mid_kernel<BMT, ACT>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    hipLaunchKernelGGL((gemm_mid_kernel<BMF, WM, WN, NJ, ACT, BKM>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
     AID_LAUNCH_CHECK();
     return AID_OK;
 }
-template <int ACT>
+// 80-row tiles when they make the layer (close to) one workgroup per CU: M a multiple of 80 beyond the 8-row-tile regime
+static inline bool mid_tall80(int M, int N, int ksplit) {
+    if (M <= 1024 || M % 80 != 0 || N % MID_BN != 0) return false;
+    const long wg = (long)(M / 80) * (N / MID_BN) * ksplit;
+    return wg >= 192 && wg <= 512;
+}
+template <int ACT, bool BKM>
 static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
+    if (mid_tall80(g.M, g.N, g.ksplit)) return launch_mid<5, 1, 4, 1, ACT, BKM>(g, s);
     const int bmt = (g.M + 255) / 256;        // up to 1024 rows: 8 row tiles of BM = 32 ceil(M / 256); beyond: ceil(M / 128) tiles of 128 rows
     switch (bmt) {
-        case 1: return launch_mid<1, ACT>(g, s);
-        case 2: return launch_mid<2, ACT>(g, s);
-        case 3: return launch_mid<3, ACT>(g, s);
-        default: return launch_mid<4, ACT>(g, s);
+        case 1: return launch_mid<1, 2, 2, 2, ACT, BKM>(g, s);
+        case 2: return launch_mid<2, 2, 2, 2, ACT, BKM>(g, s);
+        case 3: return launch_mid<3, 2, 2, 2, ACT, BKM>(g, s);
+        default: return launch_mid<4, 2, 2, 2, ACT, BKM>(g, s);
     }
 }
 
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
     const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
     return al && M > 128 && M <= MID_MAX_M && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
-          
            (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU || act == ACT_RELU);
 }
 
-// ksplit == 1: C = act(A W^T + bias) + residual.  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T (raw partials; bias / act / residual are the
-// consumer's: adaln_sum or slab_sum); act must be NONE then.
-int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
-             float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
+// ksplit == 1: C = act(A W^T + bias) + residual (preact, optional: the value before the activation).  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T
+// (raw partials; bias / act / residual are the consumer's: adaln_sum or slab_sum); act must be NONE then.
+// w_kmajor: W is [K][N] (row stride ldw) - the data-gradient form; needs N % 64 == 0 and no split.
+int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
     AID_REQUIRE(gemm_mid_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
-    AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && act == ACT_NONE && !residual), AID_E_SHAPE, "gemm_mid: split-K writes raw slabs only");
+    AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && act == ACT_NONE && !residual && !preact), AID_E_SHAPE, "gemm_mid: split-K writes raw slabs only");
+    AID_REQUIRE(!w_kmajor || (N % MID_BN == 0 && act == ACT_NONE), AID_E_SHAPE, "gemm_mid: contraction-major W needs N %% 64 == 0 and no activation (N=%d)", N);
     MidArgs g; memset(&g, 0, sizeof(g));
-    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.slab = slab;
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.preact = preact; g.slab = slab;
     g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
     ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
-    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * ((M + 255) / 256 > 4 ? 4 : (M + 255) / 256) + act; prof.variant = 22;      // layout field: 8 BMT + act = the instantiation
+    const int bmt = mid_tall80(M, N, ksplit) ? 5 : ((M + 255) / 256 > 4 ? 4 : (M + 255) / 256);
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * bmt + act + (w_kmajor ? 64 : 0); prof.variant = 22;      // layout field: 8 BMF + act (+ 64: contraction-major W) = the instantiation
+    if (w_kmajor) return launch_mid_bm<ACT_NONE, true>(g, s);
     switch (act) {
-        case ACT_GELU: return launch_mid_bm<ACT_GELU>(g, s);
-        case ACT_SILU: return launch_mid_bm<ACT_SILU>(g, s);
-        case ACT_RELU: return launch_mid_bm<ACT_RELU>(g, s);
-        default: return launch_mid_bm<ACT_NONE>(g, s);
+        case ACT_GELU: return launch_mid_bm<ACT_GELU, false>(g, s);
+        case ACT_SILU: return launch_mid_bm<ACT_SILU, false>(g, s);
+        case ACT_RELU: return launch_mid_bm<ACT_RELU, false>(g, s);
+        default: return launch_mid_bm<ACT_NONE, false>(g, s);
     }
+}
+int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+             float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
+    return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s);
 }
 
 // ---- consumers of the split-K slabs ---------------------------------------------------------------------------------------------

@@ -56,6 +56,9 @@ inline int mid_ksplit(int M) { return M <= 1024 ? 4 : (M <= 2048 ? 2 : 1); }
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s);
+// general form: w_kmajor = W stored [K][N] (the data gradient dX = dY W of a Linear: the weight as it is), preact = optional second output
+int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
+                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s);
 // x_new = res + bias + sum of `nslab` slabs [M,D] (fixed order) -> xout (optional);  y = LN(x_new) (1 + scale) + shift (adaLN, mod row = [scale | shift])
 bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
                   const float* y, int ldy);

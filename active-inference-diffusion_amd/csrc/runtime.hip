@@ -24,6 +24,10 @@ ProfScope::ProfScope(int id_, hipStream_t s_, double fl, double by) : id(id_), s
     if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { on = false; return; }
     (void)hipEventRecord(e0, s);
 }
+void ProfScope::cancel() {
+    if (!on) return;
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); on = false;
+}
 ProfScope::~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(e1, s);

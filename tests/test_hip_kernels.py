@@ -530,3 +530,21 @@ def test_grouped_weight_gradients(nat):
         tol = 2e-5 * np.sqrt(m) * (2 if (n, k) == (2048, 512) else 1)
         np.testing.assert_allclose(w.cpu().numpy(), rw, rtol=1e-5, atol=tol, err_msg=str((m, n, k)))
         np.testing.assert_allclose(b.cpu().numpy(), rb, rtol=1e-5, atol=tol, err_msg=str((m, n, k)))
+
+
+@pytest.mark.parametrize("M,N,K,lay,act", [(2560, 512, 512, "nt", "none"), (2560, 512, 512, "nn", "none"), (2560, 512, 512, "nt", "relu"), (256, 2048, 512, "nt", "gelu"),
+                                           (256, 2048, 512, "nn", "none"), (512, 2048, 512, "nn", "none"), (1280, 1024, 256, "nt", "silu"), (3200, 512, 128, "nn", "none")])
+def test_gemm_mid_routed_shapes(nat, M, N, K, lay, act):
+    """Shapes gemm_f32 hands to the one-workgroup-per-CU kernel (csrc/gemm_mid.hip): 80 x 64 tiles for the rollout's 2 560-row layers, 8 row
+    tiles for 129..1024 rows x >= 2048 columns; W as [N][K] (forward) and as [K][N] (data gradient), bias + activation + residual."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N) if lay == "nn" else (N, K)).astype(np.float32) / np.sqrt(K)
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ (W if lay == "nn" else W.T).astype(np.float64) + b
+    f = {"none": lambda x: x, "relu": lambda x: np.maximum(x, 0), "silu": lambda x: x / (1 + np.exp(-x)),
+         "gelu": lambda x: 0.5 * x * (1 + np.vectorize(__import__("math").erf)(x / np.sqrt(2)))}[act]
+    ref = f(ref) + R
+    C = torch.empty(M, N, device="cuda")
+    nat.gemm(dev(A), dev(W), C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=dev(b), act=act, residual=dev(R), ldr=N)
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))

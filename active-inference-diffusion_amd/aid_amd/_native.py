@@ -325,7 +325,7 @@ def score_forward(table: AidScoreNet, z_t, t, obs, continuous: bool, drop_mask=N
     return out
 
 
-def gemm_group_tn(dW, dy, x, db=None):
+def gemm_group_tn(dW, dy, x, db=None, scratch=None):
     """dW[i] += dy[i]^T x[i] (and db[i] += dy[i].sum(0)) for every i in ONE launch (csrc/gemm_group.hip).  Lists of dense row-major tensors;
     consecutive entries with the same dW tensor are contracted into the same accumulators."""
     n = len(dW)
@@ -335,7 +335,8 @@ def gemm_group_tn(dW, dy, x, db=None):
         assert g.shape[0] == a.shape[0] and w.shape == (g.shape[1], a.shape[1])
     check(lib().aid_gemm_group_tn(n, PP(*[_ptr(t).value for t in dW]), PP(*[(_ptr(t).value or 0) for t in db]) if db is not None else None,
                                   PP(*[_ptr(t).value for t in dy]), PP(*[_ptr(t).value for t in x]), II(*[g.shape[0] for g in dy]),
-                                  II(*[w.shape[0] for w in dW]), II(*[w.shape[1] for w in dW]), _stream()), "aid_gemm_group_tn")
+                                  II(*[w.shape[0] for w in dW]), II(*[w.shape[1] for w in dW]), _ptr(scratch),
+                                  C.c_size_t(scratch.numel() if scratch is not None else 0), _stream()), "aid_gemm_group_tn")
 
 
 def gradient_penalty(table: AidScoreNet, z, t, obs, continuous: bool, drop_mask=None, ws: Workspace = None):

@@ -118,12 +118,15 @@ inline int linear_bwd_weight(const float* dy, int lddy, const float* x, int ldx,
 
 // ---- grouped weight gradients (gemm_group.hip): the dW / db leaves of a backward pass are recorded while the adjoint chain runs and computed
 // by ONE launch at the end of the pass.  The operands a recorded problem points at must stay untouched until flush().
-constexpr int GROUP_MAX_SEG = 2, GROUP_MAX_PROB = 36;                 // 36 x 112 B + 8 B: the table travels in the kernel arguments (< 4 KB)
+constexpr int GROUP_MAX_SEG = 2, GROUP_MAX_PROB = 31;                 // 31 x 128 B + 8 B: the table travels in the kernel arguments (< 4 KB)
 struct GroupSeg { const float* a; const float* b; int lda, ldb, m, _pad; };              // a = dY [m, N], b = X [m, K]
-struct GroupProb { float* C; float* db; int ldc, N, K, nseg, tile0, tiles_k, vec, _pad; GroupSeg seg[GROUP_MAX_SEG]; };   // C [N, K] += sum_s a_s^T b_s
+// C [N, K] += sum_s a_s^T b_s.  split > 1 (one-segment problems with a long contraction): the rows are cut into `split` chunks, each chunk's
+// workgroups write raw partial tiles to part [split][N][K] (+ bias partials behind them) and a second small launch folds them in chunk order.
+struct GroupProb { float* C; float* db; float* part; int ldc, N, K, nseg, tile0, tiles_k, vec, split, tiles_n, _pad; GroupSeg seg[GROUP_MAX_SEG]; };
 struct GroupArgs { int nprob, _pad; GroupProb p[GROUP_MAX_PROB]; };
 struct GradQueue {
     GroupArgs args; hipStream_t s; double flop;
+    float* scratch = nullptr; size_t scratch_floats = 0, scratch_used = 0;       // optional, caller-owned: room for the partial tiles of split problems
     explicit GradQueue(hipStream_t st) : s(st), flop(0.0) { args.nprob = 0; args._pad = 0; }
     // dW[N, K] (row stride ldc) += dy^T x over M rows; db[N] += colsum(dy) when db != null.  A call with the same dW as the previous one
     // (and no db) becomes a second segment of that problem.

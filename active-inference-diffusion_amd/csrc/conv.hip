@@ -949,7 +949,12 @@ size_t aid_conv_decoder_workspace(const AidConvDecoder* d, int R) {
     const size_t H = d->hidden, hw = 21 * 21;
     size_t n = 0;
     n += (size_t)R * (4 * H) * 2 + (size_t)R * H * hw * 2;                  // latent_proj activations
-    n += 4u * 1024 * 1024;                                                  // W_eff images of every conv (< 3.2 M floats)
+    {   // W_eff images of every conv (conv_decoder_fwd's prep_weight calls: [cout][9 cin padded to 32] each, + a [cout] vector)
+        const size_t cin[4] = {H, H, H / 2, H / 4}, cout[4] = {H, H / 2, H / 4, H / 8};
+        auto img = [](size_t ci, size_t co, size_t k) { return co * ((ci * k * k + 31) / 32 * 32) + co + 128; };
+        for (int i = 0; i < 4; ++i) n += img(cin[i], i ? 4 * cout[i] : cout[i], 3) + img(cout[i], cout[i], 3) + (i ? img(cin[i], 4 * cout[i], 1) : 0);
+        n += img(H / 8, 32, 3) + img(32, 32, 3) + img(32, 3, 3) + 4096;
+    }
     const size_t amax = (size_t)R * (3528 * H > 32u * 168 * 168 ? 3528 * H : 32u * 168 * 168);   // largest stage: (H/8) x 168^2 = 8H x 21^2 per image
     n += amax * 5;                                                          // ping-pong activations + conv outputs
     n += (size_t)R * 168 * 168 * (9 * H / 8 > 288 ? 9 * H / 8 + 32 : 288 + 32);   // im2col of the widest 168x168 conv

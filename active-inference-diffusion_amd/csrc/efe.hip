@@ -308,6 +308,7 @@ size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec,
     size_t n = dec ? mine_ws_bytes(*dec, (int)(H * cfg->K), cfg->S, B) : 0;     // the estimator runs over all H horizon steps in one pass
     n += sizeof(float) * H * M * (48 * D + 128 + 2 * pol->L);                   // per-step saved activations (policy, dynamics, reward, value) + the policy adjoints the deferred weight gradients read
     n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
+    n += sizeof(float) * 8 * (4 * D * D + 2 * (size_t)pol->mean0.out * D + 2 * (size_t)pol->A * pol->mean0.out + D * (size_t)pol->L + 16 * D) + 4096;      // partial tiles of the split policy-gradient contractions
     n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
     n += sizeof(int32_t) * H * R + (1 << 20);
     return n;
@@ -430,6 +431,11 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
     // the policy's weight / bias gradients: dW = sum_t adj_t^T x_t as ONE contraction per layer over the H*K*B rows of the [H][K*B][.] buffers,
     // all nine layers in one grouped launch (45 launches inside the BPTT chain before)
     GradQueue gq(s);
+    {   // room for the partial tiles of the long contractions (8 row chunks of every policy gradient)
+        const size_t Dp = pol->D, Hh = pol->mean0.out;
+        gq.scratch_floats = 8 * (4 * Dp * Dp + 2 * Hh * Dp + 2 * (size_t)pol->A * Hh + Dp * (size_t)L + 16 * Dp);
+        gq.scratch = ws.f32(gq.scratch_floats); AID_WS_OK(ws);
+    }
     AID_TRY(policy_bptt_grads(*pol, *pgrads, psteps, cur_all, L, gq));
     AID_TRY(gq.flush());
     return AID_OK;

@@ -56,7 +56,7 @@ __device__ __forceinline__ void grp_store(float* __restrict__ S, int tid, const 
 }
 
 template <bool VEC>
-__device__ __forceinline__ void grp_tile(const GroupProb& p, int tn, int tk, float* smem) {
+__device__ __forceinline__ void grp_tile(const GroupProb& p, int tn, int tk, int sp, float* smem) {
     float* As = smem;                 // [2][32][68]
     float* Bs = smem + 2 * GIMG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -70,7 +70,11 @@ __device__ __forceinline__ void grp_tile(const GroupProb& p, int tn, int tk, flo
     const bool do_db = p.db != nullptr && tk == 0;
     g_f32x4 ra[2], rb[2];
     for (int sg = 0; sg < p.nseg; ++sg) {
-        const GroupSeg& q = p.seg[sg];
+        GroupSeg q = p.seg[sg];
+        if (p.split > 1) {                                 // this workgroup's chunk of the contraction rows (whole 32-row stages)
+            const int chunk = ((q.m + p.split - 1) / p.split + GB - 1) / GB * GB, r0 = min(q.m, sp * chunk), r1 = min(q.m, r0 + chunk);
+            q.a += (size_t)r0 * q.lda; q.b += (size_t)r0 * q.ldb; q.m = r1 - r0;
+        }
         const int nst = (q.m + GB - 1) / GB;
         if (nst == 0) continue;
         grp_load<VEC>(q.a, q.lda, 0, n0, q.m, p.N, tid, ra);
@@ -109,9 +113,15 @@ __device__ __forceinline__ void grp_tile(const GroupProb& p, int tn, int tk, flo
 #pragma clang loop unroll(full)
     for (int r = 0; r < 16; ++r) {
         const int row = n0 + wn + (r & 3) + 8 * (r >> 2) + 4 * h, col = k0 + wk + li;
-        if (row < p.N && col < p.K) { float* c = p.C + (size_t)row * p.ldc + col; *c = *c + acc[r]; }
+        if (row < p.N && col < p.K) {
+            if (p.split > 1) p.part[((size_t)sp * p.N + row) * p.K + col] = acc[r];
+            else { float* c = p.C + (size_t)row * p.ldc + col; *c = *c + acc[r]; }
+        }
     }
-    if (do_db && tid < GT && n0 + tid < p.N) p.db[n0 + tid] += colsum;
+    if (do_db && tid < GT && n0 + tid < p.N) {
+        if (p.split > 1) p.part[(size_t)p.split * p.N * p.K + (size_t)sp * p.N + n0 + tid] = colsum;
+        else p.db[n0 + tid] += colsum;
+    }
 }
 
 __global__ void __launch_bounds__(256) gemm_group_tn_kernel(GroupArgs g) {
@@ -120,9 +130,28 @@ __global__ void __launch_bounds__(256) gemm_group_tn_kernel(GroupArgs g) {
     int pi = 0;
     while (pi + 1 < g.nprob && b >= g.p[pi + 1].tile0) ++pi;          // uniform scalar walk over the prefix table
     const GroupProb& p = g.p[pi];
-    const int t = b - p.tile0, tn = t / p.tiles_k, tk = t % p.tiles_k;
-    if (p.vec) grp_tile<true>(p, tn, tk, smem);
-    else grp_tile<false>(p, tn, tk, smem);
+    const int per = p.tiles_n * p.tiles_k, t = b - p.tile0, sp = t / per, tt = t % per, tn = tt / p.tiles_k, tk = tt % p.tiles_k;
+    if (p.vec) grp_tile<true>(p, tn, tk, sp, smem);
+    else grp_tile<false>(p, tn, tk, sp, smem);
+}
+
+// second pass for split problems: C += part[0] + part[1] + ... (chunk order: reproducible), db likewise
+__global__ void __launch_bounds__(256) gemm_group_fold_kernel(GroupArgs g) {
+    const GroupProb& p = g.p[blockIdx.y];
+    if (p.split <= 1) return;
+    const size_t nk = (size_t)p.N * p.K, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nk; i += stride) {
+        float v = 0.f;
+        for (int sp = 0; sp < p.split; ++sp) v += p.part[(size_t)sp * nk + i];
+        const size_t row = i / p.K, col = i % p.K;
+        float* c = p.C + row * p.ldc + col; *c = *c + v;
+    }
+    if (p.db && blockIdx.x == 0)
+        for (int n = threadIdx.x; n < p.N; n += blockDim.x) {
+            float v = 0.f;
+            for (int sp = 0; sp < p.split; ++sp) v += p.part[(size_t)p.split * nk + (size_t)sp * p.N + n];
+            p.db[n] += v;
+        }
 }
 
 int GradQueue::add(float* dW, int ldc, int N, int K, const float* dy, int lddy, const float* x, int ldx, int M, float* db) {
@@ -146,21 +175,40 @@ int GradQueue::add(float* dW, int ldc, int N, int K, const float* dy, int lddy, 
     GroupProb& p = args.p[args.nprob++];
     memset(&p, 0, sizeof(p));
     p.C = dW; p.db = db; p.ldc = ldc; p.N = N; p.K = K; p.nseg = 1; p.seg[0] = sgm; p.vec = al ? 1 : 0;
-    p.tiles_k = (K + GT - 1) / GT;
+    p.tiles_k = (K + GT - 1) / GT; p.tiles_n = (N + GT - 1) / GT; p.split = 1; p.part = nullptr;
     flop += 2.0 * M * N * K;
     return AID_OK;
 }
 
 int GradQueue::flush() {
     if (args.nprob == 0) return AID_OK;
-    int tiles = 0;
-    for (int i = 0; i < args.nprob; ++i) { args.p[i].tile0 = tiles; tiles += ((args.p[i].N + GT - 1) / GT) * args.p[i].tiles_k; }
+    // a long contraction over few output tiles (the BPTT's H*K*B = 12 800 rows onto a 512 x 512 gradient: 64 tiles x 400 stages) leaves most CUs
+    // idle and the busy ones latency-bound: cut its rows into chunks of >= 1 024, one set of tiles per chunk, folded by a second small launch
+    int tiles = 0, nsplit = 0;
+    size_t max_nk = 0;
+    for (int i = 0; i < args.nprob; ++i) {
+        GroupProb& p = args.p[i];
+        const int m = p.seg[0].m;
+        if (p.nseg == 1 && m >= 4096 && scratch) {
+            int sp = m / 1536; sp = sp > 8 ? 8 : sp;
+            const size_t need = (size_t)sp * ((size_t)p.N * p.K + p.N);
+            if (sp > 1 && scratch_used + need <= scratch_floats) {
+                p.split = sp; p.part = scratch + scratch_used; scratch_used += need; ++nsplit;
+                if ((size_t)p.N * p.K > max_nk) max_nk = (size_t)p.N * p.K;
+            }
+        }
+        p.tile0 = tiles; tiles += p.tiles_n * p.tiles_k * p.split;
+    }
     {
         ProfScope prof(PROF_GEMM_TILE, s, flop, 0.0);
         prof.m = tiles; prof.n = args.nprob; prof.k = 0; prof.layout = 3; prof.variant = 30;
         hipLaunchKernelGGL(gemm_group_tn_kernel, dim3(tiles), dim3(256), sizeof(float) * 4 * GIMG, s, args);
+        if (nsplit) {
+            const unsigned bx = (unsigned)((max_nk + 1023) / 1024 > 256 ? 256 : (max_nk + 1023) / 1024);
+            hipLaunchKernelGGL(gemm_group_fold_kernel, dim3(bx ? bx : 1, args.nprob), dim3(256), 0, s, args);
+        }
     }
-    args.nprob = 0; flop = 0.0;
+    args.nprob = 0; flop = 0.0; scratch_used = 0;
     AID_LAUNCH_CHECK();
     return AID_OK;
 }
@@ -171,9 +219,10 @@ using namespace aid;
 extern "C" {
 // Test / bench entry for the grouped weight-gradient kernel: `n` problems dW_i[N_i, K_i] += dY_i^T X_i (+ db_i += colsum dY_i), one launch.
 int aid_gemm_group_tn(int n, float* const* dW, float* const* db, const float* const* dy, const float* const* x, const int* M, const int* N, const int* K,
-                      void* stream) {
+                      float* scratch, size_t scratch_floats, void* stream) {
     AID_REQUIRE(n >= 0 && dW && dy && x && M && N && K, AID_E_NULL, "aid_gemm_group_tn: null argument");
     GradQueue q((hipStream_t)stream);
+    q.scratch = scratch; q.scratch_floats = scratch ? scratch_floats : 0;
     for (int i = 0; i < n; ++i) AID_TRY(q.add(dW[i], K[i], N[i], K[i], dy[i], N[i], x[i], K[i], M[i], db ? db[i] : nullptr));
     return q.flush();
 }

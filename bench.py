@@ -324,9 +324,42 @@ def other_configs(device):
     dt, m = timed(agent)
     fl4 = 2 * 4.81e9 * b4 + 2 * NSTEPS * b4 * ALGO_FLOP_PER_DENOISE_ROW_STEP + 0.12e12 + 0.2e12
     res["cfg4_pixel_b256"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_tflops": fl4 / dt / 1e12, "frac_of_f32_mfma_peak": fl4 / dt / PEAK_F32_MFMA,
-                              "algorithmic_flop_per_step": fl4, "replay": "uint8 frames", "finite": bool(all(np.isfinite(v) for v in m.values()))}
+                              "algorithmic_flop_per_step": fl4, "replay": "uint8 frames", "pixel_epistemic": False,
+                              "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    res["pixel_epistemic_f1"] = pixel_epistemic_probe(agent)
     del agent; torch.cuda.empty_cache()
     return res
+
+
+def pixel_epistemic_probe(agent, rows=64, S=2):
+    """the gradient-free pixel estimator (ConvDecoder [R,3,168,168] images of z and four perturbed copies -> pixel_processor convs ->
+    SpatialAttentionAggregator -> projector / MINE tail; encoder/visual_encoders.py:228-459, core/active_inference.py:865-883, 977-983,
+    utils/util.py:7-75).  It is opt-in inside the pixel train_step (ai.pixel_epistemic; off in cfg4_pixel_b256 above): at the defaults it is
+    H*K*S*B = 128 000 sample rows x 5 decodes.  Measured here at a stated REDUCED size: one estimator call on `rows` belief rows with S = 2
+    ambiguity samples (K = 1), and the ConvDecoder alone on the same number of images.  FLOPs = the library's own count of its GEMM launches."""
+    from aid_amd import _native as nat
+    ai = agent.active_inference
+    if not hasattr(ai, "epistemic_estimator") or not hasattr(ai, "_pepi_tab"):
+        return None
+    dec, epi = ai.observation_decoder._tab.get(ai.observation_decoder), ai._pepi_tab.get(ai.epistemic_estimator)
+    z = torch.randn(rows, ai.latent_dim, device=agent.device)
+
+    def run(fn):
+        fn(); torch.cuda.synchronize()
+        nat.prof_enable(True); nat.prof_reset(); fn(); torch.cuda.synchronize()
+        fl = nat.prof_read(nat.PROF_GEMM)["flops"] + nat.prof_read(nat.PROF_GEMM_TILE)["flops"]
+        nat.prof_enable(False); nat.prof_reset()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts))
+        return {"ms": 1e3 * dt, "gemm_flop": fl, "achieved": fl / dt / 1e12, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK_F32_MFMA}
+    out = {"config": {"belief_rows": rows, "ambiguity_samples": S, "trajectories": 1, "latent_dim": ai.latent_dim, "note": "REDUCED size; the default pixel "
+                      "train_step would run this over K*B = 2 560 rows with S = 10, five times"}}
+    out["conv_decoder_forward"] = dict(run(lambda: nat.conv_decoder_forward(dec, z, ws=ai._ws)), images=rows)
+    out["pixel_epistemic_value"] = dict(run(lambda: nat.pixel_epistemic_value(dec, epi, z, 1, S, train=ai.training, seed=ai.noise.seed, offset=ai.noise.next_offset(),
+                                                                              ws=ai._ws)), sample_rows=rows * S, decodes=5 * rows * S)
+    return out
 
 
 def self_launch(n: int) -> int:

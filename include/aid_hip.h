@@ -86,9 +86,11 @@ int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float*
                         int ksplit, void* stream);
 /* n weight-gradient problems dW_i[N_i, K_i] += dY_i[M_i, N_i]^T X_i[M_i, K_i] (row-major, dense), and db_i[N_i] += column sums of dY_i when
  * db / db[i] is non-null, in ONE launch (csrc/gemm_group.hip: what the backward passes of aid_elbo_step / aid_efe_step do with all their
- * parameter gradients).  Two consecutive problems with the same dW are contracted into the same accumulators.  Unit-test / bench entry. */
+ * parameter gradients).  Two consecutive problems with the same dW are contracted into the same accumulators.  scratch (optional, scratch_floats
+ * floats): with it, one-segment problems over >= 4 096 rows are cut into up to 8 row chunks whose partial tiles a second launch folds in
+ * chunk order (the BPTT's contractions over H*K*B rows).  Unit-test / bench entry. */
 int aid_gemm_group_tn(int n, float* const* dW, float* const* db, const float* const* dy, const float* const* x, const int* M, const int* N, const int* K,
-                      void* stream);
+                      float* scratch, size_t scratch_floats, void* stream);
 /* TESTS / BENCHES ONLY - not part of the product path, process-wide and not thread-safe: kernel-selection override.  0 auto, 1 panel32,
  * 2 ring64, 4 tile64, 6 splitk, 8 thin TN (weight gradients of narrow layers), 9 / 11 gemm_big_kernel with prefetch distance 2 / 1,
  * 10 skinny (M <= 32 rows: act() / collector batches), 14 panel128, 15 panel64; bit 8 selects the XCD-grouped tile map of gemm_big_kernel. */

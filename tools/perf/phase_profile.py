@@ -13,6 +13,16 @@ from aid_amd import _native as nat
 
 what = sys.argv[1]
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+if what.startswith("pixel_epistemic"):        # SURVEY 8(f)-1 at the reduced size bench.py's pixel_epistemic_f1 reports (64 belief rows, S = 2)
+    import aid_amd
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=64, efe_horizon=1, latent_dim=128, hidden_dim=512, pixel_observation=True)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=4)
+    class Env4: observation_space, action_space = bench._Box((3, 3, 84, 84)), bench._Box((6,))
+    agent = aid_amd.DiffusionPixelAgent(Env4(), cfg, aid_amd.TrainingConfig(buffer_size=64), aid_amd.PixelObservationConfig())
+    for _ in range(reps):
+        r = bench.pixel_epistemic_probe(agent)
+    print("ok", what, {k: (round(v["ms"], 2), round(v["achieved"], 1)) for k, v in r.items() if k != "config"})
+    sys.exit(0)
 agent = bench.make_agent(torch.device("cuda"))
 ai, cfg = agent.active_inference, agent.config
 B, N = cfg.batch_size, cfg.diffusion.num_diffusion_steps

@@ -59,7 +59,7 @@ template <int ACT> __device__ __forceinline__ float mid_act(float x) {
 // transposed copy.  Its stage is kept in LDS as it arrives ([64][BN + 4]: 16-B writes) and fragments are gathered with four 4-B reads per
 // k-group (16 consecutive n at one k: conflict-free), in the shadow of the MFMAs.
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
-__global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) {
+__device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int tiles_n) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT = 256, BM = 16 * BMF * WM, BN = 16 * NJ * WN, BK = MID_BK, CPR = BK / 4;
     constexpr int BLD = BN + 4;                                                   // row pitch of the contraction-major W image
@@ -192,6 +192,14 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
 }
 
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
+__global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n); }
+// The 32-row tile (129..256 rows: the three concurrent 256-row belief chains of a train_step) with its registers capped at 512 / 3: its
+// workgroup is 48 KB of LDS, so three fit a CU - but at the 184 VGPRs the compiler takes by itself only two waves fit a SIMD and the third
+// chain's workgroup waits for a slot (three chains overlapped 1.63x, exactly what two resident workgroups give).
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
+__global__ void __launch_bounds__(256, 3) gemm_mid_kernel_o3(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n); }
+
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 static int launch_mid(const MidArgs& g, hipStream_t s) {
     constexpr int BM = 16 * BMF * WM, BN = 16 * NJ * WN;
     constexpr size_t lds = sizeof(float) * 2 * ((size_t)BM * MID_BK + (BKM ? (size_t)MID_BK * (BN + 4) : (size_t)BN * MID_BK));
@@ -201,7 +209,8 @@ static int launch_mid(const MidArgs& g, hipStream_t s) {
         attr_done = true;
     }
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_mid_kernel<BMF, WM, WN, NJ, ACT, BKM>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
+    if constexpr (BMF == 1 && WM == 2) hipLaunchKernelGGL((gemm_mid_kernel_o3<BMF, WM, WN, NJ, ACT, BKM>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
+    else hipLaunchKernelGGL((gemm_mid_kernel<BMF, WM, WN, NJ, ACT, BKM>), dim3(tiles_m * tiles_n * g.ksplit), dim3(256), lds, s, g, tiles_m, tiles_n);
     AID_LAUNCH_CHECK();
     return AID_OK;
 }

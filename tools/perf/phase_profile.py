@@ -59,6 +59,7 @@ fn = {"elbo": elbo, "rollout_bptt": lambda: efe(True), "efe": lambda: efe(False)
       "chain1": lambda: ai._denoise_chains([obs], [None], None, N, train, [torch.cuda.current_stream()]),
       "chain1_direct": lambda: ai.denoise_only(obs, ws=ai._ws),          # the same 256-row loop launched kernel by kernel (PMC passes: no graph replay)
       "chains3": lambda: ai.denoise_many([next_obs, obs, next_obs]),
+      "merged3": lambda: (setattr(ai, "concurrent_belief_loops", False), ai.denoise_many([next_obs, obs, next_obs]))[1],      # ONE 768-row loop
       "value_dynamics": value_dyn, "optimiser": lambda: agent.score_optimizer.step(reduce=False)}[what.replace("_cold", "")]
 dump = os.environ.get("AID_PHASE_DUMP")        # per-launch HIP-event timings of ONE call (tools/perf/launch_table.py reads the CSV)
 if dump:

@@ -325,6 +325,30 @@ def score_forward(table: AidScoreNet, z_t, t, obs, continuous: bool, drop_mask=N
     return out
 
 
+def conv3_igemm(W, x_cnhw, stride: int):
+    """3x3 conv, pad 1, as an implicit GEMM.  W [Cout, ldw] (ldw >= 9 Cin, % 4 == 0), x [Cin, B, Hi, Hi] -> [Cout, B, Ho, Ho]"""
+    Cin, B, Hi, _ = x_cnhw.shape; Cout = W.shape[0]
+    Ho = (Hi + 2 - 3) // stride + 1
+    out = torch.empty(Cout, B, Ho, Ho, device=W.device, dtype=torch.float32)
+    check(lib().aid_conv3_igemm(_ptr(W), W.shape[1], _ptr(x_cnhw), _ptr(out), Cin, Cout, B, Hi, Ho, stride, _stream()), "aid_conv3_igemm")
+    return out
+
+
+def conv3_flip_weights(W, Cin: int):
+    Cout = W.shape[0]; ldwt = (Cout * 9 + 3) // 4 * 4
+    Wt = torch.empty(Cin, ldwt, device=W.device, dtype=torch.float32)
+    check(lib().aid_conv3_flip_weights(_ptr(W), W.shape[1], _ptr(Wt), ldwt, Cin, Cout, _stream()), "aid_conv3_flip_weights")
+    return Wt
+
+
+def conv3_igemm_dw(dy_cnhw, x_cnhw, ldw: int, stride: int, slabs: int = 8):
+    Cin, B, Hi, _ = x_cnhw.shape; Cout, _, Ho, _ = dy_cnhw.shape
+    dW = torch.empty(Cout, ldw, device=x_cnhw.device, dtype=torch.float32)
+    slab = torch.empty(slabs, Cout, ldw, device=x_cnhw.device, dtype=torch.float32)
+    check(lib().aid_conv3_igemm_dw(_ptr(dy_cnhw), _ptr(x_cnhw), _ptr(dW), ldw, Cin, Cout, B, Hi, Ho, stride, _ptr(slab), slabs, _stream()), "aid_conv3_igemm_dw")
+    return dW
+
+
 def gemm_group_tn(dW, dy, x, db=None, scratch=None):
     """dW[i] += dy[i]^T x[i] (and db[i] += dy[i].sum(0)) for every i in ONE launch (csrc/gemm_group.hip).  Lists of dense row-major tensors;
     consecutive entries with the same dW tensor are contracted into the same accumulators."""

@@ -1,10 +1,11 @@
 // DrQ-v2 pixel encoder on gfx950: forward and backward (aid/encoder/visual_encoders.py:13-225, 471-492).
 //
 // Layout: activations live as C-N-HW ("CNHW": [channel][sample][h][w]) between the convolutions, so that
-//   * conv3x3 = ONE fp32-MFMA GEMM  out[Cout][N*HW] = W_eff[Cout][Cin*9] x col[Cin*9][N*HW]  with the weight in torch's own
-//     flatten order (no permutation) and the im2col matrix k-major (coalesced along w);
+//   * conv3x3 = ONE fp32-MFMA GEMM  out[Cout][N*HW] = W_eff[Cout][Cin*9] x X[Cin*9][N*HW]  with the weight in torch's own flatten order (no
+//     permutation) and X gathered from the planes by the kernel's B-operand loader (coalesced along w);
 //   * a channel plane [N][HW] is contiguous: GroupNorm / per-channel reductions / spatial pooling stream it at HBM rate.
-// First version: explicit im2col / col2im buffers (<= 2.1 GB at batch 256 - there are 288 GB); implicit GEMM is the follow-up.
+// The 3x3 convolutions are implicit GEMMs (conv_igemm.hip: forward, data gradient through the flipped weights, weight gradient): no im2col /
+// col2im buffers (round 1-2 materialised 3.8 GB of them per forward and kept them for the backward).
 // The 451 584-wide LayerNorm + Linear use a deterministic split-K ("slab") GEMM; conv weight gradients do too.
 // Spectral normalisation follows the LEGACY torch.nn.utils.spectral_norm semantics the reference uses: one power iteration per
 // training forward mutating u/v, sigma = u.(W v) with u, v constant in the backward.
@@ -97,69 +98,6 @@ __global__ void spectral_norm_bwd_kernel(const float* __restrict__ dw_eff, const
         const int c = i / K, k = i % K;
         dw_orig[i] += (dw_eff[(size_t)c * Kp + k] - dot * save[c] * save[Cout + k]) / sigma;
     }
-}
-
-// ---- im2col / col2im for 3x3, pad 1, stride s; x CNHW [Cin][B][Hi][Wi]; col [Kp][B*Ho*Wo], k = ci*9 + kh*3 + kw ------------------
-// grid (N/4/256, Kp): a block works on one row k of col (ci, kh, kw uniform), a thread on 4 consecutive columns -> one 16-B store; the
-// (b, ho, wo) decomposition is done once per thread in 32-bit arithmetic and advanced with carries.  Output-write bound (3.8 GB per
-// encoder forward at B = 256).
-__global__ void im2col3_kernel(const float* __restrict__ x, float* __restrict__ col, int Cin, int B, int Hi, int Wi, int Ho, int Wo, int stride,
-                               int K, int N) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    const int k = blockIdx.y;
-    const int n0 = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (n0 >= N) return;
-    f4 v = {0.f, 0.f, 0.f, 0.f};
-    if (k < K) {
-        const int ci = k / 9, kh = (k % 9) / 3, kw = k % 3;
-        int wo = n0 % Wo, t = n0 / Wo;
-        int ho = t % Ho, b = t / Ho;
-        const float* xc = x + (size_t)ci * B * Hi * Wi;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int hi = ho * stride + kh - 1, wi = wo * stride + kw - 1;
-            if (n0 + j < N && hi >= 0 && hi < Hi && wi >= 0 && wi < Wi) v[j] = xc[(b * Hi + hi) * Wi + wi];
-            if (++wo == Wo) { wo = 0; if (++ho == Ho) { ho = 0; ++b; } }
-        }
-    }
-    float* dst = col + (size_t)k * N + n0;
-    if ((N & 3) == 0) *reinterpret_cast<f4*>(dst) = v;
-    else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (n0 + j < N) dst[j] = v[j];
-    }
-}
-static int im2col3(const float* x, float* col, int Cin, int B, int Hi, int Ho, int stride, int K, int Kp, size_t N, hipStream_t s) {
-    AID_REQUIRE(N < ((size_t)1 << 31) && Kp <= 65535, AID_E_SHAPE, "im2col3: N=%zu Kp=%d", N, Kp);
-    if (N == 0) return AID_OK;
-    hipLaunchKernelGGL(im2col3_kernel, dim3((unsigned)((N + 1023) / 1024), Kp), dim3(256), 0, s, x, col, Cin, B, Hi, Hi, Ho, Ho, stride, K, (int)N);
-    AID_LAUNCH_CHECK(); return AID_OK;
-}
-// dx[ci][b][hi][wi] = sum_{kh,kw} dcol[(ci,kh,kw)][(b,ho,wo)] over valid (ho,wo) with ho*s+kh-1 = hi (gather form, no atomics)
-// grid (Hi*Wi/256, B, Cin): 32-bit index arithmetic inside one image plane
-__global__ void col2im3_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int Hi, int Wi, int Ho, int Wo, int stride) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= Hi * Wi) return;
-    const int hi = p / Wi, wi = p % Wi, b = blockIdx.y, ci = blockIdx.z;
-    const size_t N = (size_t)B * Ho * Wo;
-    const float* dc = dcol + (size_t)ci * 9 * N + (size_t)b * Ho * Wo;
-    float s = 0.f;
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-        const int th = hi + 1 - kh;
-        if (th < 0 || th % stride) continue;
-        const int ho = th / stride;
-        if (ho >= Ho) continue;
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const int tw = wi + 1 - kw;
-            if (tw < 0 || tw % stride) continue;
-            const int wo = tw / stride;
-            if (wo >= Wo) continue;
-            s += dc[(size_t)(kh * 3 + kw) * N + ho * Wo + wo];
-        }
-    }
-    dx[((size_t)ci * B + b) * Hi * Wi + p] = s;
 }
 
 // ---- GroupNorm + Mish + Dropout2d, one workgroup per (sample, group); x/y CNHW [C][B][HW] -----------------------------------------
@@ -509,7 +447,6 @@ static EncGeom enc_geom(const AidEncoderNet& e) {
 struct EncSaved {
     float* x0;                                   // augmented input, CNHW
     float* conv_out[ENC_LAYERS]; float* act[ENC_LAYERS]; float* gn_stats[ENC_LAYERS]; float* w_eff[ENC_LAYERS]; float* sn[ENC_LAYERS];
-    float* col[ENC_LAYERS];                      // im2col of every layer's input: re-used by the weight-gradient GEMM (3.8 GB at B=256; HBM is 288 GB)
     float *pool, *apre, *att; int32_t* amax;
     float *xf, *ln_stats, *xln;
     LlaSave s0; float* o4; float* st5; float* feat;
@@ -521,7 +458,6 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
         const size_t n = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i];
         sv.conv_out[i] = ws.f32(n); sv.act[i] = ws.f32(n); sv.gn_stats[i] = ws.f32((size_t)B * g.G[i] * 2);
         sv.w_eff[i] = ws.f32((size_t)g.cout[i] * g.Kp[i]); sv.sn[i] = ws.f32(g.cout[i] + g.K[i] + 4);
-        sv.col[i] = ws.f32((size_t)g.Kp[i] * B * g.ho[i] * g.ho[i]);
     }
     sv.pool = ws.f32((size_t)B * 2 * g.HW); sv.apre = ws.f32((size_t)B * g.HW); sv.att = ws.f32((size_t)B * g.HW);
     sv.amax = (int32_t*)ws.raw(sizeof(int32_t) * (size_t)B * g.HW);
@@ -531,11 +467,22 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
 }
 
 static int conv_slabs(size_t N) { int s = (int)(N / 8192); return s < 1 ? 1 : (s > 96 ? 96 : s); }
+// slabs of a conv weight gradient [cout][kp]: enough (tile, slab) workgroups to fill the chip (~2 000) when the gradient itself is only a few
+// 64 x 64 tiles (layer 0: 32 x 81 = 2 tiles), each slab at least 1 024 columns; never more floats than 96 slabs of the widest layer
+static int conv_dw_slabs(size_t N, int cout, int kp) {
+    const int tiles = ((cout + 63) / 64) * ((kp + 63) / 64);
+    int s = conv_slabs(N), want = 2048 / tiles, cap = (int)(N / 1024);
+    if (want > s) s = want;
+    if (s > cap) s = cap;
+    const size_t lim = (size_t)96 * 256 * 1152 / ((size_t)cout * kp);
+    if ((size_t)s > lim) s = (int)lim;
+    return s < 1 ? 1 : s;
+}
 
 
 // =================================================================================================================================
 // ConvDecoder forward, eval mode (active_inference_diffusion/encoder/visual_encoders.py:228-459): latent -> 3 x 168 x 168 image.
-// Activations are CNHW like the encoder's; every conv is W_eff[Cout, 9 Cin] x im2col (or a plain GEMM for the 1x1 residual convs).
+// Activations are CNHW like the encoder's; every 3x3 conv is an implicit GEMM (conv_igemm.hip), the 1x1 residual convs are plain GEMMs.
 // Conv bias, PixelShuffle(2), InstanceNorm2d, the residual add and Mish are ONE pass over the conv output (instnorm_kernel): the
 // sub-pixel shuffle is an index transform of the read, the bias of the source channel is added on the fly.
 // =================================================================================================================================
@@ -615,13 +562,10 @@ __global__ void sigmoid_nchw_kernel(const float* __restrict__ x, const float* __
 }
 
 struct ConvW { const float* w_eff; int cin, cout, Kp; };
-// out[Cout][R*H*W] = W_eff x im2col3(x)   (stride 1, pad 1);  col: scratch of Kp * R*H*W floats
+// out[Cout][R*H*W] = 3x3 conv of x (stride 1, pad 1) as an implicit GEMM; `col` is unused (kept in the signature of the callers' scratch layout)
 static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* col, float* out, hipStream_t s) {
-    const size_t N = (size_t)R * H * H;
-    AID_TRY(im2col3(x, col, cw.cin, R, H, H, 1, cw.cin * 9, cw.Kp, N, s));
-    GemmArgs ga = gemm_args(cw.w_eff, cw.Kp, col, (int)N, out, (int)N, cw.cout, (int)N, cw.Kp);
-    ga.b_kmajor = 1;
-    return gemm_f32(ga, s);
+    (void)col;
+    return conv3_igemm(cw.w_eff, cw.Kp, x, out, cw.cin, cw.cout, R, H, H, 1, s);
 }
 static int conv1_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
     const size_t N = (size_t)R * H * H;
@@ -657,10 +601,10 @@ size_t aid_encoder_workspace(const AidEncoderNet* enc, int B) {
     if (!enc || B <= 0) return 0;
     const EncGeom g = enc_geom(*enc);
     const size_t N = (size_t)B * g.HW;
-    size_t col = 0, act = 0;
-    for (int i = 0; i < ENC_LAYERS; ++i) { const size_t c = (size_t)g.Kp[i] * B * g.ho[i] * g.ho[i]; if (c > col) col = c;
-                                            const size_t a = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i]; if (a > act) act = a; }
-    size_t n = sizeof(float) * (2 * col + 3 * act + 2 * (size_t)B * g.F + 4 * N + 96 * (size_t)256 * 1152 + (size_t)96 * B * enc->out0.out + (1 << 20));
+    size_t act = 0;
+    for (int i = 0; i < ENC_LAYERS; ++i) { const size_t a = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i]; if (a > act) act = a; }
+    // 3 activation-sized buffers, the flipped weights of one layer, <= 96 weight-gradient slabs, the slabs of the 451 584-wide Linear
+    size_t n = sizeof(float) * (3 * act + 2 * (size_t)B * g.F + 4 * N + (size_t)256 * 2304 + 97 * (size_t)256 * 1152 + (size_t)96 * B * enc->out0.out + (1 << 20));
     return n + (1 << 20);
 }
 
@@ -682,14 +626,11 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     for (int i = 0; i < ENC_LAYERS; ++i) {
         const size_t N = (size_t)B * g.ho[i] * g.ho[i];
         const size_t mark = ws.mark();
-        float* col = sv.col[i];
         hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, s, e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], train,
                            train, sv.w_eff[i], sv.sn[i]);
         AID_LAUNCH_CHECK();
-        AID_TRY(im2col3(cur, col, g.cin[i], B, g.hi[i], g.ho[i], g.stride[i], g.K[i], g.Kp[i], N, s));
-        GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], col, (int)N, sv.conv_out[i], (int)N, g.cout[i], (int)N, g.Kp[i]);
-        ga.b_kmajor = 1;
-        AID_TRY(gemm_f32(ga, s));
+        (void)N;
+        AID_TRY(conv3_igemm(sv.w_eff[i], g.Kp[i], cur, sv.conv_out[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], s));
         {
             const int hw = g.ho[i] * g.ho[i], cpg = g.cout[i] / g.G[i];
             if (gn_reg_ok(g.cout[i], g.G[i], hw, sv.conv_out[i], sv.act[i])) {
@@ -772,9 +713,11 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         const int hw = g.ho[i] * g.ho[i];
         const size_t N = (size_t)B * hw;
         const size_t mark = ws.mark();
-        float* dconv = ws.f32((size_t)g.cout[i] * N); float* col = ws.f32((size_t)g.Kp[i] * N);
+        float* dconv = ws.f32((size_t)g.cout[i] * N);
+        const int ldwt = (g.cout[i] * 9 + 3) / 4 * 4;
+        float* wflip = i > 0 ? ws.f32((size_t)g.cin[i] * ldwt) : nullptr;
         float* dweff = ws.f32((size_t)g.cout[i] * g.Kp[i]);
-        const int S = conv_slabs(N);
+        const int S = conv_dw_slabs(N, g.cout[i], g.Kp[i]);
         float* slab = ws.f32((size_t)S * g.cout[i] * g.Kp[i]);
         float* ppart = ws.f32((size_t)B * g.cout[i] * 2);
         AID_WS_OK(ws);
@@ -788,22 +731,16 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
             hipLaunchKernelGGL(gn_param_grad_kernel, dim3(g.cout[i]), dim3(1024), 0, s, dcur, sv.conv_out[i], sv.gn_stats[i], gr.gn_g[i], gr.gn_b[i], g.cout[i], B, hw, g.G[i]);
         }
         AID_LAUNCH_CHECK();
-        {   // dW_eff[Cout][Kp] = dconv[Cout][N] x col[Kp][N]^T  (both k-contiguous along N; huge reduction -> slabs); col: the forward's im2col
-            GemmArgs ga = gemm_args(dconv, (int)N, sv.col[i], (int)N, dweff, g.Kp[i], g.cout[i], g.Kp[i], (int)N);
-            ga.slab = slab; ga.nslab = S;
-            AID_TRY(gemm_f32(ga, s));
-        }
+        // dW_eff[Cout][Kp] = sum_n dconv[Cout][n] X(k, n): the layer's input is gathered again (implicit GEMM; huge reduction -> slabs)
+        AID_TRY(conv3_igemm_dw(dconv, i > 0 ? sv.act[i - 1] : sv.x0, dweff, g.Kp[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], slab, S, s));
         hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, s, dweff, sv.w_eff[i], sv.sn[i], g.cout[i], g.K[i], g.Kp[i], gr.conv_w[i]);
         AID_LAUNCH_CHECK();
-        if (i > 0) {   // dcol[Kp][N] = W_eff^T dconv ; col2im -> gradient wrt act[i-1]
-            GemmArgs ga = gemm_args(sv.w_eff[i], g.Kp[i], dconv, (int)N, col, (int)N, g.Kp[i], (int)N, g.cout[i]);
-            ga.a_kmajor = 1; ga.b_kmajor = 1;
-            AID_TRY(gemm_f32(ga, s));
+        if (i > 0) {   // gradient wrt act[i-1]: the stride-1 conv of dconv with the flipped, channel-transposed weights
+            AID_REQUIRE(g.stride[i] == 1, AID_E_SHAPE, "aid_encoder_backward: data gradient of a strided conv is not built (layer %d)", i);
+            AID_TRY(conv3_flip_weights(sv.w_eff[i], g.Kp[i], wflip, ldwt, g.cin[i], g.cout[i], s));
             // dact (gradient wrt act[i]) was consumed by the two GroupNorm kernels above: the gradient wrt act[i-1] goes straight into it
             // (cin*hi*hi*B <= 256*HW*B for layers 1..3)
-            hipLaunchKernelGGL(col2im3_kernel, dim3((g.hi[i] * g.hi[i] + 255) / 256, B, g.cin[i]), dim3(256), 0, s, col, dact, B, g.hi[i], g.hi[i], g.ho[i],
-                               g.ho[i], g.stride[i]);
-            AID_LAUNCH_CHECK();
+            AID_TRY(conv3_igemm(wflip, ldwt, dconv, dact, g.cout[i], g.cin[i], B, g.ho[i], g.hi[i], 1, s));
             dcur = dact;
         }
         ws.release(mark);

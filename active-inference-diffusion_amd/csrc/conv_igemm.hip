@@ -1,0 +1,319 @@
+// Implicit-GEMM 3x3 convolution (pad 1, stride 1 or 2) on CNHW activations: forward, data gradient and weight gradient without an im2col
+// matrix.  Reference: the four spectral-norm convs of DrQV2Encoder (aid/encoder/visual_encoders.py:135-189) and the DecoderBlock / output
+// convs of ConvDecoder (:228-459).
+//
+//   forward        out[co][n] = sum_k W[co][k] X(k, n)            k = ci 9 + kh 3 + kw,  n = (b, ho, wo)
+//                  X(k, n)    = x[ci][b][ho s + kh - 1][wo s + kw - 1]   (0 outside the image)
+//   data gradient  of a stride-1 conv = the same kernel on dy with the flipped, channel-transposed weights (conv3_flip_weights)
+//   weight grad.   dW[co][k]  = sum_n dy[co][n] X(k, n)            (contraction over n, cut into slabs folded in order: deterministic)
+//
+// Why: the explicit path wrote X as a [9 Cin][B Ho Wo] matrix (3.8 GB per encoder forward at batch 256, kept for the weight gradient) and read it
+// back twice; im2col + col2im were 3.3 ms of a 20 ms forward + backward pair.  Here the B-operand loader computes (b, ho, wo) once per
+// thread, keeps a 9-bit border mask, and gathers the 3 x 3 taps straight from the activation planes (231 MB at the widest layer, L2 /
+// Infinity-Cache resident across the column tiles that share a plane).
+//
+// MI355X mapping: 256-thread workgroups, v_mfma_f32_32x32x2_f32, K (or n) in stages of 32, register-staged double buffering with the loads of
+// stage t + 1 issued before the MFMAs of stage t.  Loads are unconditional from clamped addresses and masked when written to LDS (a branch
+// around a global load makes the compiler drain the memory queue).  Consecutive lanes gather consecutive n (= consecutive wo): coalesced
+// 4-B loads for stride 1.
+#include "aid_common.h"
+#include "mlp.h"
+
+namespace aid {
+
+typedef float ig_f32x16 __attribute__((ext_vector_type(16)));
+typedef float ig_f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvIgArgs {
+    const float* W; int ldw;       // [Cout][ldw], ldw >= K = 9 Cin, multiple of 4, zero beyond K
+    const float* x;                // [Cin][B][Hi][Wi]
+    float* out;                    // [Cout][N]
+    int Cin, Cout, B, Hi, Wi, Ho, Wo, stride, K;
+    long N;
+};
+
+// 4 waves as (4 / WN) x WN; a wave owns TM accumulator blocks of 32 x 32 stacked along the output channels: BM = 32 TM 4 / WN rows, BN = 32 WN columns
+template <int TM, int BK, int WN>
+__global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
+    constexpr int BM = 32 * TM * (4 / WN), BN = 32 * WN, ALD = BK + 4, BLD = BN + 4, A_FL = BM * ALD, B_FL = BK * BLD;
+    constexpr int PA = BM * BK / 4 / 256, KR = 256 / BN, PBG = BK / KR, CPRA = BK / 4;      // float4 A pieces / gathered B elements per thread per stage
+    static_assert(PA >= 1 && PA * 1024 == BM * BK && PBG * KR == BK, "tile does not split into whole pieces");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                  // [2][BM][ALD]
+    float* Bs = smem + 2 * A_FL;       // [2][BK][BLD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave / WN) * (32 * TM), wn = (wave % WN) * 32;
+    const long n0 = (long)blockIdx.x * BN;
+    const int m0 = blockIdx.y * BM;
+    // ---- this thread's output column: (b, ho, wo), the offset of its top-left tap and the validity of the nine taps
+    const int nl = tid % BN, kr = tid / BN;
+    const long n = n0 + nl;
+    const bool nok = n < g.N;
+    const long nn = nok ? n : 0;
+    const int wo = (int)(nn % g.Wo); const long t1 = nn / g.Wo; const int ho = (int)(t1 % g.Ho), b = (int)(t1 / g.Ho);
+    const int h0 = ho * g.stride - 1, w0 = wo * g.stride - 1;
+    const long base = ((long)b * g.Hi + h0) * g.Wi + w0;
+    unsigned vm = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+            if (nok && h0 + kh >= 0 && h0 + kh < g.Hi && w0 + kw >= 0 && w0 + kw < g.Wi) vm |= 1u << (kh * 3 + kw);
+    const long plane = (long)g.B * g.Hi * g.Wi;
+    const int nk = (g.K + BK - 1) / BK;
+
+    ig_f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    ig_f32x4 ra[PA]; float rb[PBG]; unsigned rbm;
+    // tap j of this thread is k = BK kt + kr + KR j: (ci, kh 3 + kw) and the plane offset advance by BK per stage with a carry, no division
+    int kr9[PBG]; long kco[PBG];
+#pragma unroll
+    for (int j = 0; j < PBG; ++j) { const int k = kr + KR * j, ci = k / 9; kr9[j] = k - 9 * ci; kco[j] = (long)ci * plane; }
+    auto load_stage = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int f = tid + 256 * i, row = f / CPRA, c4 = f % CPRA;
+            const int gr = min(m0 + row, g.Cout - 1), gk = min(kt * BK + 4 * c4, g.ldw - 4);
+            ra[i] = *reinterpret_cast<const ig_f32x4*>(g.W + (size_t)gr * g.ldw + gk);
+        }
+        rbm = 0;
+#pragma unroll
+        for (int j = 0; j < PBG; ++j) {
+            const int k = kt * BK + kr + KR * j;
+            const int r9 = kr9[j], kh = (r9 * 11) >> 5, kw = r9 - 3 * kh;          // r9 / 3 for r9 < 9
+            const bool ok = k < g.K && ((vm >> r9) & 1u);
+            rb[j] = g.x[ok ? kco[j] + base + kh * g.Wi + kw : 0];
+            rbm |= (ok ? 1u : 0u) << j;
+            // k += BK for the next stage (stages are loaded in order, each exactly once)
+            kr9[j] += BK % 9; kco[j] += (long)(BK / 9) * plane;
+            if (kr9[j] >= 9) { kr9[j] -= 9; kco[j] += plane; }
+        }
+    };
+    auto store_stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int f = tid + 256 * i, row = f / CPRA, c4 = f % CPRA;
+            ig_f32x4 v = ra[i];
+            if (m0 + row >= g.Cout || kt * BK + 4 * c4 >= g.ldw) v = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<ig_f32x4*>(As + buf * A_FL + row * ALD + 4 * c4) = v;
+        }
+#pragma unroll
+        for (int j = 0; j < PBG; ++j) Bs[buf * B_FL + (kr + KR * j) * BLD + nl] = ((rbm >> j) & 1u) ? rb[j] : 0.f;
+    };
+    load_stage(0); store_stage(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_stage(kt + 1);
+        const float* a_s = As + cur * A_FL;
+        const float* b_s = Bs + cur * B_FL;
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            ig_f32x4 av[TM]; float bv[4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const ig_f32x4*>(a_s + (wm + 32 * i + li) * ALD + 8 * g8 + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = b_s[(8 * g8 + 4 * h + j) * BLD + wn + li];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][q], bv[q], acc[i], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_stage(kt + 1, cur ^ 1);
+        __syncthreads();
+    }
+    // C/D map of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const long col = n0 + wn + li;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < TM; ++i)
+#pragma clang loop unroll(full)
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row < g.Cout && col < g.N) g.out[(size_t)row * g.N + col] = acc[i][r];
+        }
+}
+
+int conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, hipStream_t s) {
+    AID_REQUIRE(W && x && out, AID_E_NULL, "conv3_igemm: null operand");
+    AID_REQUIRE(Cin > 0 && Cout > 0 && B > 0 && (stride == 1 || stride == 2) && ldw >= 9 * Cin && ldw % 4 == 0 && ((((uintptr_t)W) & 15) == 0), AID_E_SHAPE,
+                "conv3_igemm: Cin=%d Cout=%d stride=%d ldw=%d", Cin, Cout, stride, ldw);
+    ConvIgArgs g; memset(&g, 0, sizeof(g));
+    g.W = W; g.ldw = ldw; g.x = x; g.out = out; g.Cin = Cin; g.Cout = Cout; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Ho = Ho; g.Wo = Ho; g.stride = stride; g.K = 9 * Cin;
+    g.N = (long)B * Ho * Ho;
+    ProfScope prof(PROF_GEMM_TILE, s, 2.0 * Cout * g.K * (double)g.N, 4.0 * ((double)Cout * g.K + (double)Cin * B * Hi * Hi + (double)Cout * g.N));
+    prof.m = Cout; prof.n = (int)(g.N > 2000000000L ? 2000000000L : g.N); prof.k = g.K; prof.layout = stride; prof.variant = 31;
+    // 128 x 64 tiles in 16-deep stages (29 KB of LDS: five workgroups per CU; measured 93 TFLOP/s on the 256 x 451 584 x 1152 layer against 83
+    // with 32-deep stages at two per CU and 74 with 64 x 64 tiles, which gather every column four times); 64-row tiles for Cout <= 64
+    // up to 32 output channels: 32 x 128 tiles (a 64-row tile would be half empty); up to 64: 64 x 64 in 16-deep stages (19 KB)
+#define IG_LAUNCH(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
+        hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
+    if (Cout <= 32) IG_LAUNCH(1, 32, 4);
+    else if (Cout <= 64) IG_LAUNCH(1, 16, 2);
+    else IG_LAUNCH(2, 16, 2);
+#undef IG_LAUNCH
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+// Wt[ci][co 9 + kh 3 + kw] = W[co][ci 9 + (2 - kh) 3 + (2 - kw)], rows zero-padded to ldwt
+__global__ void conv3_flip_weights_kernel(const float* __restrict__ W, int ldw, float* __restrict__ Wt, int ldwt, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * ldwt) return;
+    const int ci = i / ldwt, k = i % ldwt;
+    float v = 0.f;
+    if (k < Cout * 9) { const int co = k / 9, r9 = k % 9, kh = r9 / 3, kw = r9 % 3; v = W[(size_t)co * ldw + ci * 9 + (2 - kh) * 3 + (2 - kw)]; }
+    Wt[i] = v;
+}
+int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s) {
+    AID_REQUIRE(ldwt >= 9 * Cout && ldwt % 4 == 0, AID_E_SHAPE, "conv3_flip_weights: ldwt=%d", ldwt);
+    hipLaunchKernelGGL(conv3_flip_weights_kernel, dim3((Cin * ldwt + 255) / 256), dim3(256), 0, s, W, ldw, Wt, ldwt, Cin, Cout);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+
+// ---- weight gradient: slab[sy][co][k] = sum over this slab's n of dy[co][n] X(k, n); 64 x 64 output tile, n in stages of 32 ------------------
+struct ConvDwArgs {
+    const float* dy;               // [Cout][N]
+    const float* x;                // [Cin][B][Hi][Wi]
+    float* slab; int ldw;          // [S][Cout][ldw]
+    int Cin, Cout, B, Hi, Wi, Ho, Wo, stride, K, tiles_k;
+    long N, chunk;                 // n per slab (multiple of 32)
+};
+__global__ void __launch_bounds__(256) conv3_igemm_dw_kernel(ConvDwArgs g) {
+    constexpr int BT = 64, BK = 32, LD = BK + 4, FL = BT * LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;              // [2][64 co][36]   (n contiguous)
+    float* Bs = smem + 2 * FL;     // [2][64 k][36]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    const int tco = blockIdx.x / g.tiles_k, tk = blockIdx.x % g.tiles_k;
+    const int co0 = tco * BT, k0 = tk * BT;
+    const long nb0 = (long)blockIdx.y * g.chunk, nb1 = min(g.N, nb0 + g.chunk);
+    const int nst = (int)((nb1 - nb0 + BK - 1) / BK);
+    const long plane = (long)g.B * g.Hi * g.Wi;
+    const int nl = tid & 31, kr = tid >> 5;
+    // the 8 taps this thread gathers are fixed for the whole kernel: k = k0 + kr + 8 j
+    long toff[8]; int tsh[8];                                   // offset of the tap relative to (b, ho s, wo s); bit positions of its row / column validity
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int k = k0 + kr + 8 * j, kc = min(k, g.K - 1), ci = kc / 9, r9 = kc - 9 * ci, dh = r9 / 3, dw = r9 % 3;
+        toff[j] = (long)ci * plane + (long)(dh - 1) * g.Wi + (dw - 1);
+        tsh[j] = k < g.K ? dh + 4 * dw : 31;                    // 31: an always-clear bit (k beyond the layer's K)
+    }
+    ig_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ig_f32x4 ra[2]; float rb[8]; unsigned rbm; bool ram[2];
+    // this thread's column n = nb0 + 32 st + nl as (b, ho, wo), advanced by 32 per stage with carries (no division in the loop)
+    int cwo, cho, cb;
+    { const long nn = min(nb0 + nl, g.N - 1); cwo = (int)(nn % g.Wo); const long t1 = nn / g.Wo; cho = (int)(t1 % g.Ho); cb = (int)(t1 / g.Ho); }
+    auto load_stage = [&](int st) {
+        const long nb = nb0 + (long)st * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            const long nn = nb + 4 * c4;
+            ram[i] = co0 + row < g.Cout && nn + 3 < nb1;            // N and the slab bounds are multiples of 4 on the encoder / decoder shapes
+            const long a = (long)min(co0 + row, g.Cout - 1) * g.N + (ram[i] ? nn : 0);
+            ra[i] = *reinterpret_cast<const ig_f32x4*>(g.dy + a);
+        }
+        const long n = nb + nl;
+        const bool nok = n < nb1;
+        const int wo = cwo, ho = cho, b = min(cb, g.B - 1);
+        cwo += BK;                                          // next stage's column
+        while (cwo >= g.Wo) { cwo -= g.Wo; if (++cho == g.Ho) { cho = 0; ++cb; } }
+        const int hc = ho * g.stride, wc = wo * g.stride;
+        const long base = ((long)b * g.Hi + hc) * g.Wi + wc;
+        // validity of the three rows / columns around (hc, wc): bits 0..2 rows, as a 3 x 3 product table in bits dh + 4 dw
+        unsigned hb = 0, vb = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { if (hc + d - 1 >= 0 && hc + d - 1 < g.Hi) hb |= 1u << d; }
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { if (nok && wc + d - 1 >= 0 && wc + d - 1 < g.Wi) vb |= hb << (4 * d); }
+        rbm = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = (vb >> tsh[j]) & 1u;
+            rb[j] = g.x[ok ? base + toff[j] : 0];
+            rbm |= (ok ? 1u : 0u) << j;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            *reinterpret_cast<ig_f32x4*>(As + buf * FL + row * LD + 4 * c4) = ram[i] ? ra[i] : (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) Bs[buf * FL + (kr + 8 * j) * LD + nl] = ((rbm >> j) & 1u) ? rb[j] : 0.f;
+    };
+    if (nst > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const float* a_s = As + cur * FL;
+        const float* b_s = Bs + cur * FL;
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            const ig_f32x4 av = *reinterpret_cast<const ig_f32x4*>(a_s + (wm + li) * LD + 8 * g8 + 4 * h);
+            const ig_f32x4 bv = *reinterpret_cast<const ig_f32x4*>(b_s + (wk + li) * LD + 8 * g8 + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q], bv[q], acc, 0, 0, 0);
+        }
+        if (st + 1 < nst) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = g.slab + (size_t)blockIdx.y * g.Cout * g.ldw;
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h, col = k0 + wk + li;
+        if (row < g.Cout && col < g.ldw) out[(size_t)row * g.ldw + col] = col < g.K ? acc[r] : 0.f;
+    }
+}
+__global__ void conv3_dw_fold_kernel(const float* __restrict__ slab, int S, size_t n, float* __restrict__ dW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int sy = 0; sy < S; ++sy) v += slab[(size_t)sy * n + i];
+    dW[i] = v;
+}
+int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, hipStream_t s) {
+    AID_REQUIRE(dy && x && dW && slab && S >= 1, AID_E_NULL, "conv3_igemm_dw: null operand");
+    const long N = (long)B * Ho * Ho;
+    AID_REQUIRE(N % 4 == 0 && ldw % 4 == 0 && ldw >= 9 * Cin && ((((uintptr_t)dy) & 15) == 0), AID_E_SHAPE, "conv3_igemm_dw: N=%ld ldw=%d", N, ldw);
+    ConvDwArgs g; memset(&g, 0, sizeof(g));
+    g.dy = dy; g.x = x; g.slab = slab; g.ldw = ldw; g.Cin = Cin; g.Cout = Cout; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Ho = Ho; g.Wo = Ho; g.stride = stride; g.K = 9 * Cin;
+    g.N = N; g.tiles_k = (ldw + 63) / 64;
+    g.chunk = ((N + S - 1) / S + 31) / 32 * 32;
+    AID_REQUIRE(g.chunk >= 32, AID_E_SHAPE, "conv3_igemm_dw: %d slabs for %ld columns", S, N);
+    const int S_eff = (int)((N + g.chunk - 1) / g.chunk);
+    ProfScope prof(PROF_GEMM_TILE, s, 2.0 * Cout * g.K * (double)N, 4.0 * ((double)Cout * N + (double)Cin * B * Hi * Hi));
+    prof.m = Cout; prof.n = g.K; prof.k = (int)(N > 2000000000L ? 2000000000L : N); prof.layout = 4 + stride; prof.variant = 32;
+    hipLaunchKernelGGL(conv3_igemm_dw_kernel, dim3(((Cout + 63) / 64) * g.tiles_k, S_eff), dim3(256), sizeof(float) * 4 * 64 * (32 + 4), s, g);
+    const size_t n = (size_t)Cout * ldw;
+    hipLaunchKernelGGL(conv3_dw_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, S_eff, n, dW);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+}  // namespace aid
+
+using namespace aid;
+extern "C" {
+// Unit-test entries for the implicit-GEMM convolution (W: [Cout][ldw] with ldw >= 9 Cin a multiple of 4, x: CNHW [Cin][B][Hi][Hi], out / dy: [Cout][B Ho Ho]).
+int aid_conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {
+    return conv3_igemm(W, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, (hipStream_t)stream);
+}
+int aid_conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, void* stream) {
+    return conv3_igemm_dw(dy, x, dW, ldw, Cin, Cout, B, Hi, Ho, stride, slab, S, (hipStream_t)stream);
+}
+int aid_conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, void* stream) {
+    AID_REQUIRE(W && Wt, AID_E_NULL, "aid_conv3_flip_weights: null");
+    return conv3_flip_weights(W, ldw, Wt, ldwt, Cin, Cout, (hipStream_t)stream);
+}
+}

@@ -83,6 +83,14 @@ int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const Policy
 int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
                const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s, const PolicySteps* steps = nullptr, int t = 0);
 
+// ---- implicit-GEMM 3x3 convolution on CNHW activations (conv_igemm.hip): no im2col matrix
+// out[co][n = (b, ho, wo)] = sum_k W[co][k] x[ci][b][ho s + kh - 1][wo s + kw - 1], k = ci 9 + kh 3 + kw; W [Cout][ldw], ldw >= 9 Cin, ldw % 4 == 0
+int conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, hipStream_t s);
+// dW[co][k] (row stride ldw) = sum_n dy[co][n] X(k, n); slab: scratch [S][Cout][ldw] (S row chunks folded in order)
+int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, hipStream_t s);
+// Wt[ci][co 9 + kh 3 + kw] = W[co][ci 9 + (2 - kh) 3 + (2 - kw)]: the data gradient of a stride-1 conv is conv3_igemm(Wt, dy) with Cin <-> Cout
+int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s);
+
 // ---- ConvDecoder + pixel estimator feature side (conv.hip)
 int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s);
 int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNet& e, int R, const float* z_all, const float* delta,

@@ -84,6 +84,16 @@ int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, con
  * The order of the float adds is not reproducible run to run (last-bit differences).  Bench/test entry. */
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream);
+/* Implicit-GEMM 3x3 convolution, pad 1, stride 1 or 2, on channel-major ("CNHW") activations - what aid_encoder_forward / _backward and
+ * aid_conv_decoder_forward run for every 3x3 conv (aid/encoder/visual_encoders.py:135-189, 228-459); unit-test entries.
+ *   x [Cin][B][Hi][Hi], W [Cout][ldw] (ldw >= 9 Cin, multiple of 4, k = ci 9 + kh 3 + kw), out / dy [Cout][B Ho Ho]
+ *   aid_conv3_igemm      out = conv(x, W)
+ *   aid_conv3_flip_weights  Wt[ci][co 9 + kh 3 + kw] = W[co][ci 9 + (2-kh) 3 + (2-kw)]: dx = aid_conv3_igemm(Wt, dy) with Cin <-> Cout (stride 1)
+ *   aid_conv3_igemm_dw   dW[co][k] = sum_n dy[co][n] X(k, n); slab: scratch [S][Cout][ldw]; B Ho Ho must be a multiple of 4 */
+int aid_conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream);
+int aid_conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, void* stream);
+int aid_conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, void* stream);
+
 /* n weight-gradient problems dW_i[N_i, K_i] += dY_i[M_i, N_i]^T X_i[M_i, K_i] (row-major, dense), and db_i[N_i] += column sums of dY_i when
  * db / db[i] is non-null, in ONE launch (csrc/gemm_group.hip: what the backward passes of aid_elbo_step / aid_efe_step do with all their
  * parameter gradients).  Two consecutive problems with the same dW are contracted into the same accumulators.  scratch (optional, scratch_floats

@@ -548,3 +548,31 @@ def test_gemm_mid_routed_shapes(nat, M, N, K, lay, act):
     C = torch.empty(M, N, device="cuda")
     nat.gemm(dev(A), dev(W), C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=dev(b), act=act, residual=dev(R), ldr=N)
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+
+
+@pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2)])
+def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
+    """csrc/conv_igemm.hip against torch's conv2d on the CPU (fp64): forward (border taps, stride 2, ragged channel counts), the data
+    gradient through the flipped weights, the weight gradient (slab-split contraction over B Ho Wo)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(Cin * 100 + Cout)
+    x = rng.standard_normal((B, Cin, Hi, Hi)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(9 * Cin)).astype(np.float32)
+    K = 9 * Cin; ldw = (K + 3) // 4 * 4
+    W = np.zeros((Cout, ldw), np.float32); W[:, :K] = w.reshape(Cout, K)
+    xt = torch.from_numpy(x).double().requires_grad_(True); wt = torch.from_numpy(w).double().requires_grad_(True)
+    ref = F.conv2d(xt, wt, stride=stride, padding=1)
+    x_cnhw = dev(np.ascontiguousarray(x.transpose(1, 0, 2, 3)))
+    out = nat.conv3_igemm(dev(W), x_cnhw, stride)
+    np.testing.assert_allclose(out.cpu().numpy().transpose(1, 0, 2, 3), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    dy = rng.standard_normal(tuple(ref.shape)).astype(np.float32)
+    ref.backward(torch.from_numpy(dy).double())
+    dy_cnhw = dev(np.ascontiguousarray(dy.transpose(1, 0, 2, 3)))
+    if (B * ref.shape[2] * ref.shape[3]) % 4 == 0:
+        dW = nat.conv3_igemm_dw(dy_cnhw, x_cnhw, ldw, stride, slabs=5)
+        np.testing.assert_allclose(dW.cpu().numpy()[:, :K].reshape(w.shape), wt.grad.numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(B * ref.shape[2] * ref.shape[3]))
+        assert float(dW[:, K:].abs().max()) == 0.0 if ldw > K else True
+    if stride == 1:
+        Wt = nat.conv3_flip_weights(dev(W), Cin)
+        dx = nat.conv3_igemm(Wt, dy_cnhw, 1)
+        np.testing.assert_allclose(dx.cpu().numpy().transpose(1, 0, 2, 3), xt.grad.numpy(), rtol=2e-5, atol=5e-5)

@@ -1155,7 +1155,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
 
 static inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 static inline bool mid_route_ok(const GemmArgs& g, bool vec) {
-    if (!vec || g.a_kmajor || g.dact_pre || g.mask || g.accumulate || g.slab || g.ksplit > 1 || g.alpha != 1.f) return false;
+    if (!vec || g.a_kmajor || g.mask || g.accumulate || g.slab || g.ksplit > 1 || g.alpha != 1.f) return false;
     if (g.b_kmajor && (g.act != ACT_NONE || g.N % 64 != 0)) return false;
     if (!gemm_mid_ok(g.M, g.N, g.K, 1, g.act, g.A, g.lda, g.B, g.ldb) || g.N % 64 != 0) return false;
     if (g.M > 1024) { const long wg = (long)(g.M / 80) * (g.N / 64); return g.M % 80 == 0 && wg >= 192 && wg <= 512; }
@@ -1224,7 +1224,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     // (W [K][N]) forms, optional pre-activation output.  The profiler records them under gemm_mid's own entry.
     if (g_force_kernel == 0 && mid_route_ok(g, vec)) {
         prof.cancel();
-        return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, nullptr, g.M, g.N, g.K, 1, s);
+        return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, nullptr, g.M, g.N, g.K, 1, s, g.dact_pre, g.dact);
     }
     prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor;
     int r;

@@ -37,6 +37,7 @@ struct MidArgs {
     const float* residual; int ldr;       // optional, added after the activation (ksplit == 1 only)
     float* C; int ldc;                    // ksplit == 1: output; else unused
     float* preact;                        // optional second output (row stride ldc): the value before the activation (training forward)
+    const float* dact_pre; int dact;      // optional (row stride ldc): multiply by act'(dact_pre) of kind `dact` (tangent pass through a saved pre-activation)
     float* slab;                          // ksplit > 1: [ksplit][M][N] raw partial products
     int M, N, K, ksplit, act;
 };
@@ -183,6 +184,7 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
                         float v = acc[i][j][e] + bcol;
                         if (g.preact) g.preact[(size_t)row * g.ldc + col] = v;
                         v = mid_act<ACT>(v);
+                        if (g.dact_pre) v *= act_grad(g.dact_pre[(size_t)row * g.ldc + col], g.dact);
                         if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
                         g.C[(size_t)row * g.ldc + col] = v;
                     }
@@ -218,7 +220,7 @@ static int launch_mid(const MidArgs& g, hipStream_t s) {
 static inline bool mid_tall80(int M, int N, int ksplit) {
     if (M <= 1024 || M % 80 != 0 || N % MID_BN != 0) return false;
     const long wg = (long)(M / 80) * (N / MID_BN) * ksplit;
-    return wg >= 192 && wg <= 512;
+    return wg >= 192 && wg <= 512;      // (2 560 x 256 as 128 workgroups was measured: slower than the 64 x 64 tiling, 5.41 against 5.23 ms per rollout + BPTT)
 }
 template <int ACT, bool BKM>
 static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
@@ -242,13 +244,13 @@ bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int l
 // (raw partials; bias / act / residual are the consumer's: adaln_sum or slab_sum); act must be NONE then.
 // w_kmajor: W is [K][N] (row stride ldw) - the data-gradient form; needs N % 64 == 0 and no split.
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
-                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
+                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre, int dact) {
     AID_REQUIRE(gemm_mid_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
     AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && act == ACT_NONE && !residual && !preact), AID_E_SHAPE, "gemm_mid: split-K writes raw slabs only");
     AID_REQUIRE(!w_kmajor || (N % MID_BN == 0 && act == ACT_NONE), AID_E_SHAPE, "gemm_mid: contraction-major W needs N %% 64 == 0 and no activation (N=%d)", N);
     MidArgs g; memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.preact = preact; g.slab = slab;
-    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
+    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act; g.dact_pre = ksplit == 1 ? dact_pre : nullptr; g.dact = dact;
     ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const int bmt = mid_tall80(M, N, ksplit) ? 5 : ((M + 255) / 256 > 4 ? 4 : (M + 255) / 256);
     prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * bmt + act + (w_kmajor ? 64 : 0); prof.variant = 22;      // layout field: 8 BMF + act (+ 64: contraction-major W) = the instantiation
@@ -262,7 +264,7 @@ int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
 }
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
-    return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s);
+    return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s, nullptr, 0);
 }
 
 // ---- consumers of the split-K slabs ---------------------------------------------------------------------------------------------

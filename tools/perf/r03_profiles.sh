@@ -11,10 +11,13 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 be
 echo stats done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_noov -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-overlap > $OUT/stats_noov.log 2>&1
 echo stats_noov done
+# "_cold": no warm-up train_steps in the process, so that a phase's summary holds the phase's kernels only (5 calls + 1 for the launch dump)
 for ph in elbo rollout_bptt efe chain1 chains3 value_dynamics optimiser; do
-  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/phase_$ph -- python3 $P $ph 5 > $OUT/phase_$ph.log 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/phase_$ph -- python3 $P ${ph}_cold 5 > $OUT/phase_$ph.log 2>&1
   echo phase $ph done
 done
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/phase_pixel_epistemic -- python3 $P pixel_epistemic 1 > $OUT/phase_pixel_epistemic.log 2>&1
+echo phase pixel_epistemic done
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $P chain1_direct_cold 1 > $OUT/fetch.log 2>&1
 echo fetch done
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $P chain1_direct_cold 1 > $OUT/write.log 2>&1

@@ -2,6 +2,7 @@
 `train_step`, optimiser attributes and metric keys; each phase of train_step is one fused HIP call."""
 from __future__ import annotations
 
+import sys
 from typing import Dict
 
 import numpy as np
@@ -105,7 +106,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                 self.dp_schedule_choice = "chains" if v["ms"]["chains"] <= v["ms"]["merged"] else "merged"
                 if parallel.rank() == 0:
                     print(f"[aid_amd] data parallel, {parallel.world()} ranks: belief loops as concurrent chains {v['ms']['chains']:.2f} ms/step, "
-                          f"merged {v['ms']['merged']:.2f} ms/step (slowest rank) -> {self.dp_schedule_choice}", flush=True)
+                          f"merged {v['ms']['merged']:.2f} ms/step (slowest rank) -> {self.dp_schedule_choice}", file=sys.stderr, flush=True)
                 self.dp_schedule_ms = dict(v["ms"])
                 self._dp_vote = None
                 return self.dp_schedule_choice == "chains"

@@ -78,7 +78,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     # -- data parallel: which belief-loop schedule to run -----------------------------------------------------------------------------
     # A process has four hardware queues (aid_amd/streams.py).  Main + side + two chain streams use all four; RCCL's internal stream is a
     # fifth, and a reverse loop that ends up sharing a queue with the estimator's stream costs 2x (98-108 ms against 54 per cfg-2 step).
-    # With ONE rank on real RCCL the concurrent chains still paid (54.9 against 61.5 ms merged, tools/perf/dp_one_rank_time.py), but how
+    # With ONE rank on real RCCL the concurrent chains still paid (52.0 against 59.6 ms merged in round 3, tools/perf/dp_one_rank_time.py), but how
     # many streams an N-rank communicator uses is RCCL's business.  So a data-parallel agent MEASURES: after DP_VOTE_WARM warm-up steps it
     # times DP_VOTE_STEPS steps with the concurrent chains and as many with the merged loop (host clock around a device sync, each
     # rank; the slowest rank's time counts: one MAX all-reduce per arm), keeps the faster schedule for the rest of the run and says so

@@ -12,6 +12,7 @@ parallel.is_dp = lambda: True
 if os.environ.get("AID_OWN_MAIN"):          # run everything on a non-default stream: the legacy default stream synchronises implicitly with blocking streams
     _m = torch.cuda.Stream(); torch.cuda.set_stream(_m)
 agent = bench.make_agent(torch.device("cuda"))
+agent.dp_autotune_schedule = False      # this tool sets the schedule by hand
 agent.enable_data_parallel()
 for mode, la in ((True, True), (True, False), (False, False), (True, True), (True, False)):
     agent.concurrent_belief_loops = mode; agent.lookahead_elbo = la

@@ -130,14 +130,29 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
     __syncthreads();
     float* xw = xs + wave * XR * KP;
     const int nblk = (M + XR - 1) / XR;
+    // the x values of a block are fetched one block ahead (registers), so that their latency hides behind the previous block's FMAs: with
+    // 70 KB of LDS there are two waves per SIMD and nobody else to hide a load behind
+    float xn[XR * KP / 64];
+    auto fetch = [&](int blk) {
+        const int r0 = blk * XR;
+#pragma unroll
+        for (int h = 0; h < XR * KP / 64; ++h) {
+            const int r = h * 2 + (lane >> 5), k = lane & 31;
+            const bool ok = k < K && r0 + r < M && blk < nblk;
+            xn[h] = x[ok ? (size_t)(r0 + r) * ldx + k : 0];
+            if (!ok) xn[h] = 0.f;
+        }
+    };
+    fetch(blockIdx.x * 4 + wave);
     for (int blk = blockIdx.x * 4 + wave; blk < nblk; blk += gridDim.x * 4) {
         const int r0 = blk * XR;
         // this wave's XR rows of x -> LDS (lane = r * KP + k for the first XR*KP lanes; KP = 32 so two rows per 64 lanes)
 #pragma unroll
         for (int h = 0; h < XR * KP / 64; ++h) {
             const int r = h * 2 + (lane >> 5), k = lane & 31;
-            xw[r * KP + k] = (k < K && r0 + r < M) ? x[(size_t)(r0 + r) * ldx + k] : 0.f;
+            xw[r * KP + k] = xn[h];
         }
+        fetch(blk + gridDim.x * 4);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();   // other lanes' x values are read below
         f4 acc[XR][NV];
 #pragma unroll
@@ -160,6 +175,36 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
             }
         }
         __builtin_amdgcn_wave_barrier();          // all reads of xw done before the next block overwrites it
+        // LayerNorm statistics of the XR rows together: the XR butterfly chains are independent, so their cross-lane latencies overlap
+        // (one row at a time, 12 dependent shuffles per row were ~30 % of the block's cycles at two waves per SIMD)
+        float mean[XR], rstd[XR];
+        {
+            float sm[XR];
+#pragma unroll
+            for (int r = 0; r < XR; ++r) {
+                sm[r] = 0.f;
+#pragma unroll
+                for (int i = 0; i < NV; ++i) sm[r] += (acc[r][i][0] + acc[r][i][1]) + (acc[r][i][2] + acc[r][i][3]);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int r = 0; r < XR; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) { mean[r] = sm[r] / (float)D; sm[r] = 0.f; }
+#pragma unroll
+            for (int r = 0; r < XR; ++r)
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float d = acc[r][i][j] - mean[r]; sm[r] += d * d; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+                for (int r = 0; r < XR; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+#pragma unroll
+            for (int r = 0; r < XR; ++r) rstd[r] = 1.0f / sqrtf(sm[r] / (float)D + 1e-5f);
+        }
 #pragma unroll
         for (int r = 0; r < XR; ++r) {
             const int row = r0 + r;
@@ -168,17 +213,7 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
 #pragma unroll
                 for (int i = 0; i < NV; ++i) reinterpret_cast<f4*>(lin + (size_t)row * D)[lane + 64 * i] = acc[r][i];
             }
-            float sm = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) sm += (acc[r][i][0] + acc[r][i][1]) + (acc[r][i][2] + acc[r][i][3]);
-            const float mean = wave_sum(sm) / (float)D;
-            float q = 0.f;
-#pragma unroll
-            for (int i = 0; i < NV; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { const float d = acc[r][i][j] - mean; q += d * d; }
-            const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
-            if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rstd; }
+            if (stats && lane == 0) { stats[2 * row] = mean[r]; stats[2 * row + 1] = rstd[r]; }
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 f4 o, gg = {1.f, 1.f, 1.f, 1.f}, bb = {0.f, 0.f, 0.f, 0.f}, mm = {1.f, 1.f, 1.f, 1.f}, aa = {0.f, 0.f, 0.f, 0.f};
@@ -186,7 +221,7 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
                 if (mask) mm = reinterpret_cast<const f4*>(mask + (size_t)row * D)[lane + 64 * i];
                 if (add) aa = reinterpret_cast<const f4*>(add + (size_t)row * D)[lane + 64 * i];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = act_apply((acc[r][i][j] - mean) * rstd * gg[j] + bb[j], ACT) * mm[j] + aa[j];
+                for (int j = 0; j < 4; ++j) o[j] = act_apply((acc[r][i][j] - mean[r]) * rstd[r] * gg[j] + bb[j], ACT) * mm[j] + aa[j];
                 reinterpret_cast<f4*>(y + (size_t)row * ldy)[lane + 64 * i] = o;
             }
         }

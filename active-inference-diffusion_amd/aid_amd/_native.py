@@ -242,7 +242,7 @@ def lib() -> C.CDLL:
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
                  "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
-                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace"):
+                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != 1:
@@ -294,10 +294,20 @@ def score_net_table(params: Dict[str, torch.Tensor], prefix: str, L: int, O: int
 
 # ------------------------------------------------------------------------------------------------
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, bias=None, act="none", residual=None,
-         ldr=0, alpha=1.0, accumulate=0):
+         ldr=0, alpha=1.0, accumulate=0, scratch=None):
+    if scratch is not None:      # with scratch the mid-size split-K route (K slices folded in the kernel) is open to the dispatcher
+        check(lib().aid_gemm_f32_scratch(_ptr(A), lda, a_kmajor, _ptr(B), ldb, b_kmajor, _ptr(C_out), ldc, M, N, K, _ptr(bias), ACT[act],
+                                         _ptr(residual), ldr, C.c_float(alpha), accumulate, _ptr(scratch), C.c_size_t(scratch.numel() * scratch.element_size()),
+                                         _stream()), "aid_gemm_f32_scratch")
+        return C_out
     check(lib().aid_gemm_f32(_ptr(A), lda, a_kmajor, _ptr(B), ldb, b_kmajor, _ptr(C_out), ldc, M, N, K, _ptr(bias), ACT[act],
                              _ptr(residual), ldr, C.c_float(alpha), accumulate, _stream()), "aid_gemm_f32")
     return C_out
+
+
+def gemm_scratch(device="cuda"):
+    """Scratch for gemm(..., scratch=): K slices and tile counters of the mid-size split-K route."""
+    return torch.empty((lib().aid_gemm_scratch_bytes() + 3) // 4, dtype=torch.float32, device=device)
 
 
 def fill_normal(out, seed, offset):

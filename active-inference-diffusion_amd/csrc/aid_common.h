@@ -85,6 +85,15 @@ inline GemmArgs gemm_args(const float* A, int lda, const float* B, int ldb, floa
     return g;
 }
 int gemm_f32(const GemmArgs& g, hipStream_t s);
+// Scratch for gemm_f32's split-K route (129..1024 rows x <= 1024 columns: too few 64-wide tiles for 256 CUs, so K is cut into slices and the
+// last slice to arrive folds them, gemm_mid.hip).  An entry point that owns a Workspace opens one scope for its stream; every gemm_f32 call of
+// this thread on that stream may then take the route.  Slices and tile counters live in the caller's workspace: nothing is kept between calls.
+struct SplitScope {
+    float* slab; size_t floats; int* ctr; int nctr; hipStream_t s; SplitScope* prev;
+    SplitScope(Workspace& ws, hipStream_t s, size_t floats = (size_t)1 << 20, int nctr = 256);
+    ~SplitScope();
+    static size_t bytes(size_t floats = (size_t)1 << 20, int nctr = 256) { return floats * sizeof(float) + nctr * sizeof(int) + 512; }
+};
 // tall plain Linear through 64-row x 512-column full-K workgroups (gemm_rowln.hip); gemm_f32 routes to it
 bool linear_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, int ldw);
 int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b, int act, const float* mask, int ldmask, const float* add, int ldadd,

@@ -379,7 +379,7 @@ size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec,
     size_t n = 2 * score_acts_bytes(*net, B, true) + score_tan_bytes(*net, B) + score_reverse_ws_bytes(*net, B) +
                score_cond_backward_ws_bytes(*net, B) + (dec ? decoder_ws_bytes(*dec, B) : 0);
     n += sizeof(float) * (size_t)B * ((size_t)(2 * net->n_blocks + 1) * 2 * D + 12 * L + 2 * D + (dec ? dec->O + 2 * dec->s[0].out + dec->s[2].out : net->O) + 8 * D + 64);
-    return n + (1 << 16);
+    return n + (1 << 16) + SplitScope::bytes();
 }
 
 int aid_mse(const float* a, int lda, const float* b, int ldb, int M, int N, float* out, void* stream) {
@@ -438,6 +438,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     const int D = n.D, L = n.L, O = dec ? dec->O : n.O, NA = 2 * n.n_blocks + 1, ldmod = NA * 2 * D;
     const bool train = cfg->train != 0;
     Workspace ws(wsp, ws_bytes);
+    SplitScope split(ws, s);           // the 256-row x 512-column products of both passes: K slices folded in the kernel (gemm_mid.hip)
     uint64_t ctr = cfg->offset;
     auto draw = [&](const float* given, size_t cnt, int kind, float p, const float** out) -> int {
         if (given) { *out = given; return AID_OK; }

@@ -1161,6 +1161,27 @@ static inline bool mid_route_ok(const GemmArgs& g, bool vec) {
     if (g.M > 1024) { const long wg = (long)(g.M / 80) * (g.N / 64); return g.M % 80 == 0 && wg >= 192 && wg <= 512; }
     return g.N >= 2048 && g.N <= 4096;       // 8 row tiles x >= 32 column tiles
 }
+static thread_local SplitScope* t_split = nullptr;
+SplitScope::SplitScope(Workspace& ws, hipStream_t st, size_t fl, int nc) : slab(ws.f32(fl)), floats(fl), ctr((int*)ws.raw(nc * sizeof(int))), nctr(nc), s(st), prev(t_split) {
+    if (!slab || !ctr || hipMemsetAsync(ctr, 0, nc * sizeof(int), st) != hipSuccess) { slab = nullptr; ctr = nullptr; }      // no scratch: no route
+    t_split = this;
+}
+SplitScope::~SplitScope() { t_split = prev; }
+// K slices for the split route: 0 = not this problem.  8 row tiles x N / 64 column tiles; slices double while they still fit the chip and
+// leave each an even number of 64-deep stages.
+static inline int mid_split_factor(const GemmArgs& g, bool vec, hipStream_t s) {
+    const SplitScope* sc = t_split;
+    if (!sc || !sc->slab || sc->s != s || !vec || g.a_kmajor || g.mask || g.slab || g.ksplit > 1 || g.alpha != 1.f) return 0;
+    // (K = 512: two slices of four stages each measured level with the panel kernel at 256 rows and behind it at 512 - the fold's tail, stores
+    // through the L2, the counter and the read-back, is ~4 us)
+    if (g.M <= 128 || g.M > 1024 || g.N % 64 != 0 || g.N > 1024 || g.K < 1024 || (g.b_kmajor && g.act != ACT_NONE)) return 0;
+    if (!(g.act == ACT_NONE || g.act == ACT_GELU || g.act == ACT_SILU || g.act == ACT_RELU)) return 0;
+    const int tiles = 8 * (g.N / 64);
+    int ks = 1;
+    while (ks < 8 && tiles * ks * 2 <= 256 && g.K % (256 * ks) == 0 && g.K / (2 * ks) >= 256) ks *= 2;      // a slice is at least four 64-deep stages
+    if (ks < 2 || tiles > sc->nctr || (size_t)ks * g.M * g.N > sc->floats) return 0;
+    return gemm_mid_ok(g.M, g.N, g.K, ks, g.act, g.A, g.lda, g.B, g.ldb) ? ks : 0;
+}
 // true when the automatic dispatcher sends this problem to gemm_tile_kernel (profiling label only)
 static inline bool routes_to_tile(const GemmArgs& g) {
     return g_force_kernel == 0 && (long)((g.M + 63) / 64) * ((g.N + 63) / 64) >= 160;
@@ -1222,6 +1243,11 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     // layers that one-workgroup-per-CU tiles fit exactly (gemm_mid.hip): K*B = 2 560 rows x 512 columns of the rollout / BPTT as 80 x 64 tiles,
     // 129..1024 rows x >= 2048 columns (the DiT MLP's wide layer in the ELBO passes) as 8 row tiles; forward (W [N][K]) and data-gradient
     // (W [K][N]) forms, optional pre-activation output.  The profiler records them under gemm_mid's own entry.
+    if (const int ks = g_force_kernel == 0 ? mid_split_factor(g, vec, s) : 0) {
+        prof.cancel();
+        return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, t_split->slab, g.M, g.N, g.K, ks, s, g.dact_pre,
+                           g.dact, t_split->ctr, g.accumulate);
+    }
     if (g_force_kernel == 0 && mid_route_ok(g, vec)) {
         prof.cancel();
         return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, nullptr, g.M, g.N, g.K, 1, s, g.dact_pre, g.dact);

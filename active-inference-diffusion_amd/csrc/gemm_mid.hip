@@ -39,6 +39,10 @@ struct MidArgs {
     float* preact;                        // optional second output (row stride ldc): the value before the activation (training forward)
     const float* dact_pre; int dact;      // optional (row stride ldc): multiply by act'(dact_pre) of kind `dact` (tangent pass through a saved pre-activation)
     float* slab;                          // ksplit > 1: [ksplit][M][N] raw partial products
+    int* ctr;                             // ksplit > 1, optional: one arrival counter per output tile (zero at launch, zero again at exit).  The
+                                          //   workgroup that arrives LAST at a tile folds the slices in slice order and runs the full epilogue
+                                          //   into C: a split-K GEMM that is complete when the kernel ends, bit-reproducible (gemm_f32's route)
+    int accumulate;                       // C += (act must be NONE; ksplit == 1 or folded)
     int M, N, K, ksplit, act;
 };
 
@@ -169,25 +173,86 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
         __syncthreads();
     }
     // ---- epilogue.  C/D of 16x16x4: column = lane & 15, rows 4 (lane >> 4) + {0..3}
+    if (g.ksplit > 1) {
+        const bool fold = g.ctr != nullptr;
+#pragma unroll
+        for (int i = 0; i < BMF; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int col = n0 + wn + 16 * j + r16;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int row = m0 + wm + 16 * i + 4 * kq + e;
+                    if (row < g.M && col < g.N) {
+                        float* p = g.slab + ((size_t)ky * g.M + row) * g.N + col;
+                        if (fold) __hip_atomic_store(p, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // written through the XCD's L2
+                        else *p = acc[i][j][e];
+                    }
+                }
+            }
+        if (!fold) return;                // raw slabs: the consumer folds them
+        // The slices of a tile may sit on different XCDs (one L2 each, not coherent with each other inside a kernel): partials are stored
+        // and read back with device-scope accesses, which pass the L2 (no cache write-back / invalidate: an agent-scope fence per workgroup
+        // costs ~40 us here), a thread waits for its own stores to be acknowledged before the barrier, and one thread then counts the
+        // arrival.  Whoever counts the last one reads the other slices and finishes the tile.  The fold runs in slice order whoever folds,
+        // and a slice's partial is the same bits from a register or from memory: the result does not depend on the arrival order.
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tile = tn * tiles_m + tm;
+        if (tid == 0) s_last = __hip_atomic_fetch_add(g.ctr + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == g.ksplit - 1;
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) __hip_atomic_store(g.ctr + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // for the next launch on this stream
+        f32x4 sum[BMF][NJ];
+        for (int y0 = 0; y0 < g.ksplit; y0 += 4) {    // slice order; four slices' loads are in flight together
+            f32x4 part[4][BMF][NJ];
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy)
+#pragma unroll
+                for (int i = 0; i < BMF; ++i)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const int col = n0 + wn + 16 * j + r16, y = y0 + yy;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int row = m0 + wm + 16 * i + 4 * kq + e;
+                            part[yy][i][j][e] = acc[i][j][e];
+                            if (y != ky && y < g.ksplit && row < g.M && col < g.N)
+                                part[yy][i][j][e] = __hip_atomic_load(g.slab + ((size_t)y * g.M + row) * g.N + col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+#pragma unroll
+            for (int yy = 0; yy < 4; ++yy)
+                if (y0 + yy < g.ksplit) {
+#pragma unroll
+                    for (int i = 0; i < BMF; ++i)
+#pragma unroll
+                        for (int j = 0; j < NJ; ++j) sum[i][j] = y0 + yy == 0 ? part[yy][i][j] : sum[i][j] + part[yy][i][j];
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < BMF; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = sum[i][j];
+    }
 #pragma unroll
     for (int i = 0; i < BMF; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int col = n0 + wn + 16 * j + r16;
-            const float bcol = (g.ksplit == 1 && g.bias && col < g.N) ? g.bias[col] : 0.f;
+            const float bcol = (g.bias && col < g.N) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int row = m0 + wm + 16 * i + 4 * kq + e;
                 if (row < g.M && col < g.N) {
-                    if (g.ksplit > 1) g.slab[((size_t)ky * g.M + row) * g.N + col] = acc[i][j][e];
-                    else {
-                        float v = acc[i][j][e] + bcol;
-                        if (g.preact) g.preact[(size_t)row * g.ldc + col] = v;
-                        v = mid_act<ACT>(v);
-                        if (g.dact_pre) v *= act_grad(g.dact_pre[(size_t)row * g.ldc + col], g.dact);
-                        if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
-                        g.C[(size_t)row * g.ldc + col] = v;
-                    }
+                    float v = acc[i][j][e] + bcol;
+                    if (g.preact) g.preact[(size_t)row * g.ldc + col] = v;
+                    v = mid_act<ACT>(v);
+                    if (g.dact_pre) v *= act_grad(g.dact_pre[(size_t)row * g.ldc + col], g.dact);
+                    if (g.residual) v += g.residual[(size_t)row * g.ldr + col];
+                    if (g.accumulate) v += g.C[(size_t)row * g.ldc + col];
+                    g.C[(size_t)row * g.ldc + col] = v;
                 }
             }
         }
@@ -241,19 +306,23 @@ bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int l
 }
 
 // ksplit == 1: C = act(A W^T + bias) + residual (preact, optional: the value before the activation).  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T
-// (raw partials; bias / act / residual are the consumer's: adaln_sum or slab_sum); act must be NONE then.
-// w_kmajor: W is [K][N] (row stride ldw) - the data-gradient form; needs N % 64 == 0 and no split.
+// (raw partials; bias / act / residual are the consumer's: adaln_sum or slab_sum; act must be NONE then) - or, with `ctr` (one zeroed int per
+// output tile), the slices are folded in the kernel and C gets the full epilogue as at ksplit == 1.
+// w_kmajor: W is [K][N] (row stride ldw) - the data-gradient form; needs N % 64 == 0.
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
-                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre, int dact) {
+                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre, int dact, int* ctr, int accumulate) {
     AID_REQUIRE(gemm_mid_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
-    AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && act == ACT_NONE && !residual && !preact), AID_E_SHAPE, "gemm_mid: split-K writes raw slabs only");
+    AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && (ctr ? C != nullptr : (act == ACT_NONE && !residual && !preact && !accumulate))), AID_E_SHAPE,
+                "gemm_mid: split-K writes raw slabs unless tile counters are given");
+    AID_REQUIRE(!accumulate || act == ACT_NONE, AID_E_SHAPE, "gemm_mid: accumulate with an activation");
     AID_REQUIRE(!w_kmajor || (N % MID_BN == 0 && act == ACT_NONE), AID_E_SHAPE, "gemm_mid: contraction-major W needs N %% 64 == 0 and no activation (N=%d)", N);
     MidArgs g; memset(&g, 0, sizeof(g));
     g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.residual = residual; g.ldr = ldr; g.C = C; g.ldc = ldc; g.preact = preact; g.slab = slab;
-    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act; g.dact_pre = ksplit == 1 ? dact_pre : nullptr; g.dact = dact;
+    g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act; g.dact_pre = (ksplit == 1 || ctr) ? dact_pre : nullptr; g.dact = dact;
+    g.ctr = ksplit > 1 ? ctr : nullptr; g.accumulate = accumulate;
     ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     const int bmt = mid_tall80(M, N, ksplit) ? 5 : ((M + 255) / 256 > 4 ? 4 : (M + 255) / 256);
-    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * bmt + act + (w_kmajor ? 64 : 0); prof.variant = 22;      // layout field: 8 BMF + act (+ 64: contraction-major W) = the instantiation
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 * bmt + act + (w_kmajor ? 64 : 0); prof.variant = g.ctr ? 24 : 22;      // layout field: 8 BMF + act (+ 64: contraction-major W) = the instantiation
     if (w_kmajor) return launch_mid_bm<ACT_NONE, true>(g, s);
     switch (act) {
         case ACT_GELU: return launch_mid_bm<ACT_GELU, false>(g, s);
@@ -264,7 +333,7 @@ int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
 }
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
-    return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s, nullptr, 0);
+    return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s, nullptr, 0, nullptr, 0);
 }
 
 // ---- consumers of the split-K slabs ---------------------------------------------------------------------------------------------

@@ -58,7 +58,8 @@ int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias
              float* slab, int M, int N, int K, int ksplit, hipStream_t s);
 // general form: w_kmajor = W stored [K][N] (the data gradient dX = dY W of a Linear: the weight as it is), preact = optional second output
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
-                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre = nullptr, int dact = 0);
+                float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre = nullptr, int dact = 0, int* ctr = nullptr,
+                int accumulate = 0);      // ctr: fold the K slices in the kernel (one zeroed int per output tile) and run the full epilogue into C
 // x_new = res + bias + sum of `nslab` slabs [M,D] (fixed order) -> xout (optional);  y = LN(x_new) (1 + scale) + shift (adaLN, mod row = [scale | shift])
 bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
                   const float* y, int ldy);

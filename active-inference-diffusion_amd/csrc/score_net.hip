@@ -437,6 +437,16 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
     return gemm_f32(g, (hipStream_t)stream);
 }
 
+int aid_gemm_f32_scratch(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N, int K,
+                         const float* bias, int act, const float* residual, int ldr, float alpha, int accumulate, void* scratch, size_t scratch_bytes,
+                         void* stream) {
+    AID_REQUIRE(scratch && scratch_bytes >= SplitScope::bytes(), AID_E_WORKSPACE, "aid_gemm_f32_scratch: scratch of %zu bytes, need %zu", scratch_bytes, SplitScope::bytes());
+    Workspace ws(scratch, scratch_bytes);
+    SplitScope split(ws, (hipStream_t)stream);
+    return aid_gemm_f32(A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias, act, residual, ldr, alpha, accumulate, stream);
+}
+size_t aid_gemm_scratch_bytes(void) { return SplitScope::bytes(); }
+
 int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int K, const float* bias,
                         int ksplit, void* stream) {
     GemmArgs g = gemm_args(A, lda, B, ldb, C, ldc, M, N, K);

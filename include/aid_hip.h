@@ -63,6 +63,15 @@ int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb,
                  int M, int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha,
                  int accumulate, void* stream);
 
+/* The same, with scratch (aid_gemm_scratch_bytes() bytes, borrowed for the call): problems of 129..1024 rows x <= 1024 columns with K >= 1024
+ * (the DiT blocks' 512-wide products in aid_elbo_step's passes) are then cut into K slices over ~256 workgroups; the slice that arrives last
+ * at an output tile folds the others in slice order and applies the epilogue (csrc/gemm_mid.hip), so the result is complete when the kernel
+ * ends and identical run to run.  Unit-test entry for that route; aid_elbo_step takes the scratch from its workspace. */
+int aid_gemm_f32_scratch(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M, int N, int K,
+                         const float* bias, int act, const float* residual, int ldr, float alpha, int accumulate, void* scratch, size_t scratch_bytes,
+                         void* stream);
+size_t aid_gemm_scratch_bytes(void);
+
 /* y[M,N] = act(LayerNorm(x W^T + b) * gamma + beta) * mask + add in ONE kernel (full-row tiles, LayerNorm in the GEMM epilogue; csrc/gemm_rowln.hip):
  * N in {512, 1024}, M >= 2048, K >= 64 and a multiple of 4, 16-B aligned operands, act in {0 none, 1 relu, 2 silu}; mask [M,N] (row stride N) / add / gamma / beta / b
  * may be NULL.  What Linear -> LayerNorm -> SiLU stages of the observation decoder run as on the estimator's sample rows

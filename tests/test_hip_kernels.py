@@ -550,6 +550,42 @@ def test_gemm_mid_routed_shapes(nat, M, N, K, lay, act):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,lay,act,acc", [(256, 512, 2048, "nt", "none", 0), (256, 512, 2048, "nn", "none", 1), (512, 512, 2048, "nn", "none", 0),
+                                               (256, 1024, 1024, "nt", "gelu", 0), (200, 512, 13312, "nn", "none", 0), (768, 256, 1024, "nt", "silu", 0)])
+def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):
+    """gemm_f32's split-K route for 129..1024 rows x <= 1024 columns, K >= 1024 (csrc/gemm_mid.hip with tile counters; what aid_elbo_step's passes
+    take for the DiT blocks' 512-wide products): K slices over ~256 workgroups, the last slice to arrive folds the others in slice order and
+    applies bias / activation / residual / accumulate.  Checked against fp64, for bit-identical repeats (the fold order is fixed whoever folds),
+    for the profile naming the route (variant 24) and for the tile counters being back at zero (the same scratch serves every call)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N) if lay == "nn" else (N, K)).astype(np.float32) / np.sqrt(K)
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32); C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ (W if lay == "nn" else W.T).astype(np.float64) + b
+    f = {"none": lambda x: x, "silu": lambda x: x / (1 + np.exp(-x)), "gelu": lambda x: 0.5 * x * (1 + np.vectorize(__import__("math").erf)(x / np.sqrt(2)))}[act]
+    ref = f(ref) + R + (C0 if acc else 0)
+    scratch = nat.gemm_scratch()
+    Ad, Wd, bd, Rd = dev(A), dev(W), dev(b), dev(R)
+    outs = []
+    nat.prof_enable(True); nat.prof_reset()
+    for _ in range(3):
+        C = dev(C0.copy())
+        nat.gemm(Ad, Wd, C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc, scratch=scratch)
+        outs.append(C.cpu().numpy())
+    torch.cuda.synchronize()
+    nat.prof_dump(str(tmp_path / "prof.csv"))
+    nat.prof_enable(False); nat.prof_reset()
+    import csv
+    recs = list(csv.DictReader(open(tmp_path / "prof.csv")))
+    np.testing.assert_allclose(outs[0], ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    assert len(recs) == 3 and all(int(r["variant"]) == 24 for r in recs), recs
+    # without scratch the dispatcher takes another kernel: same value to rounding
+    C = dev(C0.copy())
+    nat.gemm(Ad, Wd, C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc)
+    np.testing.assert_allclose(C.cpu().numpy(), outs[0], rtol=2e-5, atol=2e-5 * np.sqrt(K))
+
+
 @pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2)])
 def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     """csrc/conv_igemm.hip against torch's conv2d on the CPU (fp64): forward (border taps, stride 2, ragged channel counts), the data

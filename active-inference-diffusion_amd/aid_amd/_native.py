@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libaid_hip.so")
 AID_MAX_BLOCKS = 8
 T_DISCRETE, T_CONTINUOUS = 0, 1
-ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3}
+ACT = {"none": 0, "relu": 1, "silu": 2, "gelu": 3, "mish": 4, "tanh": 5}
 PROF_GEMM, PROF_ROWWISE, PROF_OPTIM, PROF_GEMM_TILE = 0, 1, 2, 3
 
 _fp = C.POINTER(C.c_float)

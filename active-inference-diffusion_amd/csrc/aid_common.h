@@ -94,6 +94,9 @@ struct SplitScope {
     ~SplitScope();
     static size_t bytes(size_t floats = (size_t)1 << 20, int nctr = 256) { return floats * sizeof(float) + nctr * sizeof(int) + 512; }
 };
+// thin outputs (N <= 32) at 33..8192 rows: W in LDS, a wave per four rows (gemm_thin.hip); gemm_f32 routes to it
+bool gemm_thin_n_ok(const GemmArgs& g);
+int gemm_thin_n(const GemmArgs& g, hipStream_t s);
 // tall plain Linear through 64-row x 512-column full-K workgroups (gemm_rowln.hip); gemm_f32 routes to it
 bool linear_rows_ok(int M, int N, int K, int act, const float* x, int ldx, const float* W, int ldw);
 int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b, int act, const float* mask, int ldmask, const float* add, int ldadd,

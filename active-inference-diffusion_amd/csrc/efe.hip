@@ -306,7 +306,7 @@ size_t aid_efe_step_workspace(const AidPolicyNet* pol, const AidDecoderNet* dec,
     if (!pol || !cfg || B <= 0 || (!dec && !cfg->skip_epistemic)) return 0;
     const size_t M = (size_t)cfg->K * B, R = M * cfg->S, D = pol->D, H = cfg->H;
     size_t n = dec ? mine_ws_bytes(*dec, (int)(H * cfg->K), cfg->S, B) : 0;     // the estimator runs over all H horizon steps in one pass
-    n += sizeof(float) * H * M * (48 * D + 128 + 2 * pol->L);                   // per-step saved activations (policy, dynamics, reward, value) + the policy adjoints the deferred weight gradients read
+    n += sizeof(float) * H * M * (52 * D + 128 + 2 * pol->L);                   // per-step saved activations (policy, dynamics, reward, value) + the policy adjoints the deferred weight gradients read
     n += sizeof(float) * M * (24 * D + 64);                           // backward scratch
     n += sizeof(float) * 8 * (4 * D * D + 2 * (size_t)pol->mean0.out * D + 2 * (size_t)pol->A * pol->mean0.out + D * (size_t)pol->L + 16 * D) + 4096;      // partial tiles of the split policy-gradient contractions
     n += sizeof(float) * (H * (M * (pol->A + pol->L) + R * pol->L * 5 + R * 512 * 5) + R * H);   // Philox noise when not given
@@ -436,7 +436,7 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
         gq.scratch_floats = 8 * (4 * Dp * Dp + 2 * Hh * Dp + 2 * (size_t)pol->A * Hh + Dp * (size_t)L + 16 * Dp);
         gq.scratch = ws.f32(gq.scratch_floats); AID_WS_OK(ws);
     }
-    AID_TRY(policy_bptt_grads(*pol, *pgrads, psteps, cur_all, L, gq));
+    AID_TRY(policy_bptt_grads(*pol, *pgrads, psteps, cur_all, L, gq, ws));
     AID_TRY(gq.flush());
     return AID_OK;
 }

@@ -1243,6 +1243,10 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
     // layers that one-workgroup-per-CU tiles fit exactly (gemm_mid.hip): K*B = 2 560 rows x 512 columns of the rollout / BPTT as 80 x 64 tiles,
     // 129..1024 rows x >= 2048 columns (the DiT MLP's wide layer in the ELBO passes) as 8 row tiles; forward (W [N][K]) and data-gradient
     // (W [K][N]) forms, optional pre-activation output.  The profiler records them under gemm_mid's own entry.
+    if (g_force_kernel == 0 && gemm_thin_n_ok(g)) {
+        prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.b_kmajor; prof.variant = 25; prof.id = PROF_GEMM;
+        return gemm_thin_n(g, s);
+    }
     if (const int ks = g_force_kernel == 0 ? mid_split_factor(g, vec, s) : 0) {
         prof.cancel();
         return gemm_mid_ex(g.A, g.lda, g.B, g.ldb, g.b_kmajor, g.bias, g.act, g.residual, g.ldr, g.C, g.ldc, g.preact, t_split->slab, g.M, g.N, g.K, ks, s, g.dact_pre,

@@ -24,7 +24,8 @@ int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, con
 // dlin_keep (optional, [M,out]): the adjoint of the Linear output is left there and the weight / bias gradients are NOT computed: the caller
 // contracts them later (GradQueue: one grouped launch per backward pass, gemm_group.hip).
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
-            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep = nullptr);
+            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep = nullptr,
+            float* dyeff_keep = nullptr);      // dyeff_keep: the operand of the LayerNorm gamma / beta gradients is left there, their column sums to the caller
 
 // y = act(x W^T + b) * mask            (Linear -> activation), pre-activation saved
 struct LaSave { float *pre, *y; };
@@ -73,13 +74,15 @@ struct PolicySteps {
     int H, M;
     PolicySave sv[16];
     float *dmean, *dlstd, *dm0, *ds0, *dtr[3], *de0, *dh;        // [H][M][.] adjoints of mean2 / lstd2 / mean0 / lstd0 / trunk i / enc0 outputs, enc3 output
+    float* dyeff[4];                                             // [H][M][D] dy act'(.) of the enc0 / trunk i LayerNorms: what their gamma / beta gradients sum
 };
 int policy_steps_alloc(const AidPolicyNet& p, int M, int H, Workspace& ws, PolicySteps& ps);
 // record dW / db of every policy Linear over all H steps into q (z_all: [H][M][L] inputs of the H forward passes)
-int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q);
+// (and the LayerNorm gamma / beta gradients, likewise over all H*M rows at once)
+int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q, Workspace& ws);
 // d_action [M,A] (may be null = 0), ent_coef[M] = dLoss/d(entropy_sum) per row (may be null), accumulates param grads; dz optional
 // steps / t (optional): write step t's adjoints into the PolicySteps slices and leave the Linear weight / bias gradients to policy_bptt_grads
-// (LayerNorm parameter gradients are still accumulated here).
+// and the LayerNorm parameter gradients to policy_bptt_grads.
 int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float* z, int ldz, const float* eps, const PolicySave& sv,
                const float* d_action, const float* ent_coef, float* dz, int lddz, Workspace& ws, hipStream_t s, const PolicySteps* steps = nullptr, int t = 0);
 

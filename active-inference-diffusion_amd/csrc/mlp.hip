@@ -48,13 +48,13 @@ int lla_fwd(const AidLinear& l, const AidLN& ln, int act, const float* mask, con
     return AID_OK;
 }
 int lla_bwd(const AidLinear& l, const AidLN& ln, const AidLinear* gl, const AidLN* gln, int act, const float* mask, const float* x,
-            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep) {
+            int ldx, int M, const LlaSave& sv, const float* dy, float* dx, int lddx, Workspace& ws, hipStream_t s, float* dlin_keep, float* dyeff_keep) {
     const size_t mark = ws.mark();
     float* dlin = dlin_keep ? dlin_keep : ws.f32((size_t)M * l.out);
-    float* dyeff = gln ? ws.f32((size_t)M * l.out) : nullptr;
+    float* dyeff = dyeff_keep ? dyeff_keep : (gln ? ws.f32((size_t)M * l.out) : nullptr);
     AID_WS_OK(ws);
     AID_TRY(ln_bwd_rows(dy, l.out, sv.lin, l.out, sv.stats, ln.g, ln.b, act, mask, dlin, l.out, dyeff, M, l.out, s));
-    if (gln) AID_TRY(ln_param_grad(dyeff, sv.lin, l.out, sv.stats, gln->g, gln->b, M, l.out, s, &ws));
+    if (gln && !dyeff_keep) AID_TRY(ln_param_grad(dyeff, sv.lin, l.out, sv.stats, gln->g, gln->b, M, l.out, s, &ws));
     if (gl && !dlin_keep) {
         AID_TRY(linear_bwd_weight(dlin, l.out, x, ldx, gl->w, M, l.out, l.in, s, 1));
         if (gl->b) AID_TRY(colsum(dlin, l.out, gl->b, M, l.out, 1, s, &ws));
@@ -327,13 +327,17 @@ int policy_steps_alloc(const AidPolicyNet& p, int M, int H, Workspace& ws, Polic
     ps.dmean = ws.f32(HM * A); ps.dlstd = ws.f32(HM * A); ps.dm0 = ws.f32(HM * Hh); ps.ds0 = ws.f32(HM * Hh);
     for (int i = 0; i < 3; ++i) ps.dtr[i] = ws.f32(HM * D);
     ps.de0 = ws.f32(HM * D); ps.dh = ws.f32(HM * D);
+    for (int i = 0; i < 4; ++i) ps.dyeff[i] = ws.f32(HM * D);
     AID_WS_OK(ws);
     return AID_OK;
 }
 
-int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q) {
+int policy_bptt_grads(const AidPolicyNet& p, const AidPolicyNet& g, const PolicySteps& ps, const float* z_all, int ldz, GradQueue& q, Workspace& ws) {
     const int D = p.D, A = p.A, Hh = p.mean0.out, R = ps.H * ps.M;
     const PolicySave& s0 = ps.sv[0];                      // slice 0 = base of every [H][M][.] buffer
+    // LayerNorm gamma / beta: column sums of dyeff x_hat and dyeff over the H*M rows of all steps (3 launches per layer instead of 3 H)
+    AID_TRY(ln_param_grad(ps.dyeff[0], s0.e0.lin, D, s0.e0.stats, g.enc_ln.g, g.enc_ln.b, R, D, q.s, &ws));
+    for (int i = 0; i < 3; ++i) AID_TRY(ln_param_grad(ps.dyeff[1 + i], s0.tr[i].lin, D, s0.tr[i].stats, g.trunk_ln[i].g, g.trunk_ln[i].b, R, D, q.s, &ws));
     AID_TRY(q.add(g.mean2.w, Hh, A, Hh, ps.dmean, A, s0.m0.y, Hh, R, g.mean2.b));
     AID_TRY(q.add(g.lstd2.w, Hh, A, Hh, ps.dlstd, A, s0.s0.y, Hh, R, g.lstd2.b));
     AID_TRY(q.add(g.mean0.w, D, Hh, D, ps.dm0, Hh, s0.h2, D, R, g.mean0.b));
@@ -370,19 +374,19 @@ int policy_bwd(const AidPolicyNet& p, const AidPolicyNet* g, int M, const float*
     AID_TRY(la_bwd(p.lstd0, g ? &g->lstd0 : nullptr, ACT_RELU, nullptr, sv.h2, D, M, sv.s0, ds0, H, dh2, D, s, 1, &ws, defer));
     // h2 = h + trunk(h)
     AID_TRY(lla_bwd(p.trunk[2], p.trunk_ln[2], g ? &g->trunk[2] : nullptr, g ? &g->trunk_ln[2] : nullptr, ACT_RELU, nullptr, sv.tr[1].y, D, M, sv.tr[2], dh2, dA, D, ws, s,
-                    defer ? slot(steps->dtr[2], D) : nullptr));
+                    defer ? slot(steps->dtr[2], D) : nullptr, defer ? slot(steps->dyeff[3], D) : nullptr));
     AID_TRY(lla_bwd(p.trunk[1], p.trunk_ln[1], g ? &g->trunk[1] : nullptr, g ? &g->trunk_ln[1] : nullptr, ACT_RELU, nullptr, sv.tr[0].y, D, M, sv.tr[1], dA, dB, D, ws, s,
-                    defer ? slot(steps->dtr[1], D) : nullptr));
+                    defer ? slot(steps->dtr[1], D) : nullptr, defer ? slot(steps->dyeff[2], D) : nullptr));
     float* dhv = defer ? dhk : dA;                       // dh = d(trunk input) + dh2 (the residual): kept per step when the gradients are deferred
     AID_TRY(lla_bwd(p.trunk[0], p.trunk_ln[0], g ? &g->trunk[0] : nullptr, g ? &g->trunk_ln[0] : nullptr, ACT_RELU, nullptr, sv.h, D, M, sv.tr[0], dB, dhv, D, ws, s,
-                    defer ? slot(steps->dtr[0], D) : nullptr));
+                    defer ? slot(steps->dtr[0], D) : nullptr, defer ? slot(steps->dyeff[1], D) : nullptr));
     AID_TRY(add_inplace(dhv, dh2, (size_t)M * D, s));   // dh
     if (g && !defer) {
         AID_TRY(linear_bwd_weight(dA, D, sv.e0.y, D, g->enc3.w, M, D, D, s, 1)); AID_TRY(colsum(dA, D, g->enc3.b, M, D, 1, s, &ws));
     }
     AID_TRY(linear_bwd_data(dhv, D, p.enc3.w, D, dB, D, M, D, s));
     AID_TRY(lla_bwd(p.enc0, p.enc_ln, g ? &g->enc0 : nullptr, g ? &g->enc_ln : nullptr, ACT_RELU, nullptr, z, ldz, M, sv.e0, dB, dz, lddz, ws, s,
-                    defer ? slot(steps->de0, D) : nullptr));
+                    defer ? slot(steps->de0, D) : nullptr, defer ? slot(steps->dyeff[0], D) : nullptr));
     ws.release(mark);
     return AID_OK;
 }

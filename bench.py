@@ -126,11 +126,13 @@ def kernel_name(variant, layout):
         return f"gemm_rowln_kernel<{1024 if variant == 20 else 512}, {16 if variant == 20 or layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, true, {b(layout & 16)}>"
     if variant == 23:
         return f"gemm_rowln_kernel<512, {16 if layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, false, false>"
-    if variant == 22:      # layout = 8 BMF + act (+ 64: contraction-major W); the 32-row tile is the register-capped instantiation
+    if variant in (22, 24):      # layout = 8 BMF + act (+ 64: contraction-major W); the 32-row tile is the register-capped instantiation; 24 = K slices folded in the kernel
         bmf, act, bkm = (layout >> 3) & 7, layout & 7, b(layout & 64)
         if bmf == 5:
             return f"gemm_mid_kernel<5, 1, 4, 1, {act}, {bkm}>"
         return f"gemm_mid_kernel{'_o3' if bmf == 1 else ''}<{bmf}, 2, 2, 2, {act}, {bkm}>"
+    if variant == 25:
+        return "gemm_thin_n_kernel"
     if variant == 30:
         return "gemm_group_tn_kernel"
     if variant == 31:

@@ -550,6 +550,29 @@ def test_gemm_mid_routed_shapes(nat, M, N, K, lay, act):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K,lay,act,acc", [(2560, 17, 512, "nn", "none", 0), (2560, 6, 256, "nt", "relu", 0), (2560, 1, 512, "nt", "none", 1), (257, 23, 512, "nn", "none", 0),
+                                               (100, 16, 1024, "nt", "silu", 0), (96, 32, 512, "nn", "none", 0), (4099, 2, 256, "nt", "relu", 0), (64, 17, 384, "nn", "none", 1), (300, 9, 68, "nt", "none", 0)])
+def test_gemm_thin_outputs(nat, tmp_path, M, N, K, lay, act, acc):
+    """N <= 32 output columns at 33..8192 rows (csrc/gemm_thin.hip: W transposed into LDS, a wave per four rows, fold8 reductions): the small
+    networks' heads over the rollout's 2 560 rows and the data gradients into their 17- / 23-wide inputs (W as stored, [K][N] with ld = N).
+    Ragged M, K not a multiple of 256, bias + activation + residual + accumulate; the profile names the route (variant 25)."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = rng.standard_normal((K, N) if lay == "nn" else (N, K)).astype(np.float32) / np.sqrt(K)
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32); C0 = rng.standard_normal((M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ (W if lay == "nn" else W.T).astype(np.float64) + b
+    f = {"none": lambda x: x, "relu": lambda x: np.maximum(x, 0), "silu": lambda x: x / (1 + np.exp(-x)), "tanh": np.tanh}[act]
+    ref = f(ref) + R + (C0 if acc else 0)
+    C = dev(C0.copy())
+    nat.prof_enable(True); nat.prof_reset()
+    nat.gemm(dev(A), dev(W), C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=dev(b), act=act, residual=dev(R), ldr=N, accumulate=acc)
+    torch.cuda.synchronize(); nat.prof_dump(str(tmp_path / "prof.csv")); nat.prof_enable(False); nat.prof_reset()
+    import csv
+    recs = list(csv.DictReader(open(tmp_path / "prof.csv")))
+    assert len(recs) == 1 and int(recs[0]["variant"]) == 25, recs
+    np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+
+
 @pytest.mark.parametrize("M,N,K,lay,act,acc", [(256, 512, 2048, "nt", "none", 0), (256, 512, 2048, "nn", "none", 1), (512, 512, 2048, "nn", "none", 0),
                                                (256, 1024, 1024, "nt", "gelu", 0), (200, 512, 13312, "nn", "none", 0), (768, 256, 1024, "nt", "silu", 0)])
 def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):

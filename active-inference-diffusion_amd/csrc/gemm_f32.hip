@@ -224,8 +224,10 @@ __global__ void __launch_bounds__(256) gemm_smallk_kernel(GemmArgs g, int tiles_
     for (int i = tid; i < 64 * K; i += 256) {
         const int r = i / K, k = i % K;
         xs[r][k] = (m0 + r < g.M) ? g.A[(size_t)(m0 + r) * g.lda + k] : 0.f;
-        wsm[r][k] = (n0 + r < g.N) ? g.B[(size_t)(n0 + r) * g.ldb + k] : 0.f;
+        if (!g.b_kmajor) wsm[r][k] = (n0 + r < g.N) ? g.B[(size_t)(n0 + r) * g.ldb + k] : 0.f;
     }
+    if (g.b_kmajor)      // W stored [K][N] (the data gradient through a layer with <= 32 outputs): n runs fastest in memory
+        for (int i = tid; i < 64 * K; i += 256) { const int k = i >> 6, r = i & 63; wsm[r][k] = (n0 + r < g.N) ? g.B[(size_t)k * g.ldb + n0 + r] : 0.f; }
     __syncthreads();
     const int tc = tid & 15, tr = tid >> 4;      // rows tr + 16 i, columns 4 tc + j (contiguous: 16-B stores on the plain epilogue)
     float acc[4][4];
@@ -1122,7 +1124,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
     }
     // Automatic selection, set by measurement on MI355X (profiles/gemm_*_r01.txt, tools/perf/cold_chain.py).
     // K <= 32 (first layer of every network, K = latent / observation dim): VALU kernel, output-write bound.
-    if (!AKM && !BKM && g.K >= 1 && g.K <= 32) return launch_smallk(g, s);
+    if (!AKM && g.K >= 1 && g.K <= 32 && (!BKM || g.M >= 64)) return launch_smallk(g, s);
     // act() / collector batches: one wave per output column, W row in registers (weight-streaming, not MFMA-shaped)
     if (!AKM && !BKM && vec && g.M <= 32 && g.K >= 64 && g.K <= 4096 && g.ksplit <= 1) return launch_skinny(g, s);
     // one column tile under many row tiles (N = 17 / 6 / 1 heads over 25 600 rows): an A-streaming problem; the 35 KB panel variant keeps

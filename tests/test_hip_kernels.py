@@ -550,6 +550,22 @@ def test_gemm_mid_routed_shapes(nat, M, N, K, lay, act):
     np.testing.assert_allclose(C.cpu().numpy(), ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
+@pytest.mark.parametrize("M,N,K", [(2560, 512, 17), (300, 70, 6), (64, 256, 1), (2560, 256, 2)])
+def test_gemm_small_k_data_gradient_layout(nat, tmp_path, M, N, K):
+    """K <= 32 with W stored [K][N] (the data gradient through a layer with <= 32 outputs, e.g. dh = dmean W_mean2 in the policy BPTT): the
+    VALU small-K kernel (variant 3) stages that layout too instead of leaving the shape to the unaligned 64 x 64 MFMA tile kernel."""
+    rng = np.random.default_rng(M + N + K)
+    A = rng.standard_normal((M, K)).astype(np.float32); W = rng.standard_normal((K, N)).astype(np.float32); C0 = rng.standard_normal((M, N)).astype(np.float32)
+    C = dev(C0.copy())
+    nat.prof_enable(True); nat.prof_reset()
+    nat.gemm(dev(A), dev(W), C, M, N, K, K, N, N, 0, 1, accumulate=1)
+    torch.cuda.synchronize(); nat.prof_dump(str(tmp_path / "prof.csv")); nat.prof_enable(False); nat.prof_reset()
+    import csv
+    recs = list(csv.DictReader(open(tmp_path / "prof.csv")))
+    assert len(recs) == 1 and int(recs[0]["variant"]) == 3, recs
+    np.testing.assert_allclose(C.cpu().numpy(), A.astype(np.float64) @ W.astype(np.float64) + C0, rtol=2e-5, atol=2e-5)
+
+
 @pytest.mark.parametrize("M,N,K,lay,act,acc", [(2560, 17, 512, "nn", "none", 0), (2560, 6, 256, "nt", "relu", 0), (2560, 1, 512, "nt", "none", 1), (257, 23, 512, "nn", "none", 0),
                                                (100, 16, 1024, "nt", "silu", 0), (96, 32, 512, "nn", "none", 0), (4099, 2, 256, "nt", "relu", 0), (64, 17, 384, "nn", "none", 1), (300, 9, 68, "nt", "none", 0)])
 def test_gemm_thin_outputs(nat, tmp_path, M, N, K, lay, act, acc):

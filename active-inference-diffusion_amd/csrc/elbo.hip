@@ -93,15 +93,19 @@ __global__ void kl_prior_kernel(const float* __restrict__ z, const float* __rest
     }
     const float kl = blk_sum(acc, sh);
     if (threadIdx.x == 0) out[0] = kl / (float)B;
-    if (dpm) for (int l = threadIdx.x; l < L; l += blockDim.x) {   // one thread per latent dim: deterministic
-        float g0 = 0.f, g1 = 0.f;
-        const float sd = expf(pls[l]);
-        for (int b = 0; b < B; ++b) {
-            const float e = peps[(size_t)b * L + l];
-            const float d = z[(size_t)b * L + l] - (pm[l] + sd * e);
-            g0 += d; g1 += d * sd * e;
+    if (dpm) {      // one wave per latent dim, lanes over the batch, fixed-order butterfly: deterministic
+        const int lane = threadIdx.x & 63, nw = blockDim.x >> 6;
+        for (int l = threadIdx.x >> 6; l < L; l += nw) {
+            float g0 = 0.f, g1 = 0.f;
+            const float sd = expf(pls[l]);
+            for (int b = lane; b < B; b += 64) {
+                const float e = peps[(size_t)b * L + l];
+                const float d = z[(size_t)b * L + l] - (pm[l] + sd * e);
+                g0 += d; g1 += d * sd * e;
+            }
+            g0 = wave_sum(g0); g1 = wave_sum(g1);
+            if (lane == 0) { dpm[l] += c * g0; dpls[l] += c * g1; }
         }
-        dpm[l] += c * g0; dpls[l] += c * g1;
     }
 }
 
@@ -146,14 +150,27 @@ __global__ void elbo_metrics_kernel(float* __restrict__ m, const float* __restri
 }
 
 // sequential EMA of active_inference.py:750-771 (python-double arithmetic, float32 storage), order-dependent by design
+// (an update touches one bin and bins do not interact: thread b applies, in sample order, the updates of bin b - the same arithmetic in the same
+// order per bin as the sequential loop, without its 256 dependent round trips to memory: 44 -> ~5 us.  Launch with >= 100 threads.)
 __global__ void time_importance_update_kernel(float* __restrict__ w, const float* __restrict__ t, const float* __restrict__ per, int B, int first) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    if (first) for (int i = 0; i < 100; ++i) w[i] = 1.0f;
-    for (int i = 0; i < B; ++i) {
-        int bin = (int)(long long)(t[i] * 99.0f);
-        bin = bin < 0 ? 0 : (bin > 99 ? 99 : bin);
-        w[bin] = (float)(0.99 * (double)w[bin] + 0.01 * (double)per[i]);
+    __shared__ int sb[1024];
+    __shared__ float sp[1024];
+    if (blockIdx.x != 0) return;
+    const int tid = threadIdx.x;
+    float wv = tid < 100 ? (first ? 1.0f : w[tid]) : 0.f;
+    for (int c0 = 0; c0 < B; c0 += 1024) {
+        const int nc = B - c0 < 1024 ? B - c0 : 1024;
+        __syncthreads();
+        for (int i = tid; i < nc; i += blockDim.x) {
+            int bin = (int)(long long)(t[c0 + i] * 99.0f);
+            sb[i] = bin < 0 ? 0 : (bin > 99 ? 99 : bin); sp[i] = per[c0 + i];
+        }
+        __syncthreads();
+        if (tid < 100)
+            for (int i = 0; i < nc; ++i)
+                if (sb[i] == tid) wv = (float)(0.99 * (double)wv + 0.01 * (double)sp[i]);
     }
+    if (tid < 100) w[tid] = wv;
 }
 
 // importance sampling of t (active_inference.py:731-748): softmax(w) -> inverse-CDF categorical -> (idx + u)/100
@@ -322,7 +339,7 @@ static int adam_step_impl(float* p, const float* g, float* m, float* v, float* e
 
 int aid_time_importance_update(float* time_importance, const float* t, const float* per_sample, int n, int first_call, void* stream) {
     AID_REQUIRE(time_importance && t && per_sample, AID_E_NULL, "aid_time_importance_update: null tensor");
-    hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, time_importance, t, per_sample, n, first_call);
+    hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, time_importance, t, per_sample, n, first_call);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -537,7 +554,7 @@ int aid_elbo_step(const AidScoreNet* net, const AidScoreNet* grads, const AidDif
     }
     hipLaunchKernelGGL(elbo_metrics_kernel, dim3(1), dim3(64), 0, s, metrics, tmp, cfg->kl_weight, cfg->diffusion_weight, cfg->reward_weight, cfg->gp_weight);
     if (!cfg->defer_time_importance) {
-        hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(64), 0, s, time_importance, t, per, B, cfg->first_call);
+        hipLaunchKernelGGL(time_importance_update_kernel, dim3(1), dim3(128), 0, s, time_importance, t, per, B, cfg->first_call);
         AID_LAUNCH_CHECK();
     }
     if (t_out) AID_TRY(copy_f32(t, t_out, B, s));

@@ -469,8 +469,18 @@ int sinusoid_bwd(const float* dsin, const float* t, const float* fs, float tmul,
 
 __global__ void dot_accum_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n, float scale, float* __restrict__ out) {
     __shared__ float sh[16];
+    typedef float f4 __attribute__((ext_vector_type(4)));
     float acc = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += blockDim.x) acc += a[i] * (b ? b[i] : 1.f);
+    size_t done = 0;
+    if (b && ((((uintptr_t)a | (uintptr_t)b) & 15) == 0)) {       // 16-B loads, four in flight per thread (131 072 elements were 128 dependent 4-B loads: 55 us)
+        const size_t n4 = n >> 2;
+        f4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (size_t i = threadIdx.x; i < n4; i += blockDim.x) s4 += reinterpret_cast<const f4*>(a)[i] * reinterpret_cast<const f4*>(b)[i];
+        acc = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        done = n4 << 2;
+    }
+    for (size_t i = done + threadIdx.x; i < n; i += blockDim.x) acc += a[i] * (b ? b[i] : 1.f);
     const float tot = block_sum_1024(acc, sh);
     if (threadIdx.x == 0) out[0] += scale * tot;
 }

@@ -196,10 +196,22 @@ __device__ __forceinline__ float act_grad2(float x, int act) {
         default: return 0.f;
     }
 }
+// Sum over the 64 lanes of a (fully active) wave, the same value returned to every lane.  Data-parallel-primitive form: four adds inside a
+// row of 16 (quad swaps, half-row and row mirrors), row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 / 3, total read from lane 63 -
+// ~12 VALU instructions where six `__shfl_xor` steps are six dependent trips through the LDS crossbar (ds_bpermute, ~100 cycles each).
+// LayerNorm rows do two of these back to back; the 5-us row kernels of the 256-row chains are mostly that latency.  Fixed order: reproducible.
+template <int CTRL, int ROW_MASK, bool BOUND>
+__device__ __forceinline__ float dpp_add_(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, BOUND));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add_<0xB1, 0xF, true>(v);        // quad_perm [1,0,3,2]
+    v = dpp_add_<0x4E, 0xF, true>(v);        // quad_perm [2,3,0,1]
+    v = dpp_add_<0x141, 0xF, true>(v);       // row_half_mirror
+    v = dpp_add_<0x140, 0xF, true>(v);       // row_mirror: every lane of a row holds the row's sum
+    v = dpp_add_<0x142, 0xA, false>(v);      // row_bcast:15 -> rows 1 and 3
+    v = dpp_add_<0x143, 0xC, false>(v);      // row_bcast:31 -> rows 2 and 3: lane 63 holds the total
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 // 8 per-lane partial sums -> 8 wave totals with 4 + 2 + 1 + 3 = 10 cross-lane moves (each butterfly stage halves the values a lane
 // carries); afterwards lane 8 c (c = 0..7) holds the total of value c.  Fixed order: reproducible.

@@ -222,8 +222,9 @@ __device__ __forceinline__ float fold8(const float (&acc)[8], int lane) {
     for (int i = 0; i < 4; ++i) { const float recv = __shfl_xor(h32 ? acc[i] : acc[i + 4], 32, 64); a4[i] = (h32 ? acc[i + 4] : acc[i]) + recv; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const float recv = __shfl_xor(h16 ? a4[i] : a4[i + 2], 16, 64); a2[i] = (h16 ? a4[i + 2] : a4[i]) + recv; }
-    { const float recv = __shfl_xor(h8 ? a2[0] : a2[1], 8, 64); a1 = (h8 ? a2[1] : a2[0]) + recv; }
-    a1 += __shfl_xor(a1, 4, 64); a1 += __shfl_xor(a1, 2, 64); a1 += __shfl_xor(a1, 1, 64);
+    // the partner at distance 8 is inside the row of 16 (row_ror:8), and the last three steps are plain sums over 8 lanes: DPP, no LDS trip
+    { const float send = h8 ? a2[0] : a2[1]; const float recv = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(send), 0x128, 0xF, 0xF, true)); a1 = (h8 ? a2[1] : a2[0]) + recv; }
+    a1 = dpp_add_<0xB1, 0xF, true>(a1); a1 = dpp_add_<0x4E, 0xF, true>(a1); a1 = dpp_add_<0x141, 0xF, true>(a1);
     return a1;
 }
 __device__ __forceinline__ double wave_sum_d(double v) {

@@ -175,8 +175,8 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
             }
         }
         __builtin_amdgcn_wave_barrier();          // all reads of xw done before the next block overwrites it
-        // LayerNorm statistics of the XR rows together: the XR butterfly chains are independent, so their cross-lane latencies overlap
-        // (one row at a time, 12 dependent shuffles per row were ~30 % of the block's cycles at two waves per SIMD)
+        // LayerNorm statistics of the XR rows together: the XR reduction chains are independent, so their latencies overlap
+        // (one row at a time behind 12 dependent ds_bpermute steps they were ~30 % of the block's cycles at two waves per SIMD)
         float mean[XR], rstd[XR];
         {
             float sm[XR];
@@ -187,9 +187,7 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
                 for (int i = 0; i < NV; ++i) sm[r] += (acc[r][i][0] + acc[r][i][1]) + (acc[r][i][2] + acc[r][i][3]);
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int r = 0; r < XR; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+            for (int r = 0; r < XR; ++r) sm[r] = wave_sum(sm[r]);
 #pragma unroll
             for (int r = 0; r < XR; ++r) { mean[r] = sm[r] / (float)D; sm[r] = 0.f; }
 #pragma unroll
@@ -199,9 +197,7 @@ __global__ void __launch_bounds__(256) lin_smallk_ln_act_kernel(const float* __r
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { const float d = acc[r][i][j] - mean[r]; sm[r] += d * d; }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1)
-#pragma unroll
-                for (int r = 0; r < XR; ++r) sm[r] += __shfl_xor(sm[r], o, 64);
+            for (int r = 0; r < XR; ++r) sm[r] = wave_sum(sm[r]);
 #pragma unroll
             for (int r = 0; r < XR; ++r) rstd[r] = 1.0f / sqrtf(sm[r] / (float)D + 1e-5f);
         }

@@ -7,6 +7,7 @@ from aid_amd import _native as nat
 what = sys.argv[1]
 M = 256
 N, K, ks, act = {"none": (2048, 512, 1, "none"), "gelu": (2048, 512, 1, "gelu"), "down": (512, 2048, 4, "none")}[what]
-A = torch.randn(M, K, device="cuda"); Ws = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(24)]; b = torch.randn(N, device="cuda")
-for i in range(240): nat.gemm_mid(A, Ws[i % 24], b if ks == 1 else None, act, None, ks)
+NW = int(os.environ.get("MID_NW", "24"))          # 24 x 4 MB of weights: cold in the L2s every launch, as in situ; MID_NW=1: warm
+A = torch.randn(M, K, device="cuda"); Ws = [torch.randn(N, K, device="cuda") / K ** 0.5 for _ in range(NW)]; b = torch.randn(N, device="cuda")
+for i in range(240): nat.gemm_mid(A, Ws[i % NW], b if ks == 1 else None, act, None, ks)
 torch.cuda.synchronize()

@@ -260,12 +260,14 @@ int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const flo
     return AID_OK;
 }
 
+static int g_chunk_cap = 0;
 static size_t denoise_chunk_steps(const AidScoreNet& n, int B, int N) {
     // steps whose (z-independent) conditioning is precomputed together: bound the [C*B, 26D] modulation buffer to ~1.5 GB
     const size_t per_step = (size_t)B * (2 * n.n_blocks + 1) * 2 * n.D * sizeof(float);
     size_t c = ((size_t)3 << 29) / (per_step ? per_step : 1);
     if (c < 1) c = 1;
     if (c > (size_t)N) c = N;
+    if (g_chunk_cap > 0 && c > (size_t)g_chunk_cap) c = g_chunk_cap;      // timing experiments (aid_denoise_debug)
     return c;
 }
 
@@ -427,6 +429,8 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     a.mod = mod_own;
     return AID_OK;
 }
+
+int aid_denoise_debug(int chunk_cap) { g_chunk_cap = chunk_cap; return AID_OK; }
 
 int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M,
                  int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha, int accumulate,

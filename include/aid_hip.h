@@ -86,8 +86,10 @@ int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, c
  * Unit-test / bench entries; the reverse loop calls them through aid_denoise_loop. */
 int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                  float* slab, int M, int N, int K, int ksplit, void* stream);
-/* timing experiments: force the row-tile height of the mid-M kernel to >= 32 bmt_min rows (1 = automatic) */
+/* timing experiments: force the row-tile height of the mid-M kernel to >= 32 bmt_min rows (1 = automatic); cap the number of denoise steps that share one
+ * hoisted conditioning pass (0 = automatic) */
 int aid_mid_debug(int bmt_min);
+int aid_denoise_debug(int chunk_cap);
 int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
                   float* y, int ldy, int M, int D, void* stream);
 

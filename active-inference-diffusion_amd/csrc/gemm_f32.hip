@@ -1161,7 +1161,9 @@ static inline bool mid_route_ok(const GemmArgs& g, bool vec) {
     if (g.b_kmajor && (g.act != ACT_NONE || g.N % 64 != 0)) return false;
     if (!gemm_mid_ok(g.M, g.N, g.K, 1, g.act, g.A, g.lda, g.B, g.ldb) || g.N % 64 != 0) return false;
     if (g.M > 1024) { const long wg = (long)(g.M / 80) * (g.N / 64); return g.M % 80 == 0 && wg >= 192 && wg <= 512; }
-    return g.N >= 2048 && g.N <= 4096;       // 8 row tiles x >= 32 column tiles
+    // 8 row tiles x >= 8 column tiles: even as 64 workgroups (N = 512, K = 512: 8.8 us) the eight-stage pipeline beats the 32 x 32 panel kernel's
+    // 256 workgroups (11 - 13 us) on the ELBO passes' 256- / 512-row products
+    return g.N >= 512 && g.N <= 4096;
 }
 static thread_local SplitScope* t_split = nullptr;
 SplitScope::SplitScope(Workspace& ws, hipStream_t st, size_t fl, int nc) : slab(ws.f32(fl)), floats(fl), ctr((int*)ws.raw(nc * sizeof(int))), nctr(nc), s(st), prev(t_split) {

@@ -14,3 +14,6 @@ for _ in range(3): agent.train_step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(steps): agent.train_step()
 torch.cuda.synchronize(); print(f"cfg4: {(time.perf_counter() - t0) / steps * 1e3:.2f} ms per train_step")
+if os.environ.get("AID_DUMP"):
+    from aid_amd import _native as nat
+    nat.prof_enable(True); nat.prof_reset(); agent.train_step(); torch.cuda.synchronize(); nat.prof_dump(os.environ["AID_DUMP"]); nat.prof_enable(False)

@@ -7,7 +7,7 @@ instead of 54, depending only on how many streams had been used before; tools/pe
 besides the caller's takes it from here: ONE side stream and TWO chain streams per device for the whole process, created once, handed to every
 agent - with the caller's stream that is exactly four.  A process that uses further streams of its own is over the limit and should set
 `agent.concurrent_belief_loops = False` (belief updates as one merged loop: side + main only).  RCCL's internal stream in data-parallel runs is
-such a fifth stream: measured with one rank on real RCCL the chains still paid (52.0 against 59.6 ms merged in round 3), but an N-rank communicator may use
+such a fifth stream: measured with one rank on real RCCL the chains still paid (50.1 against 56.4 ms merged at the end of round 3), but an N-rank communicator may use
 more, so a data-parallel state agent does not assume either way - it times both schedules during its first steps and keeps the faster one
 (`DiffusionStateAgent._dp_schedule_vote`)."""
 from __future__ import annotations

@@ -908,28 +908,44 @@ int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, f
 }  // extern "C"
 
 namespace aid {
-int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s) {
-    const size_t mark0 = ws.mark();
-    const int H = d.hidden, L = d.L, HW0 = 441;
+// The decoder in three parts, so that a caller decoding many latents (the pixel estimator: z and four perturbed copies of every row, 16 images at a
+// time) prepares the spectral-norm weight images ONCE and streams latent_proj's 1.85 GB second Linear ONCE per <= 640 rows as an MFMA GEMM, instead of
+// once per 16-image decode through the weight-streaming skinny kernel (40 x 0.64 ms per 128 rows).
+struct DecPrep { ConvW m0[4], m1[4], rs[4], o0, o3, o6; };
+static int conv_decoder_prep(const AidConvDecoder& d, Workspace& ws, DecPrep& p, hipStream_t s) {
+    const int H = d.hidden;
     // ---- conv weights (eval-mode spectral norm: W / (u . W v))
-    ConvW m0[4], m1[4], rs[4], o0, o3, o6;
     const int cin[4] = {H, H, H / 2, H / 4}, cout[4] = {H, H / 2, H / 4, H / 8}; const int up[4] = {0, 1, 1, 1};
     for (int i = 0; i < 4; ++i) {
-        AID_TRY(prep_weight(d.blk[i].main0, cin[i], up[i] ? 4 * cout[i] : cout[i], 3, ws, m0[i], s));
-        AID_TRY(prep_weight(d.blk[i].main1, cout[i], cout[i], 3, ws, m1[i], s));
-        if (up[i]) AID_TRY(prep_weight(d.blk[i].res, cin[i], 4 * cout[i], 1, ws, rs[i], s));
+        AID_TRY(prep_weight(d.blk[i].main0, cin[i], up[i] ? 4 * cout[i] : cout[i], 3, ws, p.m0[i], s));
+        AID_TRY(prep_weight(d.blk[i].main1, cout[i], cout[i], 3, ws, p.m1[i], s));
+        if (up[i]) AID_TRY(prep_weight(d.blk[i].res, cin[i], 4 * cout[i], 1, ws, p.rs[i], s));
     }
     AidSNConv t0 = {d.out0_w, nullptr, nullptr, d.out0_b}, t3 = {d.out3_w, nullptr, nullptr, d.out3_b}, t6 = {d.out6_w, nullptr, nullptr, d.out6_b};
-    AID_TRY(prep_weight(t0, H / 8, 32, 3, ws, o0, s)); AID_TRY(prep_weight(t3, 32, 32, 3, ws, o3, s)); AID_TRY(prep_weight(t6, 32, 3, 3, ws, o6, s));
-    // ---- latent_proj: Linear, LN, Mish, (Dropout: eval), Linear, LN over 112 896, Mish -> CNHW [256][R][21x21]
-    float* a0 = ws.f32((size_t)R * 4 * H); float* a1 = ws.f32((size_t)R * 4 * H); float* big = ws.f32((size_t)R * H * HW0);
-    const size_t amax = (size_t)R * ((size_t)3528 * H > 32u * 168 * 168 ? (size_t)3528 * H : 32u * 168 * 168);
-    float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
-    float* col = ws.f32((size_t)R * 168 * 168 * (9 * H / 8 > 288 ? 9 * H / 8 + 32 : 288 + 32));
+    AID_TRY(prep_weight(t0, H / 8, 32, 3, ws, p.o0, s)); AID_TRY(prep_weight(t3, 32, 32, 3, ws, p.o3, s)); AID_TRY(prep_weight(t6, 32, 3, 3, ws, p.o6, s));
+    return AID_OK;
+}
+// latent_proj up to the second Linear: Linear, LN, Mish, (Dropout: eval), Linear -> big [R][H * 441] (the LayerNorm over 112 896 + Mish follow per chunk)
+static int conv_decoder_latent(const AidConvDecoder& d, int R, const float* z, float* big, Workspace& ws, hipStream_t s) {
+    const int H = d.hidden, L = d.L, HW0 = 441;
+    const size_t mark = ws.mark();
+    float* a0 = ws.f32((size_t)R * 4 * H); float* a1 = ws.f32((size_t)R * 4 * H);
     AID_WS_OK(ws);
     AID_TRY(linear_fwd(z, L, d.l0.w, d.l0.b, a0, 4 * H, R, 4 * H, L, ACT_NONE, s));
     AID_TRY(ln_act(a0, 4 * H, d.ln1.g, d.ln1.b, ACT_MISH, nullptr, a1, 4 * H, nullptr, R, 4 * H, s));
     AID_TRY(linear_fwd(a1, 4 * H, d.l4.w, d.l4.b, big, H * HW0, R, H * HW0, 4 * H, ACT_NONE, s));
+    ws.release(mark);
+    return AID_OK;
+}
+static int conv_decoder_trunk(const AidConvDecoder& d, const DecPrep& p, int R, const float* big, float* out, Workspace& ws, hipStream_t s) {
+    const size_t mark0 = ws.mark();
+    const int H = d.hidden, HW0 = 441;
+    const int cout[4] = {H, H / 2, H / 4, H / 8}; const int up[4] = {0, 1, 1, 1};
+    const ConvW* m0 = p.m0; const ConvW* m1 = p.m1; const ConvW* rs = p.rs; const ConvW& o0 = p.o0; const ConvW& o3 = p.o3; const ConvW& o6 = p.o6;
+    const size_t amax = (size_t)R * ((size_t)3528 * H > 32u * 168 * 168 ? (size_t)3528 * H : 32u * 168 * 168);
+    float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
+    float* col = nullptr;
+    AID_WS_OK(ws);
     hipLaunchKernelGGL(bigln_mish_cnhw_kernel, dim3(R), dim3(1024), 0, s, big, d.ln5.g, d.ln5.b, xa, R, H, HW0);
     AID_LAUNCH_CHECK();
     // ---- decoder blocks
@@ -961,6 +977,16 @@ int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out,
     hipLaunchKernelGGL(instnorm_kernel, dim3(32 * R), dim3(256), 0, s, cv, d.out3_b, (const float*)nullptr, x, 32, R, hsz, hsz, 0, ACT_MISH);
     AID_TRY(conv3_fwd(o6, x, R, hsz, col, cv, s));
     L1D(sigmoid_nchw_kernel, (size_t)3 * R * hsz * hsz, s, cv, d.out6_b, out, 3, R, hsz * hsz);
+    ws.release(mark0);
+    return AID_OK;
+}
+int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s) {
+    const size_t mark0 = ws.mark();
+    DecPrep p;
+    AID_TRY(conv_decoder_prep(d, ws, p, s));
+    float* big = ws.f32((size_t)R * d.hidden * 441); AID_WS_OK(ws);
+    AID_TRY(conv_decoder_latent(d, R, z, big, ws, s));
+    AID_TRY(conv_decoder_trunk(d, p, R, big, out, ws, s));
     ws.release(mark0);
     return AID_OK;
 }
@@ -1062,6 +1088,7 @@ __global__ void __launch_bounds__(256) agg_attention_kernel(const float* __restr
     (void)red;
 }
 
+constexpr int JAC_SC = 128;      // rows whose latent_proj runs as one GEMM in pixel_jacobian_features (5 x 128 x 225 792 floats = 578 MB at hidden = 512)
 struct PlainConv { const float* w_eff; int cin, cout, K, Kp; };
 static int prep_plain(const float* w, int cin, int cout, int k, Workspace& ws, PlainConv& out, hipStream_t s) {
     const int K = cin * k * k, Kp = (K + 31) / 32 * 32;
@@ -1074,6 +1101,7 @@ static int prep_plain(const float* w, int cin, int cout, int k, Workspace& ws, P
 int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNet& e, int R, const float* z_all, const float* delta,
                             const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* jin, Workspace& ws, hipStream_t s) {
     constexpr int RC = 16, C = 128, T = 441, NQ = 16, HEADS = 8;
+    static_assert(JAC_SC % RC == 0, "super-chunks are whole chunks");
     const int L = dec.L;
     const size_t mark = ws.mark();
     PlainConv p0, p2, p4;
@@ -1090,14 +1118,28 @@ int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNe
     float* mask_buf = (train && !attn_mask) ? ws.f32((size_t)RC * HEADS * NQ * T) : nullptr;
     AID_WS_OK(ws);
     uint64_t ctr = offset;
+    // decoder weights once; latent_proj for z and its four perturbed copies of up to SC rows at a time (5 SC x 225 792 floats), then 16 images per trunk pass
+    DecPrep prep;
+    AID_TRY(conv_decoder_prep(dec, ws, prep, s));
+    const size_t bigw = (size_t)dec.hidden * 441;
+    float* zall = ws.f32((size_t)5 * JAC_SC * L); float* big = ws.f32((size_t)5 * JAC_SC * bigw);
+    AID_WS_OK(ws);
+    (void)zp;
     for (int r0 = 0; r0 < R; r0 += RC) {
         const int n = R - r0 < RC ? R - r0 : RC;
-        const float* z = z_all + (size_t)r0 * L;
-        AID_TRY(conv_decoder_fwd(dec, n, z, fz, ws, s));
+        const int s0 = r0 / JAC_SC * JAC_SC, ns = R - s0 < JAC_SC ? R - s0 : JAC_SC;      // this chunk's super-chunk: rows s0 .. s0 + ns
+        if (r0 == s0) {
+            AID_TRY(copy_f32(z_all + (size_t)s0 * L, zall, (size_t)ns * L, s));
+            for (int j = 0; j < 4; ++j) {
+                hipLaunchKernelGGL(perturb_rows_kernel, dim3((ns + 63) / 64), dim3(64), 0, s, z_all + (size_t)s0 * L, delta + ((size_t)j * R + s0) * L, e.perturbation_scale,
+                                   zall + (size_t)(1 + j) * ns * L, ns, L);
+                AID_LAUNCH_CHECK();
+            }
+            AID_TRY(conv_decoder_latent(dec, 5 * ns, zall, big, ws, s));
+        }
+        AID_TRY(conv_decoder_trunk(dec, prep, n, big + (size_t)(r0 - s0) * bigw, fz, ws, s));
         for (int j = 0; j < 4; ++j) {
-            hipLaunchKernelGGL(perturb_rows_kernel, dim3((n + 63) / 64), dim3(64), 0, s, z, delta + ((size_t)j * R + r0) * L, e.perturbation_scale, zp, n, L);
-            AID_LAUNCH_CHECK();
-            AID_TRY(conv_decoder_fwd(dec, n, zp, fp, ws, s));
+            AID_TRY(conv_decoder_trunk(dec, prep, n, big + ((size_t)(1 + j) * ns + (r0 - s0)) * bigw, fp, ws, s));
             L1D(fd_to_cnhw_kernel, (size_t)3 * n * 168 * 168, s, fp, fz, e.perturbation_scale, dimg, 3, n, 168 * 168);
             // pixel_processor: 168 -> 84 -> 42 -> 21
             const PlainConv* pcs[3] = {&p0, &p2, &p4}; const float* bs[3] = {e.pp0_b, e.pp2_b, e.pp4_b};
@@ -1138,7 +1180,7 @@ int pixel_jacobian_features(const AidConvDecoder& dec, const AidPixelEpistemicNe
     return AID_OK;
 }
 size_t pixel_jacobian_ws_bytes(const AidConvDecoder& dec) {
-    return aid_conv_decoder_workspace(&dec, 16) + sizeof(float) * (size_t)16 * (3 * 168 * 168 * 3 + 32 * 84 * 84 + 64 * 42 * 42 + 128 * 441 * 3 + 96 * 84 * 84 + 800 * 42 * 42
+    return sizeof(float) * (size_t)5 * JAC_SC * ((size_t)dec.hidden * 441 + 8 * (size_t)dec.hidden + dec.L + 64) + aid_conv_decoder_workspace(&dec, 16) + sizeof(float) * (size_t)16 * (3 * 168 * 168 * 3 + 32 * 84 * 84 + 64 * 42 * 42 + 128 * 441 * 3 + 96 * 84 * 84 + 800 * 42 * 42
                                                                                + 16 * 128 * 2 + 8 * 16 * 441 + 4096) + (4u << 20);
 }
 }  // namespace aid

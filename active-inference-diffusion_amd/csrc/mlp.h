@@ -55,14 +55,14 @@ int dynamics_fwd(const AidDynamicsNet& d, int M, const float* z, int ldz, const 
                  Workspace& ws, hipStream_t s);
 // d_next: gradient wrt next_mean = 2z + net([z|a]).  dz_out = 2 d_next + dx[:, :L] ; da_out = dx[:, L:]
 int dynamics_bwd(const AidDynamicsNet& d, const AidDynamicsNet* g, int M, const DynSave& sv, const float* d_next, float* dz_out,
-                 float* da_out, Workspace& ws, hipStream_t s);
+                 float* da_out, Workspace& ws, hipStream_t s, GradQueue* q = nullptr);      // q: weight / bias gradients recorded, the caller flushes
 
 // ---- value network, aid/models/value_networks.py:47-60
 struct ValueSave { float *sin_e, *te_pre, *x; LlaSave s[3]; float* out; };   // x = [state | relu(te1(sinus(t)))]
 int value_fwd(const AidValueNet& v, int M, const float* state, int lds, const float* t, float* out, ValueSave& sv, Workspace& ws, hipStream_t s);
 // d_out [M] gradient wrt V.  dstate (optional) [M,L].  Parameter grads when g != null.
 int value_bwd(const AidValueNet& v, const AidValueNet* g, int M, const float* t, const ValueSave& sv, const float* d_out, float* dstate,
-              int ldds, Workspace& ws, hipStream_t s);
+              int ldds, Workspace& ws, hipStream_t s, GradQueue* q = nullptr);
 
 // ---- policy, aid/models/policy_networks.py:95-146
 struct PolicySave { LlaSave e0; float* h; LlaSave tr[3]; float* h2; LaSave m0, s0; float *mean, *lstd, *action, *ent, *logp; bool prealloc = false; };

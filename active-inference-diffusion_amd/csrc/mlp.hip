@@ -165,20 +165,29 @@ int dynamics_fwd(const AidDynamicsNet& d, int M, const float* z, int ldz, const 
     return AID_OK;
 }
 int dynamics_bwd(const AidDynamicsNet& d, const AidDynamicsNet* g, int M, const DynSave& sv, const float* d_next, float* dz_out,
-                 float* da_out, Workspace& ws, hipStream_t s) {
+                 float* da_out, Workspace& ws, hipStream_t s, GradQueue* q) {
     const int L = d.L, A = d.A, X = L + A, D = d.net[0].out;
+    // q: the four weight / bias gradients are recorded (their adjoints kept in buffers that outlive this call) and contracted by the caller's one grouped launch
+    float* dl[3] = {nullptr, nullptr, nullptr};
+    if (g && q) { for (int i = 0; i < 3; ++i) dl[i] = ws.f32((size_t)M * D); }
     const size_t mark = ws.mark();
     float* dA = ws.f32((size_t)M * D); float* dB = ws.f32((size_t)M * D); float* dx = ws.f32((size_t)M * X);
     AID_WS_OK(ws);
-    if (g) {
+    if (g && q) AID_TRY(q->add(g->out.w, D, L, D, d_next, L, sv.s[2].y, D, M, g->out.b));
+    else if (g) {
         AID_TRY(linear_bwd_weight(d_next, L, sv.s[2].y, D, g->out.w, M, L, D, s, 1));
         AID_TRY(colsum(d_next, L, g->out.b, M, L, 1, s));
     }
     AID_TRY(linear_bwd_data(d_next, L, d.out.w, D, dA, D, M, L, s));
-    AID_TRY(lla_bwd(d.net[2], d.ln[2], g ? &g->net[2] : nullptr, g ? &g->ln[2] : nullptr, ACT_RELU, nullptr, sv.s[1].y, D, M, sv.s[2], dA, dB, D, ws, s));
-    AID_TRY(lla_bwd(d.net[1], d.ln[1], g ? &g->net[1] : nullptr, g ? &g->ln[1] : nullptr, ACT_RELU, nullptr, sv.s[0].y, D, M, sv.s[1], dB, dA, D, ws, s));
+    AID_TRY(lla_bwd(d.net[2], d.ln[2], g ? &g->net[2] : nullptr, g ? &g->ln[2] : nullptr, ACT_RELU, nullptr, sv.s[1].y, D, M, sv.s[2], dA, dB, D, ws, s, dl[2]));
+    AID_TRY(lla_bwd(d.net[1], d.ln[1], g ? &g->net[1] : nullptr, g ? &g->ln[1] : nullptr, ACT_RELU, nullptr, sv.s[0].y, D, M, sv.s[1], dB, dA, D, ws, s, dl[1]));
     const bool need_dx = dz_out || da_out;
-    AID_TRY(lla_bwd(d.net[0], d.ln[0], g ? &g->net[0] : nullptr, g ? &g->ln[0] : nullptr, ACT_RELU, nullptr, sv.x, X, M, sv.s[0], dA, need_dx ? dx : nullptr, X, ws, s));
+    AID_TRY(lla_bwd(d.net[0], d.ln[0], g ? &g->net[0] : nullptr, g ? &g->ln[0] : nullptr, ACT_RELU, nullptr, sv.x, X, M, sv.s[0], dA, need_dx ? dx : nullptr, X, ws, s, dl[0]));
+    if (g && q) {
+        AID_TRY(q->add(g->net[2].w, D, D, D, dl[2], D, sv.s[1].y, D, M, g->net[2].b));
+        AID_TRY(q->add(g->net[1].w, D, D, D, dl[1], D, sv.s[0].y, D, M, g->net[1].b));
+        AID_TRY(q->add(g->net[0].w, X, D, X, dl[0], D, sv.x, X, M, g->net[0].b));
+    }
     if (dz_out) AID_TRY(axpby_cols(d_next, L, 2.0f, dx, X, 1.0f, dz_out, L, M, L, s));
     if (da_out) AID_TRY(copy_cols(dx + L, X, da_out, A, M, A, s));
     ws.release(mark);
@@ -204,29 +213,41 @@ int value_fwd(const AidValueNet& v, int M, const float* state, int lds, const fl
     return AID_OK;
 }
 int value_bwd(const AidValueNet& v, const AidValueNet* g, int M, const float* t, const ValueSave& sv, const float* d_out, float* dstate,
-              int ldds, Workspace& ws, hipStream_t s) {
+              int ldds, Workspace& ws, hipStream_t s, GradQueue* q) {
     const int L = v.L, TE = v.TE, X = L + TE, D = v.net[0].out;
+    // q: the five weight / bias gradients are recorded (their adjoints kept in buffers that outlive this call) and contracted by the caller's one grouped launch
+    float* dl[3] = {nullptr, nullptr, nullptr}; float* dte_keep = nullptr;
+    if (g && q) { for (int i = 0; i < 3; ++i) dl[i] = ws.f32((size_t)M * D); dte_keep = ws.f32((size_t)M * TE); }
     const size_t mark = ws.mark();
     float* dA = ws.f32((size_t)M * D); float* dB = ws.f32((size_t)M * D); float* dx = ws.f32((size_t)M * X);
-    float* dte = ws.f32((size_t)M * TE); float* dsin = ws.f32((size_t)M * TE);
+    float* dte = dte_keep ? dte_keep : ws.f32((size_t)M * TE); float* dsin = ws.f32((size_t)M * TE);
     AID_WS_OK(ws);
-    if (g) {
+    if (g && q) AID_TRY(q->add(g->out.w, D, 1, D, d_out, 1, sv.s[2].y, D, M, g->out.b));
+    else if (g) {
         AID_TRY(linear_bwd_weight(d_out, 1, sv.s[2].y, D, g->out.w, M, 1, D, s, 1));
         AID_TRY(colsum(d_out, 1, g->out.b, M, 1, 1, s));
     }
     AID_TRY(linear_bwd_data(d_out, 1, v.out.w, D, dA, D, M, 1, s));
-    AID_TRY(lla_bwd(v.net[2], v.ln[2], g ? &g->net[2] : nullptr, g ? &g->ln[2] : nullptr, ACT_RELU, nullptr, sv.s[1].y, D, M, sv.s[2], dA, dB, D, ws, s));
-    AID_TRY(lla_bwd(v.net[1], v.ln[1], g ? &g->net[1] : nullptr, g ? &g->ln[1] : nullptr, ACT_RELU, nullptr, sv.s[0].y, D, M, sv.s[1], dB, dA, D, ws, s));
+    AID_TRY(lla_bwd(v.net[2], v.ln[2], g ? &g->net[2] : nullptr, g ? &g->ln[2] : nullptr, ACT_RELU, nullptr, sv.s[1].y, D, M, sv.s[2], dA, dB, D, ws, s, dl[2]));
+    AID_TRY(lla_bwd(v.net[1], v.ln[1], g ? &g->net[1] : nullptr, g ? &g->ln[1] : nullptr, ACT_RELU, nullptr, sv.s[0].y, D, M, sv.s[1], dB, dA, D, ws, s, dl[1]));
     const bool need_dx = dstate || g;
-    AID_TRY(lla_bwd(v.net[0], v.ln[0], g ? &g->net[0] : nullptr, g ? &g->ln[0] : nullptr, ACT_RELU, nullptr, sv.x, X, M, sv.s[0], dA, need_dx ? dx : nullptr, X, ws, s));
+    AID_TRY(lla_bwd(v.net[0], v.ln[0], g ? &g->net[0] : nullptr, g ? &g->ln[0] : nullptr, ACT_RELU, nullptr, sv.x, X, M, sv.s[0], dA, need_dx ? dx : nullptr, X, ws, s, dl[0]));
+    if (g && q) {
+        AID_TRY(q->add(g->net[2].w, D, D, D, dl[2], D, sv.s[1].y, D, M, g->net[2].b));
+        AID_TRY(q->add(g->net[1].w, D, D, D, dl[1], D, sv.s[0].y, D, M, g->net[1].b));
+        AID_TRY(q->add(g->net[0].w, X, D, X, dl[0], D, sv.x, X, M, g->net[0].b));
+    }
     if (dstate) AID_TRY(copy_cols(dx, X, dstate, ldds, M, L, s));
     if (g) {  // time-embedding branch: te = relu(te1(sinus(t)))
         AID_TRY(copy_cols(dx + L, X, dte, TE, M, TE, s));
         // relu'(pre) with pre stored at stride X inside sv.te_pre's buffer? (see value_fwd) -> use the output: relu out > 0 <=> pre > 0
         AID_TRY(copy_cols(sv.x + L, X, dsin, TE, M, TE, s));                       // dsin temporarily = relu output
         AID_TRY(act_bwd_dual(dsin, dte, nullptr, nullptr, ACT_RELU, (size_t)M * TE, s));
-        AID_TRY(linear_bwd_weight(dte, TE, sv.sin_e, TE, g->te1.w, M, TE, TE, s, 1));
-        AID_TRY(colsum(dte, TE, g->te1.b, M, TE, 1, s));
+        if (q) AID_TRY(q->add(g->te1.w, TE, TE, TE, dte, TE, sv.sin_e, TE, M, g->te1.b));
+        else {
+            AID_TRY(linear_bwd_weight(dte, TE, sv.sin_e, TE, g->te1.w, M, TE, TE, s, 1));
+            AID_TRY(colsum(dte, TE, g->te1.b, M, TE, 1, s));
+        }
         AID_TRY(linear_bwd_data(dte, TE, v.te1.w, TE, dsin, TE, M, TE, s));
         AID_TRY(sinusoid_bwd(dsin, t, v.freq_scale, 1.0f, AID_T_DISCRETE, g->freq_scale, M, TE, s));
     }

@@ -333,8 +333,8 @@ int aid_lambda_returns(const float* rewards, const float* next_values, const flo
 }
 
 size_t aid_small_net_workspace(int B, int D) { return sizeof(float) * (size_t)B * (64 * (size_t)D + 1024) + (1 << 16); }
-size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 * aid_small_net_workspace(B + 64, val->D) : 0; }
-size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B) { return dyn ? aid_small_net_workspace(B, dyn->D) : 0; }
+size_t aid_value_step_workspace(const AidValueNet* val, int B) { return val ? 2 * aid_small_net_workspace(B + 64, val->D) + sizeof(float) * (size_t)(B + 64) * 4 * val->D : 0; }
+size_t aid_dynamics_step_workspace(const AidDynamicsNet* dyn, int B) { return dyn ? aid_small_net_workspace(B, dyn->D) + sizeof(float) * (size_t)(B + 64) * 4 * dyn->D : 0; }
 
 int aid_value_step(const AidValueNet* val, const AidValueNet* vgrads, int B, const float* latents, const float* next_latents,
                    const float* rewards, const float* dones, float gamma, double lam, int n_steps, float* targets_out, float* loss_out,
@@ -358,7 +358,9 @@ int aid_value_step_ex(const AidValueNet* val, const AidValueNet* vgrads, int B, 
     AID_TRY(aid_lambda_returns_ex(rewards, nv, dones, Bx, gamma, lam, n_steps, 0, tg, stream));   // rows >= B: halo, their targets are unused
     hipLaunchKernelGGL(huber_kernel, dim3(1), dim3(1024), 0, s, v, tg, B, dv, loss_out);
     AID_LAUNCH_CHECK();
-    AID_TRY(value_bwd(*val, vgrads, B, t0, sv, dv, nullptr, 0, ws, s));
+    GradQueue gq(s);          // the five Linear weight / bias gradients in one grouped launch (this step sits at the very end of the train_step's critical path)
+    AID_TRY(value_bwd(*val, vgrads, B, t0, sv, dv, nullptr, 0, ws, s, &gq));
+    AID_TRY(gq.flush());
     if (targets_out) AID_TRY(copy_f32(tg, targets_out, B, s));
     return AID_OK;
 }
@@ -374,7 +376,9 @@ int aid_dynamics_step(const AidDynamicsNet* dyn, const AidDynamicsNet* dgrads, i
     AID_TRY(dynamics_fwd(*dyn, B, latents, L, actions, dyn->A, pred, sv, ws, s));
     hipLaunchKernelGGL(mse_grad_kernel, dim3(1), dim3(1024), 0, s, pred, next_latents, (size_t)B * L, dp, loss_out);
     AID_LAUNCH_CHECK();
-    AID_TRY(dynamics_bwd(*dyn, dgrads, B, sv, dp, nullptr, nullptr, ws, s));
+    GradQueue gq(s);
+    AID_TRY(dynamics_bwd(*dyn, dgrads, B, sv, dp, nullptr, nullptr, ws, s, &gq));
+    AID_TRY(gq.flush());
     return AID_OK;
 }
 

@@ -245,9 +245,13 @@ def lib() -> C.CDLL:
                  "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
-    if L.aid_version() != 1:
-        raise RuntimeError("aid_amd: ABI version mismatch between aid_amd/_native.py and libaid_hip.so")
+    if L.aid_version() != ABI_VERSION:
+        raise RuntimeError(f"aid_amd: ABI version mismatch: aid_amd/_native.py binds version {ABI_VERSION} of include/aid_hip.h, "
+                           f"{path} reports {L.aid_version()}; rebuild the library")
     return L
+
+
+ABI_VERSION = 2        # AID_ABI_VERSION of include/aid_hip.h this module's ctypes signatures were written against
 
 
 def check(rc: int, what: str):

@@ -195,7 +195,10 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         InfoNCE, whose feature gradients drive the two encoder backward passes -> policy / value / dynamics phases."""
         cfg, ai = self.config, self.active_inference
         B = cfg.batch_size
-        if len(self.replay_buffer) < B:
+        ready = len(self.replay_buffer) >= B
+        if parallel.is_dp():      # the early return sits in front of this step's collectives: every rank takes it or none does
+            ready = bool(parallel.agree_min([ready], device=self.device)[0])
+        if not ready:
             return {}
         ai.concurrent_belief_loops = self.overlap_streams       # one stream only when asked for one (profiling)
         batch = self.replay_buffer.sample(B)

@@ -92,7 +92,10 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     def _dp_schedule_vote(self) -> bool:
         """-> run this step's belief updates as concurrent chains?"""
         v = getattr(self, "_dp_vote", None)
-        if v is None or not self.concurrent_belief_loops or not self.overlap_streams:
+        # the vote issues collectives (agree_max_float): whether it runs this step is the ranks' AGREED verdict (_take_prefetch), never a
+        # rank-local one - a rank with concurrent_belief_loops / overlap_streams / dp_autotune_schedule switched differently would otherwise
+        # pair its next collective with the other ranks' vote
+        if v is None or not self._agreed.get("vote", False):
             return self.concurrent_belief_loops if self.dp_schedule_choice is None else self.dp_schedule_choice == "chains"
         import time as _t
         order = ("warm", "chains", "merged")
@@ -130,11 +133,15 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
         prefetch backs off exponentially, so a train-once-per-env-step loop pays (almost) nothing for it."""
         cfg, ai = self.config, self.active_inference
         B = cfg.batch_size
-        if len(self.replay_buffer) < B:
-            return {}
         dp = parallel.is_dp()
+        ready = len(self.replay_buffer) >= B
+        if not ready and not dp:
+            return {}
         main = torch.cuda.current_stream()
-        pre = self._take_prefetch(B)           # data parallel: a collective decision (one 6-int all-reduce), see _take_prefetch
+        pre = self._take_prefetch(B, ready)    # data parallel: a collective decision (one 8-int all-reduce), see _take_prefetch
+        if not self._agreed["ready"]:          # some rank's replay shard is still short of a minibatch: no rank steps (the reference's `return {}`)
+            self._lookahead = None
+            return {}
         had_la = self._lookahead is not None
         la = self._take_lookahead(accepted=pre is not None)
         chains = self._dp_schedule_vote() if dp else self.concurrent_belief_loops
@@ -144,11 +151,21 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             # writing the score gradients and its shadow state, while everything below - the commit of that state and the score step if it
             # was accepted, zero_grad and this step's own ELBO if not - now runs on `main`
             main.wait_stream(self._comm_stream())
+        elide = bool(self.elide_dead_next_belief)
         if pre is not None:
             batch, both = pre
         else:
             batch = self.replay_buffer.sample(B)
-            both = ai.denoise_pair(batch["observations"], batch["next_observations"])
+            if elide:
+                # state_agent.py:138-139 computes a next_obs belief that :195-196 overwrites before anything reads it: only its DRAWS matter
+                # (they advance the stream every later draw comes from).  A parity tape is advanced by exactly those draws; device Philox
+                # has nothing to keep aligned.
+                N_, tr_ = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
+                n_obs = ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N_, tr_)
+                ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N_, tr_)          # the dead update's draws, consumed and dropped
+                both = ai.denoise_only(batch["observations"], noise=n_obs)
+            else:
+                both = ai.denoise_pair(batch["observations"], batch["next_observations"])
         obs, actions, rewards = batch["observations"], batch["actions"], batch["rewards"]
         next_obs, dones = batch["next_observations"], batch["dones"]
         if la is not None:          # this step's normalised rewards and ELBO were computed at the end of the previous step (_lookahead_elbo)
@@ -202,7 +219,11 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                 hook = lambda: ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
                 n3 = hook()                                        # draws of the third belief update ...
                 nxt = self.replay_buffer.sample(B)                 # ... then the next step's index draw and its two belief updates
-                tri = ai.denoise_many([next_obs, nxt["observations"], nxt["next_observations"]], [n3, hook(), hook()], ws=ws)
+                if elide:       # the next step's next_obs belief is never read (see above): its draws are taken, the loop is not run
+                    n1 = hook(); hook()
+                    tri = ai.denoise_many([next_obs, nxt["observations"]], [n3, n1], ws=ws)
+                else:
+                    tri = ai.denoise_many([next_obs, nxt["observations"], nxt["next_observations"]], [n3, hook(), hook()], ws=ws)
                 next_latents = tri[:B]
                 self._prefetch = {"batch": nxt, "latents": tri[B:], "buffer": (id(self.replay_buffer), self.replay_buffer.version),
                                   "params": (self.score_optimizer.arena.step_count, ai.param_version), "B": B, "train": train}
@@ -271,6 +292,12 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
     # committed when the next step accepts the prefetch (same validity test), and discarded otherwise.
     lookahead_elbo = True
     _lookahead = None
+    # The reference computes a belief over next_obs at the top of the step (state_agent.py:138-139) and overwrites it with a re-sampled one
+    # (:195-196) before anything reads it - the pixel agent does read its (pixel_agent.py:364-371), the state agent does not.  True: that
+    # reverse loop is not run (one of the three 50-step loops of a step; its random draws are still consumed from a parity tape, so every
+    # later draw, every metric and every post-step tensor is unchanged: tests/test_hip_agent.py::test_dead_next_belief_elision_changes_nothing).
+    # False: executed as the reference executes it.
+    elide_dead_next_belief = True
     concurrent_belief_loops = True     # the belief updates of a step as separate concurrent reverse loops (DiffusionActiveInference._denoise_chains)
 
     def _lookahead_elbo(self, side, ws, dp, main):
@@ -302,7 +329,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
 
     # What this step does about prefetching, as agreed by all ranks (one rank: its own switches).  Written by _take_prefetch at the start of
     # every train_step and read by everything further down that gates a collective.
-    _agreed = {"prefetch": True, "lookahead": True}
+    _agreed = {"prefetch": True, "lookahead": True, "vote": False, "ready": True}
 
     def _want_prefetch(self) -> bool:
         self._prefetch = None
@@ -313,7 +340,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
             return False
         return True
 
-    def _take_prefetch(self, B: int):
+    def _take_prefetch(self, B: int, ready: bool = True):
         """The prefetched (minibatch, latents) if they are exactly what this step would compute, else None.
 
         Data parallel: accepting or rejecting changes which collectives the step issues (an accepted look-ahead ELBO has already run its
@@ -329,10 +356,16 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
               pre["params"] == (self.score_optimizer.arena.step_count, ai.param_version) and pre["train"] == ai.latent_score_network.training)
         had = pre is not None
         want_pre, want_la = bool(self.prefetch_next_batch), bool(self.lookahead_elbo and self.overlap_streams)
+        # the schedule vote (_dp_schedule_vote) and the "buffer still short of a minibatch" early return both decide whether collectives are
+        # issued further down: they ride on the same exchange
+        vote = bool(getattr(self, "_dp_vote", None) is not None and self.concurrent_belief_loops and self.overlap_streams)
         if parallel.is_dp():
-            v = parallel.agree_min([ok, -int(had), -self._prefetch_wait, -self._prefetch_backoff, want_pre, want_la], device=self.device)
+            v = parallel.agree_min([ok, -int(had), -self._prefetch_wait, -self._prefetch_backoff, want_pre, want_la, vote, ready], device=self.device)
             ok, had, self._prefetch_wait, self._prefetch_backoff, want_pre, want_la = bool(v[0]), bool(-v[1]), -v[2], -v[3], bool(v[4]), bool(v[5])
-        self._agreed = {"prefetch": want_pre, "lookahead": want_la}
+            vote, ready = bool(v[6]), bool(v[7])
+        self._agreed = {"prefetch": want_pre, "lookahead": want_la, "vote": vote, "ready": ready}
+        if not ready:
+            return None
         if ok:
             self._prefetch_backoff = 0
             return pre["batch"], pre["latents"]

@@ -615,9 +615,8 @@ __global__ void sigmoid_nchw_kernel(const float* __restrict__ x, const float* __
 }
 
 struct ConvW { const float* w_eff; int cin, cout, Kp; };
-// out[Cout][R*H*W] = 3x3 conv of x (stride 1, pad 1) as an implicit GEMM; `col` is unused (kept in the signature of the callers' scratch layout)
-static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* col, float* out, hipStream_t s) {
-    (void)col;
+// out[Cout][R*H*W] = 3x3 conv of x (stride 1, pad 1) as an implicit GEMM (conv_igemm.hip: nothing of size 9 Cin x R H W is written)
+static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
     return conv3_igemm(cw.w_eff, cw.Kp, x, out, cw.cin, cw.cout, R, H, H, 1, s);
 }
 static int conv1_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
@@ -947,7 +946,6 @@ size_t aid_conv_decoder_workspace(const AidConvDecoder* d, int R) {
     }
     const size_t amax = (size_t)R * (3528 * H > 32u * 168 * 168 ? 3528 * H : 32u * 168 * 168);   // largest stage: (H/8) x 168^2 = 8H x 21^2 per image
     n += amax * 5;                                                          // ping-pong activations + conv outputs
-    n += (size_t)R * 168 * 168 * (9 * H / 8 > 288 ? 9 * H / 8 + 32 : 288 + 32);   // im2col of the widest 168x168 conv
     return sizeof(float) * n + (1 << 20);
 }
 
@@ -997,7 +995,6 @@ static int conv_decoder_trunk(const AidConvDecoder& d, const DecPrep& p, int R, 
     const ConvW* m0 = p.m0; const ConvW* m1 = p.m1; const ConvW* rs = p.rs; const ConvW& o0 = p.o0; const ConvW& o3 = p.o3; const ConvW& o6 = p.o6;
     const size_t amax = (size_t)R * ((size_t)3528 * H > 32u * 168 * 168 ? (size_t)3528 * H : 32u * 168 * 168);
     float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
-    float* col = nullptr;
     AID_WS_OK(ws);
     hipLaunchKernelGGL(bigln_mish_cnhw_kernel, dim3(R), dim3(1024), 0, s, big, d.ln5.g, d.ln5.b, xa, R, H, HW0);
     AID_LAUNCH_CHECK();
@@ -1006,9 +1003,9 @@ static int conv_decoder_trunk(const AidConvDecoder& d, const DecPrep& p, int R, 
     float* x = xa; float* y = xb;
     for (int i = 0; i < 4; ++i) {
         const int ho = up[i] ? 2 * hsz : hsz, co = cout[i];
-        AID_TRY(conv3_fwd(m0[i], x, R, hsz, col, cv, s));                                                       // [co or 4co][R][hsz^2]
+        AID_TRY(conv3_fwd(m0[i], x, R, hsz, cv, s));                                                       // [co or 4co][R][hsz^2]
         AID_TRY(instnorm(cv, d.blk[i].main0.bias, (const float*)nullptr, y, co, R, ho, ho, up[i], ACT_MISH, s));
-        AID_TRY(conv3_fwd(m1[i], y, R, ho, col, cv, s));                                                        // [co][R][ho^2]
+        AID_TRY(conv3_fwd(m1[i], y, R, ho, cv, s));                                                        // [co][R][ho^2]
         const float* resid = x;                                                                                 // identity residual (block 0)
         if (up[i]) {
             AID_TRY(conv1_fwd(rs[i], x, R, hsz, cr, s));                                                        // [4co][R][hsz^2]
@@ -1021,11 +1018,11 @@ static int conv_decoder_trunk(const AidConvDecoder& d, const DecPrep& p, int R, 
         float* t = x; x = y; y = t; hsz = ho;
     }
     // ---- output_proj: (conv, IN, Mish) x2, conv, sigmoid
-    AID_TRY(conv3_fwd(o0, x, R, hsz, col, cv, s));
+    AID_TRY(conv3_fwd(o0, x, R, hsz, cv, s));
     AID_TRY(instnorm(cv, d.out0_b, (const float*)nullptr, y, 32, R, hsz, hsz, 0, ACT_MISH, s));
-    AID_TRY(conv3_fwd(o3, y, R, hsz, col, cv, s));
+    AID_TRY(conv3_fwd(o3, y, R, hsz, cv, s));
     AID_TRY(instnorm(cv, d.out3_b, (const float*)nullptr, x, 32, R, hsz, hsz, 0, ACT_MISH, s));
-    AID_TRY(conv3_fwd(o6, x, R, hsz, col, cv, s));
+    AID_TRY(conv3_fwd(o6, x, R, hsz, cv, s));
     L1D(sigmoid_nchw_kernel, (size_t)3 * R * hsz * hsz, s, cv, d.out6_b, out, 3, R, hsz * hsz);
     ws.release(mark0);
     return AID_OK;

@@ -1166,8 +1166,14 @@ static inline bool mid_route_ok(const GemmArgs& g, bool vec) {
     return g.N >= 512 && g.N <= 4096;
 }
 static thread_local SplitScope* t_split = nullptr;
-SplitScope::SplitScope(Workspace& ws, hipStream_t st, size_t fl, int nc) : slab(ws.f32(fl)), floats(fl), ctr((int*)ws.raw(nc * sizeof(int))), nctr(nc), s(st), prev(t_split) {
-    if (!slab || !ctr || hipMemsetAsync(ctr, 0, nc * sizeof(int), st) != hipSuccess) { slab = nullptr; ctr = nullptr; }      // no scratch: no route
+SplitScope::SplitScope(Workspace& ws, hipStream_t st, size_t fl, int nc) : slab(nullptr), floats(fl), ctr(nullptr), nctr(nc), s(st), prev(t_split) {
+    // The scratch is optional: a workspace sized without it (a caller holding the previous formula's size) must degrade to "no route", not to
+    // AID_E_WORKSPACE - so look before allocating (Workspace::raw marks an overflow that the next AID_WS_OK would report).
+    const size_t a0 = (ws.off + 255) & ~(size_t)255, a1 = (a0 + fl * sizeof(float) + 255) & ~(size_t)255;
+    if (ws.base != nullptr && !ws.overflow && a1 + nc * sizeof(int) <= ws.bytes) {
+        slab = ws.f32(fl); ctr = (int*)ws.raw(nc * sizeof(int));
+        if (!slab || !ctr || hipMemsetAsync(ctr, 0, nc * sizeof(int), st) != hipSuccess) { slab = nullptr; ctr = nullptr; }      // no scratch: no route
+    }
     t_split = this;
 }
 SplitScope::~SplitScope() { t_split = prev; }

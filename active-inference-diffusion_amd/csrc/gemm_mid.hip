@@ -26,6 +26,10 @@
 #include "aid_common.h"
 #include "rowwise.h"
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "gemm_mid.hip: the in-kernel split-K fold relies on gfx942 / gfx950 sc1 (agent-scope, L2-bypassing) store-acknowledge semantics; build with --offload-arch=gfx950"
+#endif
+
 namespace aid {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -196,6 +200,16 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
         // costs ~40 us here), a thread waits for its own stores to be acknowledged before the barrier, and one thread then counts the
         // arrival.  Whoever counts the last one reads the other slices and finishes the tile.  The fold runs in slice order whoever folds,
         // and a slice's partial is the same bits from a register or from memory: the result does not depend on the arrival order.
+        //
+        // Ordering contract (hardware, not the C++ memory model - the atomics below are RELAXED on purpose): on gfx942 / gfx950 a
+        // `global_store ... sc1` is performed at agent scope (written through the XCD's non-coherent L2 to the memory side every XCD sees)
+        // and its vmcnt slot is released only when that write is acknowledged there; `s_waitcnt vmcnt(0)` therefore means "my partials are
+        // visible device-wide", the workgroup barrier extends that to all 256 threads, and the arrival count issued after it cannot be
+        // observed before them.  On the reading side `global_load ... sc1` misses the local L2 by scope, and the loads are issued only after
+        // the thread that counted the last arrival has published s_last through LDS + barrier.  No other target is compiled (see the
+        // #error below); tests/test_hip_kernels.py::test_gemm_split_k_folded_in_kernel poisons the slices with NaN between launches and
+        // changes the operands every launch, so a stale or early read shows up as NaN / a wrong sum.  If it ever trips: make the counter
+        // increment __ATOMIC_RELEASE and the fold's first load __ATOMIC_ACQUIRE (cost: the L2 write-back measured above).
         __shared__ int s_last;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();

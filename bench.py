@@ -36,9 +36,25 @@ import torch
 
 O, A, D, BATCH, HORIZON, NSTEPS = 17, 6, 512, 256, 5, 50
 PEAK_F32_MFMA = 157.3e12       # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
-# algorithmic FLOPs of one cfg-2 train_step, dead work removed, shared-t time embedding hoisted
-ALGO_FLOP_PER_STEP = 4.54e12
 ALGO_FLOP_PER_DENOISE_ROW_STEP = 46.4e6
+# algorithmic FLOPs of one cfg-2 train_step, dead work removed, shared-t time embedding hoisted (4.54 TFLOP) - MINUS the belief
+# update over next_obs that the reference computes at state_agent.py:138-139 and overwrites at :195-196 before anything reads it: one of the
+# three 50-step reverse loops of a step (50 x 256 rows x 46.4 MFLOP = 0.594 TFLOP) is dead work too, whether or not it is executed.
+DEAD_BELIEF_FLOP_PER_STEP = NSTEPS * BATCH * ALGO_FLOP_PER_DENOISE_ROW_STEP
+ALGO_FLOP_PER_STEP = 4.54e12 - DEAD_BELIEF_FLOP_PER_STEP
+
+
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> with the highest round number NN present (None if there is none): the roofline objects cite the newest committed
+    rocprofv3 artefact of each kind instead of a hard-coded round."""
+    import glob
+    import re
+    best = None
+    for f in glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)):
+        m = re.match(r"r(\d\d)_", os.path.basename(f))
+        if m and (best is None or int(m.group(1)) > best[0]):
+            best = (int(m.group(1)), f)
+    return best[1] if best else None
 
 
 class _Box:
@@ -50,9 +66,9 @@ class _Env:
     observation_space, action_space = _Box((O,)), _Box((A,))
 
 
-def make_agent(device, seed=0):
+def make_agent(device, seed=0, batch=BATCH):
     import aid_amd
-    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=BATCH, efe_horizon=HORIZON, latent_dim=O, hidden_dim=D)
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=batch, efe_horizon=HORIZON, latent_dim=O, hidden_dim=D)
     cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
     torch.manual_seed(seed)
     agent = aid_amd.DiffusionStateAgent(_Env(), cfg, aid_amd.TrainingConfig(buffer_size=8192))
@@ -200,7 +216,7 @@ def roofline_phases(agent):
     (median of 3).  `flop` = sum of 2 M N K over the GEMM launches the library counted for one call of the phase (aid_prof_*): the work
     actually executed, i.e. after the W_o W_v collapse and the shared-t hoisting; `frac` = flop / ms / fp32-MFMA peak.  The estimator is
     the difference between the whole aid_efe_step and the same call with skip_epistemic (it is one launch sequence inside that call).
-    tools/perf/phase_profile.py runs the same phases under rocprofv3 (profiles/r03_phase_*_kernel_stats.csv)."""
+    tools/perf/phase_profile.py runs the same phases under rocprofv3 (profiles/rNN_phase_*_kernel_stats.csv)."""
     from aid_amd import _native as nat
     ai, cfg = agent.active_inference, agent.config
     B, N = cfg.batch_size, cfg.diffusion.num_diffusion_steps
@@ -248,6 +264,9 @@ def roofline_phases(agent):
     def three_chains():
         return ai.denoise_many([next_obs, obs, next_obs])
 
+    def two_chains():
+        return ai.denoise_many([next_obs, obs])
+
     def value_dyn():
         agent.value_optimizer.zero_grad(); agent.dynamics_optimizer.zero_grad()
         nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones, cfg.discount_factor, 0.95, 5, ws=ai._ws)
@@ -273,8 +292,10 @@ def roofline_phases(agent):
               f"({ms_t:.2f} ms) minus the same call with skip_epistemic ({ms_r:.2f} ms)", "current stream")
         fl_c, n_c = counted(lambda: ai.denoise_only(obs, ws=ai._ws))        # direct launches of the same 256-row loop (a graph replay is not counted)
         phase("reverse_loop_one_chain", timed(one_chain), fl_c, n_c, f"one {N}-step reverse-diffusion loop at {B} rows, hipGraph replay (core/diffusion.py:176-206)", "current stream")
-        phase("reverse_loops_three_chains", timed(three_chains), 3 * fl_c, 3 * n_c, f"the three belief updates of a train_step as three concurrent {B}-row loops "
-              "(hipGraph replays): the schedule the timed steps run", "current + two chain streams")
+        phase("reverse_loops_three_chains", timed(three_chains), 3 * fl_c, 3 * n_c, f"the three belief updates the reference's train_step executes as three concurrent {B}-row loops "
+              "(hipGraph replays): the schedule `value` times", "current + two chain streams")
+        phase("reverse_loops_two_chains", timed(two_chains), 2 * fl_c, 2 * n_c, f"the two LIVE belief updates of a train_step (the next_obs belief of state_agent.py:138-139 is never read) as two "
+              f"concurrent {B}-row loops: the schedule `value_dead_belief_elided` times", "current + one chain stream")
         fl_v, n_v = counted(value_dyn)
         phase("value_dynamics", timed(value_dyn), fl_v, n_v, "value step (two value forwards, lambda-returns, Huber, backward) + dynamics step at 256 rows: a latency "
               "chain of ~60 small launches, 2 GFLOP", "current stream")
@@ -309,6 +330,21 @@ def other_configs(device):
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         print("[bench] other config, ms per step:", [round(1e3 * t, 1) for t in ts], file=sys.stderr, flush=True)
         return float(np.median(ts)), m
+    # BASELINE configs[0]: the reference's CPU-runnable plumbing case on the HIP path (B = 32, EFE horizon 1, 10 denoise steps).  Live FLOPs (SURVEY
+    # 8d: 0.126 TFLOP executed-minus-dead) minus the never-read next_obs belief update, which the agent's default schedule does not run.
+    b1, h1, n1 = 32, 1, 10
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b1, efe_horizon=h1, latent_dim=O, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=n1)
+    agent = aid_amd.DiffusionStateAgent(_Env(), cfg, aid_amd.TrainingConfig(buffer_size=8192))
+    rng = np.random.default_rng(0); n = 4096
+    agent.replay_buffer.add_batch(rng.standard_normal((n, O)), rng.uniform(-1, 1, (n, A)), rng.standard_normal(n), rng.standard_normal((n, O)), rng.random(n) < 0.01)
+    dt, m = timed(agent, warm=4, steps=10)
+    fl1 = 0.126e12 - n1 * b1 * ALGO_FLOP_PER_DENOISE_ROW_STEP
+    res["cfg1_b32"] = {"workload": "HalfCheetah-v4 state obs, batch=32, EFE horizon=1, 10 denoise steps (BASELINE configs[0])", "ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt,
+                       "algorithmic_flop_per_step": fl1, "algorithmic_tflops": fl1 / dt / 1e12, "frac_of_f32_mfma_peak": fl1 / dt / PEAK_F32_MFMA,
+                       "note": "32-row layers: launch / weight-streaming bound (SURVEY 8d), the MFMA fraction is shown for completeness",
+                       "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    del agent; torch.cuda.empty_cache()
     o3, a3, b3 = 11, 3, 1024
     cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b3, efe_horizon=HORIZON, latent_dim=o3, hidden_dim=D)
     cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
@@ -319,8 +355,8 @@ def other_configs(device):
     rng = np.random.default_rng(0); n = 4096
     agent.replay_buffer.add_batch(rng.standard_normal((n, o3)), rng.uniform(-1, 1, (n, a3)), rng.standard_normal(n), rng.standard_normal((n, o3)), rng.random(n) < 0.01)
     dt, m = timed(agent)
-    fl3 = 18.1e12
-    res["cfg3_hopper_b1024"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_tflops": fl3 / dt / 1e12, "frac_of_f32_mfma_peak": fl3 / dt / PEAK_F32_MFMA,
+    fl3 = 18.1e12 - NSTEPS * b3 * ALGO_FLOP_PER_DENOISE_ROW_STEP        # SURVEY 8(d)'s 18.1 TFLOP minus the never-read next_obs belief update (not run by default)
+    res["cfg3_hopper_b1024"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_flop_per_step": fl3, "algorithmic_tflops": fl3 / dt / 1e12, "frac_of_f32_mfma_peak": fl3 / dt / PEAK_F32_MFMA,
                                 "finite": bool(all(np.isfinite(v) for v in m.values()))}
     del agent; torch.cuda.empty_cache()
     l4, a4, b4 = 128, 6, 256
@@ -432,17 +468,23 @@ def dry_rehearsal(args, world, rank):
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     ok = bool(torch.allclose(g, torch.full((1024,), (world + 1) / 2.0)))
+    ones = torch.ones(1)
     if world > 1:
+        dist.all_reduce(ones)                 # the ranks the communicator really has (what the GPU run reports as rccl_ranks_seen)
         dist.destroy_process_group()
     if not ok:
         raise SystemExit(f"rank {rank}: all-reduce mean gave {float(g[0])}")
     if os.environ.get("AID_BENCH_DRY_FAIL_RANK", "") == str(rank):
         raise SystemExit(3)
+    strong = args.scaling == "strong"
+    rows = BATCH // world if strong else BATCH
     if rank == 0:
-        print(json.dumps({"metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": None, "unit": "train steps/s (batch=256 each)",
+        print(json.dumps({"metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": None,
+                          "unit": "train steps/s (batch=256 each)" if not strong else "train steps/s (global batch=256, split over the ranks)",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
-                          "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "none (DRY launcher rehearsal over gloo on CPU; not a result)",
-                          "config": {"workload": "launcher rehearsal", "global_batch": BATCH * world, "parallelism": f"dp{world}"}}))
+                          "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none (DRY launcher rehearsal over gloo on CPU; not a result)",
+                          "config": {"workload": "launcher rehearsal", "global_batch": rows * world, "rows_per_rank": rows, "parallelism": f"dp{world}"},
+                          "data_parallel": {"rccl_ranks_seen": int(ones.item()), "backend": "gloo", "rows_per_rank": rows, "scaling": args.scaling}}))
 
 
 def main():
@@ -454,7 +496,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="keep every phase on one stream (rocprofv3 --pmc passes: counter collection "
                     "serialises dispatches anyway and crashes on this pool when two streams dispatch concurrently)")
     ap.add_argument("--dump-launches", default="", help="write the per-launch GEMM timings of the profiled step to this CSV")
-    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (small-batch loops, cfg 3 / cfg 4 train_steps)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the untimed extras (small-batch loops, cfg 1 / cfg 3 / cfg 4 train_steps)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="weak (default): 256 rows PER RANK (BASELINE configs[4] at N=8: global batch "
+                    "2048); strong: the 256-row global batch of configs[1] split over the ranks (256/N rows each; N must divide 256)")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -464,6 +508,9 @@ def main():
         sys.exit(self_launch(args.gpus))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.scaling == "strong" and BATCH % world:
+        raise SystemExit(f"--scaling strong: {world} ranks do not divide the global batch of {BATCH}")
+    rows = BATCH // world if args.scaling == "strong" else BATCH          # minibatch rows per rank
     # AID_BENCH_REHEARSAL=gloo: rehearse the multi-rank glue (rendezvous, sharded sampling, gradient / normaliser / time-importance
     # collectives, barrier + max-over-ranks timing, rank-0 line) with several ranks sharing ONE GPU; the number it prints is not a result.
     # AID_BENCH_REHEARSAL=dry: the launcher + rendezvous + timing protocol alone on a box WITHOUT a GPU (tests/test_bench_launcher_cpu.py):
@@ -485,7 +532,7 @@ def main():
     from aid_amd import _native as nat
     if os.environ.get("AID_ROWLN_DEBUG"):          # kernel A/B experiments (tools/perf/README.md); never set by the driver
         nat.lib().aid_rowln_debug(int(os.environ["AID_ROWLN_DEBUG"]))
-    agent = make_agent(device, seed=rank)
+    agent = make_agent(device, seed=rank, batch=rows)
     if world > 1:
         agent.enable_data_parallel()
     if args.no_overlap:
@@ -499,6 +546,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed_steps(k):
+        """EXACTLY k train_steps between barrier + synchronize on both sides; -> (max over ranks of the bracketed time, this rank's own time)."""
+        sync(); t0 = time.perf_counter()
+        for _ in range(k):
+            agent.train_step()
+        torch.cuda.synchronize(); own = time.perf_counter() - t0          # this rank's own time, before the closing barrier
+        sync(); el = time.perf_counter() - t0
+        if world > 1:
+            import torch.distributed as dist
+            tt = torch.tensor([el], device=device if not rehearsal else "cpu", dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            el = float(tt)
+        return el, own
+
+    # `value`: the step as the reference executes it, dead next_obs belief update included (what rounds 1-3 timed).  A second timed region
+    # of the same K steps in the same process runs the agent's default - that update elided (state_agent.py:138-139 is overwritten at
+    # :195-196 before any read; same metrics and post-step tensors, tests/test_hip_agent.py::test_dead_next_belief_elision_changes_nothing).
+    agent.elide_dead_next_belief = False
     warm = max(args.warmup, 2)                # >= 2: the zero-initialised score head makes step-1 gradients degenerate
     for _ in range(warm):
         agent.train_step()
@@ -506,23 +571,23 @@ def main():
     # _dp_schedule_vote); those steps are warm-up too - the timed region runs ONE schedule.  Same count on every rank (the vote is collective).
     while world > 1 and getattr(agent, "_dp_vote", None) is not None and warm < 16:
         agent.train_step(); warm += 1
-    sync(); t0 = time.perf_counter()
-    for _ in range(args.steps):
+    elapsed, own = timed_steps(args.steps)
+    agent.elide_dead_next_belief = True
+    for _ in range(2):                        # the first step still consumes a three-loop prefetch; the chain graphs of the two-loop form are captured here
         agent.train_step()
-    torch.cuda.synchronize(); own = time.perf_counter() - t0          # this rank's own time, before the closing barrier
-    sync(); elapsed = time.perf_counter() - t0
+    elapsed_elided, own_elided = timed_steps(args.steps)
     dp_info = None
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=device if not rehearsal else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt)
         # what a SCALE record can be checked against: the ranks the communicator really has (counted by an all-reduce of ones on the
         # backend the gradients use), every rank's own time for the K steps, and the schedule the data-parallel agent settled on
         ones = torch.ones(1, device=device if not rehearsal else "cpu"); dist.all_reduce(ones)
         mine = torch.tensor([1e3 * own / args.steps], device=device if not rehearsal else "cpu", dtype=torch.float64)
         allms = [torch.zeros_like(mine) for _ in range(world)]; dist.all_gather(allms, mine)
+        mine2 = torch.tensor([1e3 * own_elided / args.steps], device=mine.device, dtype=torch.float64)
+        allms2 = [torch.zeros_like(mine2) for _ in range(world)]; dist.all_gather(allms2, mine2)
         dp_info = {"rccl_ranks_seen": int(ones.item()), "backend": dist.get_backend(), "per_rank_ms_per_step": [float(x) for x in allms],
+                   "per_rank_ms_per_step_dead_belief_elided": [float(x) for x in allms2], "rows_per_rank": rows, "scaling": args.scaling,
                    "belief_loop_schedule": getattr(agent, "dp_schedule_choice", None), "belief_loop_schedule_ms": getattr(agent, "dp_schedule_ms", None)}
     # ---- outside the timed region: denoise-only rate and the live GEMM roofline (event-bracketed launches)
     SKIP = set(os.environ.get("AID_BENCH_SKIP", "").split(","))      # diagnostics only
@@ -571,12 +636,12 @@ def main():
     g = {k: gt[k] + gs[k] for k in gt}
     tf = lambda d: (d["flops"] / (d["ms"] * 1e-3) / 1e12) if d["ms"] > 0 else 0.0
     # HBM-side bytes per launch come from the committed rocprofv3 PMC passes, not from this run (profiles/README.md: how they were taken and
-    # corrected): r03_pmc_chain_summary.json = one 256-row reverse loop alone (the kernels of the concurrent chains), r02_pmc_summary.json = one
-    # single-stream train_step (the tall kernels; unchanged since).  Every roofline object names its source in `traffic_source`.
+    # corrected): rNN_pmc_chain_summary.json = one 256-row reverse loop alone (the kernels of the concurrent chains), rNN_pmc_summary.json = one
+    # single-stream train_step (the tall kernels) - the newest round present of each.  Every roofline object names its source in `traffic_source`.
     pmc = []
-    for fn in ("r03_pmc_chain_summary.json", "r03_pmc_summary.json", "r02_pmc_summary.json"):
+    for path in (latest_profile("pmc_chain_summary.json"), latest_profile("pmc_summary.json")):
         try:
-            pmc.append((fn, json.load(open(os.path.join(ROOT, "profiles", fn)))))
+            pmc.append((os.path.basename(path), json.load(open(path))))
         except Exception:
             pass
     def traffic(prefix):
@@ -603,7 +668,7 @@ def main():
     ss_dominant["note"] = ("largest share of GPU time in the SINGLE-STREAM step; achieved = sum(2MNK) / sum(HIP-event durations) of its launches "
                            "(compare us_per_launch with AverageNs of the same name in profiles/*_kernel_stats_no_overlap.csv)")
     # which kernel: largest share of kernel time in the OVERLAPPED schedule (side stream + three concurrent 256-row chains), from the rocprofv3
-    # --kernel-trace --stats summary of `python bench.py` committed under profiles/ (tools/perf/r03_profiles.sh)
+    # --kernel-trace --stats summary of `python bench.py` committed under profiles/ (tools/perf/r04_profiles.sh)
     chain_entries = [entry(n, d) for n, d in sorted(prof_chain["per_kernel"].items(), key=lambda kv: -kv[1]["ms"])]
     for e in chain_entries:
         e["profiled"] = "one 256-row reverse loop alone, single stream, direct launches (what each of the three concurrent chains launches)"
@@ -611,7 +676,8 @@ def main():
     live = {e["kernel"]: e for e in [entry(n, d) for n, d in ranked]}
     live.update({e["kernel"]: e for e in chain_entries})        # the chain kernels' own measurement wins over the merged-loop instantiations
     share = {}
-    stats_csv = os.path.join(ROOT, "profiles", "r03_train_step_kernel_stats.csv")
+    stats_csv = latest_profile("train_step_kernel_stats.csv")       # rocprofv3 --kernel-trace --stats of `python bench.py`, newest round committed
+    stats_name = "profiles/" + os.path.basename(stats_csv) if stats_csv else None
     try:
         import csv
         rows = list(csv.DictReader(open(stats_csv)))
@@ -626,16 +692,18 @@ def main():
         dominant = dict(live[cands[0][1]]); second = dict(live[cands[1][1]]) if len(cands) > 1 else None
         for e in (dominant, second):
             if e is not None:
-                e["overlapped_schedule"] = dict(share[e["kernel"]], source="profiles/r03_train_step_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command)")
-                # the same work priced at the profiler's average duration: HIP events add ~2 us to a launch of a few us (two extra packets
-                # per kernel through the command processor), so for the small chain kernels the live figure reads lower than this one
+                e["overlapped_schedule"] = dict(share[e["kernel"]], source=f"{stats_name} (rocprofv3 --kernel-trace --stats of this command)")
+                # `achieved` / `frac`: the launch's algorithmic FLOPs at the PROFILER's average duration of this kernel in the timed schedule (the
+                # figure that follows from the committed summary).  HIP events add ~2 us to a launch of a few us (two extra packets per kernel
+                # through the command processor), so the live event-bracketed figure of this run is kept beside it as *_hip_events.
+                e["achieved_hip_events"], e["frac_hip_events"] = e["achieved"], e["frac"]
                 at = e["flop_per_launch"] / (share[e["kernel"]]["avg_us"] * 1e-6) / 1e12
-                e["achieved_at_rocprofv3_average"] = at; e["frac_at_rocprofv3_average"] = at * 1e12 / PEAK_F32_MFMA
+                e["achieved"], e["frac"] = at, at * 1e12 / PEAK_F32_MFMA
+                e["us_per_launch_hip_events"] = e["us_per_launch"]; e["us_per_launch"] = share[e["kernel"]]["avg_us"]
         dominant["note"] = ("the GEMM kernel instantiation with the largest share of kernel time in the schedule the timed steps run (overlapped_schedule, from the "
-                            "committed rocprofv3 trace); achieved = sum(2MNK) / sum(HIP-event durations) of its launches measured live in the configuration `profiled` "
-                            "names (events are faithful on one busy stream only; they still add ~2 us per launch, which matters for a 7 us kernel: "
-                            "achieved_at_rocprofv3_average prices the same FLOPs at the profiler's average duration); compare us_per_launch with AverageNs in "
-                            "profiles/r03_phase_chain1_kernel_stats.csv (chain kernels) or r03_train_step_kernel_stats_no_overlap.csv (the others)")
+                            f"committed rocprofv3 trace {stats_name}); achieved = 2MNK per launch / that trace's average duration of the kernel; "
+                            "achieved_hip_events = sum(2MNK) / sum(HIP-event durations) of its launches measured live in this run in the configuration `profiled` "
+                            "names (events are faithful on one busy stream only and add ~2 us per launch, which matters for a 7 us kernel)")
     else:
         dominant, second = ss_dominant, ss_second
     ov_entries = None
@@ -643,17 +711,32 @@ def main():
         ov_entries = []
         for _, k in cands[:8]:
             e = dict(live[k]); e["overlapped_schedule"] = share[k]; ov_entries.append(e)
+    strong = args.scaling == "strong"
+    # weak: every rank completes its own batch-256 step per step => `world` batch-256 steps per step time; strong: the ranks together complete ONE
+    # batch-256 step (256 / world rows each) per step time
+    agg = 1.0 if strong else float(world)
+    steps_per_s_el = args.steps / elapsed_elided
     out = {
-        "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * world, "unit": "train steps/s (batch=256 each)",
+        "metric": "training steps/s (batch=256), HalfCheetah-v4 state dims", "value": steps_per_s * agg,
+        "unit": "train steps/s (batch=256 each)" if not strong else "train steps/s (global batch=256, split over the ranks)",
         "n_gpus": world, "steps": args.steps, "warmup": warm, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU over gloo; not a result)",
-        "config": {"workload": "HalfCheetah-v4 state obs (O=17,A=6,L=17), batch=256/GPU, EFE horizon=5, K=10, S=10, 50 denoise steps, hidden=512 "
-                               "(BASELINE configs[1]); full DiffusionStateAgent.train_step", "global_batch": BATCH * world,
-                   "parallelism": f"dp{world}" if world > 1 else "single", "rng": "device Philox4x32-10"},
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic" if not rehearsal else "synthetic (REHEARSAL: ranks share one GPU over gloo; not a result)",
+        "config": {"workload": f"HalfCheetah-v4 state obs (O=17,A=6,L=17), batch={rows}/GPU, EFE horizon=5, K=10, S=10, 50 denoise steps, hidden=512 "
+                               "(BASELINE configs[1]" + (f", its 256-row batch split over {world} ranks" if strong and world > 1 else "") +
+                               "); full DiffusionStateAgent.train_step as the reference executes it (incl. the next_obs belief update it never reads)",
+                   "global_batch": rows * world, "rows_per_rank": rows, "parallelism": f"dp{world}" if world > 1 else "single", "rng": "device Philox4x32-10"},
+        # second timed region, same process, same K: the agent's default schedule, which does not run the belief update over next_obs that
+        # state_agent.py:138-139 computes and :195-196 overwrites before any read (identical metrics and post-step tensors)
+        "value_dead_belief_elided": steps_per_s_el * agg, "ms_per_step_dead_belief_elided": 1e3 * elapsed_elided / args.steps,
+        "dead_belief": {"flop_per_step": DEAD_BELIEF_FLOP_PER_STEP * rows / BATCH, "reference": "agents/state_agent.py:138-139 (overwritten at :195-196)",
+                        "executed_in": "value / ms_per_step", "not_executed_in": "value_dead_belief_elided / ms_per_step_dead_belief_elided",
+                        "note": "never part of the FLOP numerators below: they count live work only (SURVEY 8d: executed total minus dead work)"},
         "denoise_steps_per_s": NSTEPS / dn, "denoise_row_steps_per_s": NSTEPS * BATCH / dn,
         "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
-        "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * steps_per_s / 1e12,
-        "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * steps_per_s / PEAK_F32_MFMA,
+        "train_step_live_flop": ALGO_FLOP_PER_STEP * rows / BATCH,
+        "train_step_algorithmic_tflops": ALGO_FLOP_PER_STEP * rows / BATCH * steps_per_s / 1e12,
+        "train_step_frac_of_f32_mfma_peak": ALGO_FLOP_PER_STEP * rows / BATCH * steps_per_s / PEAK_F32_MFMA,
+        "train_step_frac_of_f32_mfma_peak_dead_belief_elided": ALGO_FLOP_PER_STEP * rows / BATCH * steps_per_s_el / PEAK_F32_MFMA,
         "roofline": dominant,
         "roofline_second_kernel": second,
         "roofline_kernels": ov_entries if ov_entries else [entry(n, d) for n, d in ranked[:8]],

@@ -33,7 +33,9 @@ extern "C" {
 #define AID_E_UNSUPPORTED (-5)
 
 #define AID_MAX_BLOCKS 8
-#define AID_ABI_VERSION 1
+/* Bumped whenever an existing entry point changes its signature or a table struct its layout (additions do not bump it).
+ *   2: aid_value_step / aid_value_step_ex take `lam` as double (round 3; was float). */
+#define AID_ABI_VERSION 2
 
 int aid_version(void);
 const char* aid_last_error(void);

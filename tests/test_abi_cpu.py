@@ -34,7 +34,10 @@ def test_library_exports_every_declared_symbol(nat):
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     lib.aid_version.restype = C.c_int
-    assert lib.aid_version() == 1           # no GPU needed
+    hdr = open(os.path.join(ROOT, "include", "aid_hip.h")).read()
+    want = int(re.search(r"#define AID_ABI_VERSION (\d+)", hdr).group(1))
+    from aid_amd import _native
+    assert lib.aid_version() == want == _native.ABI_VERSION           # no GPU needed
     lib.aid_last_error.restype = C.c_char_p
     assert isinstance(lib.aid_last_error(), bytes)
 

@@ -39,3 +39,36 @@ def test_bench_under_an_external_launcher_keeps_working():
     assert json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])["n_gpus"] == 1
     r = _run(env, "--gpus", "2", "--steps", "2")       # inconsistent: refuse rather than silently mislabel the line
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+def _line(r):
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_eight_ranks_weak_and_strong_self_launched():
+    """The two curves the first 8-GPU lease must yield without a code change: weak (BASELINE configs[4]: 8 x 256 rows) and strong
+    (configs[1]'s 256-row batch split 8 ways), each with the ranks the communicator really had."""
+    out = _line(_run({}, "--gpus", "8", "--steps", "2", "--warmup", "1"))
+    assert out["n_gpus"] == 8 and out["scaling"] == "weak" and out["config"]["global_batch"] == 2048 and out["config"]["rows_per_rank"] == 256
+    assert out["data_parallel"]["rccl_ranks_seen"] == 8
+    out = _line(_run({}, "--gpus", "8", "--steps", "2", "--warmup", "1", "--scaling", "strong"))
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["config"]["global_batch"] == 256 and out["config"]["rows_per_rank"] == 32
+    assert out["data_parallel"]["rccl_ranks_seen"] == 8 and "global batch=256" in out["unit"]
+    r = _run({}, "--gpus", "3", "--steps", "1", "--scaling", "strong")          # 3 does not divide 256: refuse, every rank
+    assert r.returncode != 0 and "do not divide" in (r.stderr + r.stdout)
+
+
+def test_bench_eight_ranks_under_torch_distributed_run():
+    """The driver's launch form for N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py ..."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AID_BENCH_REHEARSAL="dry", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--scaling", "strong"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    out = _line(r)
+    assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["data_parallel"]["rccl_ranks_seen"] == 8 and out["config"]["rows_per_rank"] == 32

@@ -372,3 +372,45 @@ def test_concurrent_belief_loops_equal_the_merged_loop():
     small = [o[:64] for o in obs]
     assert not all(128 < o.shape[0] <= ai.CHAIN_MAX_ROWS for o in small)
     assert ai._chain_streams_for(4) is None
+
+
+@pytest.mark.parametrize("B", [8, 160])
+def test_dead_next_belief_elision_changes_nothing(B):
+    """state_agent.py:138-139 computes a next_obs belief that :195-196 overwrites before any read.  With `elide_dead_next_belief` the agent does
+    not run that reverse loop (it only consumes its draws): three back-to-back train_steps on one parity tape with the switch on and off -
+    unprefetched first step, prefetched steps with the look-ahead ELBO, merged loops (B = 8) and concurrent chains (B = 160) - give the same
+    metrics, the same post-step state_dict, the same normaliser / time-importance state, and the tape ends at the same position."""
+    O, A, D, N, H = 17, 6, 64, 4, 2
+    cap = 256
+    specs = param_specs(O, A, O, D, N)
+    p = draw_params(specs, 78, orc.schedule_tables(N))
+    bs = NoiseStream(10)
+    store = {"observations": bs.randn(cap, O), "actions": np.tanh(bs.randn(cap, A)).astype(np.float32), "rewards": bs.randn(cap),
+             "next_observations": bs.randn(cap, O), "dones": bs.rand(cap) < 0.1}
+    runs = {}
+    for elide in (False, True):
+        agent = _agent(O, A, D, N, H, B, cap=cap)
+        agent.elide_dead_next_belief = elide
+        ai = agent.active_inference
+        sd0 = ai.state_dict()
+        ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+        agent.replay_buffer.add_batch(store["observations"], store["actions"], store["rewards"], store["next_observations"], store["dones"])
+        pn = ParityNoise(555); ai.noise = pn; agent.replay_buffer.index_source = pn
+        ms = [agent.train_step() for _ in range(3)]
+        assert agent._prefetch is not None and agent._prefetch["latents"].shape[0] == (B if elide else 2 * B)
+        torch.cuda.synchronize()
+        runs[elide] = {"metrics": ms, "sd": {k: v.detach().cpu().clone() for k, v in ai.state_dict().items()},
+                       "rn": agent.reward_normalizer.state.cpu().clone(), "tiw": ai.time_importance_weights.cpu().clone(),
+                       "tape": float(pn.ns.randn(1, 1)[0, 0]), "last": {k: v.cpu().clone() for k, v in agent._last.items()}}
+    a, b = runs[False], runs[True]
+    assert a["tape"] == b["tape"]                       # both consumed exactly the reference's draws
+    for m0, m1 in zip(a["metrics"], b["metrics"]):
+        assert set(m0) == set(m1)
+        for k in m0:
+            np.testing.assert_allclose(m1[k], m0[k], rtol=1e-5, atol=1e-7, err_msg=k)
+    for k in a["sd"]:
+        np.testing.assert_allclose(b["sd"][k].numpy(), a["sd"][k].numpy(), rtol=1e-5, atol=1e-7, err_msg=k)
+    np.testing.assert_allclose(b["rn"].numpy(), a["rn"].numpy(), rtol=1e-12)
+    np.testing.assert_allclose(b["tiw"].numpy(), a["tiw"].numpy(), rtol=1e-5, atol=1e-7)
+    for k in a["last"]:
+        np.testing.assert_allclose(b["last"][k].numpy(), a["last"][k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)

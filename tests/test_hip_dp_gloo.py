@@ -168,3 +168,26 @@ def test_dp_prefetch_decisions_are_collective(scenario):
                 p.kill()
     for r, msg in res:
         assert msg == "ok", f"rank {r}:\n{msg}"
+
+
+def test_bench_strong_scaling_rehearsal_four_ranks_on_one_gpu():
+    """`bench.py --gpus 4 --scaling strong` end to end with the four ranks sharing cuda:0 over gloo (AID_BENCH_REHEARSAL=gloo): the launcher, the
+    256-row global batch split into 64-row shards, every data-parallel collective of the real train_step at that size, both timed regions
+    (dead next_obs belief executed / elided) and the JSON line with the ranks the communicator really had.  The number is not a result (one GPU)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(AID_BENCH_REHEARSAL="gloo", AID_BENCH_SKIP="phases,graphs", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--scaling", "strong", "--steps", "2", "--warmup", "2", "--no-extras",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == "strong" and out["config"]["global_batch"] == 256 and out["config"]["rows_per_rank"] == 64
+    dp = out["data_parallel"]
+    assert dp["rccl_ranks_seen"] == 4 and dp["backend"] == "gloo" and len(dp["per_rank_ms_per_step"]) == 4 and len(dp["per_rank_ms_per_step_dead_belief_elided"]) == 4
+    assert out["value"] > 0 and out["value_dead_belief_elided"] > 0 and "REHEARSAL" in out["data"]
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]          # strong: ONE global batch-256 step per step time

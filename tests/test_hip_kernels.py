@@ -597,32 +597,47 @@ def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):
     applies bias / activation / residual / accumulate.  Checked against fp64, for bit-identical repeats (the fold order is fixed whoever folds),
     for the profile naming the route (variant 24) and for the tile counters being back at zero (the same scratch serves every call)."""
     rng = np.random.default_rng(M + N + K)
-    A = rng.standard_normal((M, K)).astype(np.float32)
-    W = rng.standard_normal((K, N) if lay == "nn" else (N, K)).astype(np.float32) / np.sqrt(K)
-    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32); C0 = rng.standard_normal((M, N)).astype(np.float32)
-    ref = A.astype(np.float64) @ (W if lay == "nn" else W.T).astype(np.float64) + b
     f = {"none": lambda x: x, "silu": lambda x: x / (1 + np.exp(-x)), "gelu": lambda x: 0.5 * x * (1 + np.vectorize(__import__("math").erf)(x / np.sqrt(2)))}[act]
-    ref = f(ref) + R + (C0 if acc else 0)
     scratch = nat.gemm_scratch()
-    Ad, Wd, bd, Rd = dev(A), dev(W), dev(b), dev(R)
-    outs = []
-    nat.prof_enable(True); nat.prof_reset()
-    for _ in range(3):
+    b = rng.standard_normal(N).astype(np.float32); R = rng.standard_normal((M, N)).astype(np.float32); C0 = rng.standard_normal((M, N)).astype(np.float32)
+    bd, Rd = dev(b), dev(R)
+
+    def launch(Ad, Wd, scr=scratch):
         C = dev(C0.copy())
-        nat.gemm(Ad, Wd, C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc, scratch=scratch)
-        outs.append(C.cpu().numpy())
+        nat.gemm(Ad, Wd, C, M, N, K, K, Wd.shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc, scratch=scr)
+        return C
+    # A test that can FAIL on a stale or early slice read (the fold's hand-off across XCDs is ordered by sc1 accesses + vmcnt, not by the C++
+    # memory model): every launch gets NEW operands, so the slices a previous launch left in the scratch hold wrong values, and the whole
+    # scratch - slices and counters; the counters are zeroed again when the call opens its scope - is poisoned with NaN in between.
+    nat.prof_enable(True); nat.prof_reset()
+    outs, refs, ops = [], [], []
+    for i in range(3):
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        W = rng.standard_normal((K, N) if lay == "nn" else (N, K)).astype(np.float32) / np.sqrt(K)
+        ref = A.astype(np.float64) @ (W if lay == "nn" else W.T).astype(np.float64) + b
+        refs.append(f(ref) + R + (C0 if acc else 0))
+        ops.append((dev(A), dev(W)))
+        scratch.fill_(float("nan"))
+        outs.append(launch(*ops[-1]))
     torch.cuda.synchronize()
     nat.prof_dump(str(tmp_path / "prof.csv"))
     nat.prof_enable(False); nat.prof_reset()
     import csv
     recs = list(csv.DictReader(open(tmp_path / "prof.csv")))
-    np.testing.assert_allclose(outs[0], ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
-    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
     assert len(recs) == 3 and all(int(r["variant"]) == 24 for r in recs), recs
+    for o, ref in zip(outs, refs):
+        o = o.cpu().numpy()
+        assert np.isfinite(o).all()
+        np.testing.assert_allclose(o, ref, rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    # bit-identical repeats of the first problem, each on a freshly poisoned scratch and after other problems have used it (the fold order is
+    # fixed whoever folds); the tile counters are back at zero after every launch (the same scratch serves every call)
+    for _ in range(2):
+        scratch.fill_(float("nan"))
+        assert torch.equal(launch(*ops[0]), outs[0])
     # without scratch the dispatcher takes another kernel: same value to rounding
     C = dev(C0.copy())
-    nat.gemm(Ad, Wd, C, M, N, K, K, W.shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc)
-    np.testing.assert_allclose(C.cpu().numpy(), outs[0], rtol=2e-5, atol=2e-5 * np.sqrt(K))
+    nat.gemm(ops[0][0], ops[0][1], C, M, N, K, K, ops[0][1].shape[1], N, 0, 1 if lay == "nn" else 0, bias=bd, act=act, residual=Rd, ldr=N, accumulate=acc)
+    np.testing.assert_allclose(C.cpu().numpy(), outs[0].cpu().numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
 @pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2)])

@@ -53,7 +53,21 @@ def _prefetch_state_machine(rank):
     assert not ag._agreed["prefetch"] and not ag._want_prefetch(); same_everywhere(state())
     ag.prefetch_next_batch, ag.overlap_streams = True, rank == 0          # rank 1 runs single-stream: no look-ahead anywhere
     ag._take_prefetch(8)
-    assert ag._agreed == {"prefetch": True, "lookahead": False}
+    assert ag._agreed == {"prefetch": True, "lookahead": False, "vote": False, "ready": True}
+    # the schedule vote and the "replay shard still short of a minibatch" early return also gate collectives: both follow the agreed verdict.
+    # rank 1 has the vote pending but rank 0 has concurrent chains switched off -> nobody votes (no agree_max_float is issued: a mismatched
+    # collective here would hang this test); rank 0's buffer is short -> nobody steps
+    ag.overlap_streams = True
+    ag._dp_vote = {"phase": "warm", "n": 0, "t0": None, "ms": {}}
+    ag.concurrent_belief_loops = rank == 1
+    ag._take_prefetch(8, ready=True)
+    assert ag._agreed["vote"] is False and ag._agreed["ready"] is True
+    assert ag._dp_schedule_vote() == ag.concurrent_belief_loops and ag._dp_vote["n"] == 0        # untouched: the vote did not run
+    ag.concurrent_belief_loops = True
+    ag._take_prefetch(8, ready=rank == 1)
+    assert ag._agreed["vote"] is True and ag._agreed["ready"] is False
+    ag._take_prefetch(8, ready=True)
+    assert ag._agreed["ready"] is True and ag._dp_schedule_vote() is True and ag._dp_vote["n"] == 1    # both ranks advance the vote together
 
 
 def _worker(rank, world, port, q):

@@ -163,7 +163,7 @@ class DiffusionStateAgent(BaseActiveInferenceAgent):
                 N_, tr_ = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
                 n_obs = ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N_, tr_)
                 ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N_, tr_)          # the dead update's draws, consumed and dropped
-                both = ai.denoise_only(batch["observations"], noise=n_obs)
+                both = ai.denoise_only(batch["observations"], noise=n_obs, ws=ai._ws)      # ws given: the direct loop, as denoise_pair runs it
             else:
                 both = ai.denoise_pair(batch["observations"], batch["next_observations"])
         obs, actions, rewards = batch["observations"], batch["actions"], batch["rewards"]

@@ -680,9 +680,9 @@ def main():
     stats_name = "profiles/" + os.path.basename(stats_csv) if stats_csv else None
     try:
         import csv
-        rows = list(csv.DictReader(open(stats_csv)))
-        tot = sum(float(r["TotalDurationNs"]) for r in rows) or 1.0
-        for r in rows:
+        stat_rows = list(csv.DictReader(open(stats_csv)))
+        tot = sum(float(r["TotalDurationNs"]) for r in stat_rows) or 1.0
+        for r in stat_rows:
             nm = r["Name"].replace("void ", "").split("(")[0]
             share[nm] = {"share_of_kernel_time": float(r["TotalDurationNs"]) / tot, "calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3}
     except Exception:

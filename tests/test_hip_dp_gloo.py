@@ -71,7 +71,8 @@ def _scenario_worker(rank, world, port, q, scenario):
                 m = agent.train_step()
                 assert all(np.isfinite(v) for v in m.values()), (step, m)
             assert agent.dp_schedule_choice in ("chains", "merged") and agent._dp_vote is None
-            assert len(agent.active_inference.__dict__.get("_chain_graphs", {})) >= 3         # the chain arm ran from captured graphs
+            # the chain arm ran from captured graphs: one per live belief update of a step (two with the dead next_obs update elided, else three)
+            assert len(agent.active_inference.__dict__.get("_chain_graphs", {})) >= (2 if agent.elide_dead_next_belief else 3)
             choice = parallel.agree_min([agent.dp_schedule_choice == "chains"]) + parallel.agree_min([-(agent.dp_schedule_choice == "chains")])
             assert choice[0] == -choice[1]
         _replicas_identical(agent, rank)

@@ -369,6 +369,7 @@ static int launch_rowln_dbg(const RowLnArgs& g, hipStream_t s) {
 // reverse loop running underneath the step is 0.7 ms shorter (tools/perf/README.md).  Chosen per STREAM: aid_stream_hint bit 1, which the agent sets on its
 // main stream while the side stream is in use.  aid_rowln_debug(34 / 35) forces it on / off process-wide for A/B timing.
 static int g_rowln_bkt16 = -1;
+static int g_rowln_split1024 = 0;
 static inline bool rowln_bkt16(hipStream_t s) { return g_rowln_bkt16 >= 0 ? g_rowln_bkt16 != 0 : (stream_hint_flags(s) & 2) != 0; }
 template <int BN, int BKT, int ACT>
 static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
@@ -441,6 +442,12 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
     RowLnArgs g; memset(&g, 0, sizeof(g));
     g.A = x; g.lda = ldx; g.W = W; g.ldw = K; g.bias = b; g.gamma = gamma; g.beta = beta; g.add = add; g.ldadd = ldadd; g.mask = mask; g.ldmask = ldmask; g.Y = y; g.ldy = ldy;
     g.M = M; g.K = K; g.eps = 1e-5f;
+    if (N == 1024 && g_rowln_split1024 && linear_rows_ok(M, N, K, ACT_NONE, x, ldx, W, K) && ldy == N) {
+        // experiment (aid_rowln_debug(40)): the 1024-wide stage as two 512-column blocks of the plain full-row kernel (16-deep stages under the
+        // stream hint: 74 KB of LDS, shares its CU) + a separate LayerNorm / act / skip pass over the 1024-wide rows
+        AID_TRY(linear_rows(x, ldx, W, K, b, ACT_NONE, nullptr, 0, nullptr, 0, y, ldy, M, N, K, s));
+        return ln_act(y, ldy, gamma, beta, act, mask, y, ldy, nullptr, M, N, s, add);
+    }
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     prof.m = M; prof.n = N; prof.k = K; prof.variant = N == 1024 ? 20 : 21;
     const bool d16 = N == 512 && K % 16 == 0 && rowln_bkt16(s);
@@ -458,7 +465,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 }  // namespace aid
 
 using namespace aid;
-extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else if (mode == 34) g_rowln_bkt16 = 1; else if (mode == 35) g_rowln_bkt16 = 0; else if (mode == 36) g_rowln_bkt16 = -1; else g_rowln_dbg = mode; return AID_OK; }
+extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else if (mode == 34) g_rowln_bkt16 = 1; else if (mode == 35) g_rowln_bkt16 = 0; else if (mode == 36) g_rowln_bkt16 = -1; else if (mode == 40) g_rowln_split1024 = 1; else if (mode == 41) g_rowln_split1024 = 0; else g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                                  const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");

@@ -734,6 +734,26 @@ def gemm_mid(A, W, bias=None, act="none", residual=None, ksplit=1):
     return slab
 
 
+def gemm_w4(A, W, bias=None, act="none", ksplit=1):
+    """aid_gemm_w4 (<= 128 rows): ksplit == 1 -> C [M,N] = act(A W^T + bias); else raw K-slice slabs [ksplit, M, N]."""
+    M, K = A.shape; N = W.shape[0]
+    if ksplit == 1:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32)
+        check(lib().aid_gemm_w4(_ptr(A), A.stride(0), _ptr(W), W.stride(0), _ptr(bias), ACT[act], _ptr(out), N, None, M, N, K, 1, _stream()), "aid_gemm_w4")
+        return out
+    slab = torch.empty(ksplit, M, N, device=A.device, dtype=torch.float32)
+    check(lib().aid_gemm_w4(_ptr(A), A.stride(0), _ptr(W), W.stride(0), None, 0, None, 0, _ptr(slab), M, N, K, ksplit, _stream()), "aid_gemm_w4")
+    return slab
+
+
+def gemm_mid_afold(a_slabs, abias, act, W, ksplit):
+    """aid_gemm_mid_afold: slabs [ksplit, M, N] of act(abias + sum(a_slabs, 0)) W^T, the A operand folded in the loader (M <= 128, 4 input slabs)."""
+    nfold, M, K = a_slabs.shape; N = W.shape[0]
+    out = torch.empty(ksplit, M, N, device=W.device, dtype=torch.float32)
+    check(lib().aid_gemm_mid_afold(_ptr(a_slabs), nfold, _ptr(abias), ACT[act], _ptr(W), W.stride(0), _ptr(out), M, N, K, ksplit, _stream()), "aid_gemm_mid_afold")
+    return out
+
+
 def adaln_sum(res, slab, bias, mod, want_x=True):
     """aid_adaln_sum: x = res + bias + sum(slab, 0); y = LN(x) (1 + mod[:, :D]) + mod[:, D:] -> (x or None, y)"""
     M, D = res.shape

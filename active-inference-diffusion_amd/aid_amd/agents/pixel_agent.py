@@ -203,17 +203,41 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         ai.concurrent_belief_loops = self.overlap_streams       # one stream only when asked for one (profiling)
         batch = self.replay_buffer.sample(B)
         actions, rewards, dones = batch["actions"], batch["rewards"], batch["dones"]
-        enc_obs, ctx_a = self.encode_observation(batch["observations"], keep_for_backward=True, slot="a")
-        enc_next, ctx_b = self.encode_observation(batch["next_observations"], keep_for_backward=True, slot="b")
         dp = parallel.is_dp()
+        N, train = cfg.diffusion.num_diffusion_steps, ai.latent_score_network.training
+        # Schedule (results unchanged; draws are made in the reference's order: encoder pass a, encoder pass b, belief a, belief b, ELBO, EFE):
+        # the belief over obs needs encode(obs) only, the ELBO needs that belief only, and nothing before the value phase reads the belief over
+        # next_obs.  So chain a starts on a chain stream as soon as encode(obs) is enqueued and runs underneath encode(next_obs); chain b
+        # starts behind encode(next_obs) and runs underneath the ELBO, InfoNCE, the encoder backward passes and the policy phase.
+        self._mark("start")
+        obs_a = self._process_batch_observations(batch["observations"]); obs_b = self._process_batch_observations(batch["next_observations"])
+        n_a, n_b = self._encoder_noise(B), self._encoder_noise(B)
+        enc_obs, ctx_a = self.encoder(obs_a, n_a, keep_for_backward=True, slot="a")
+        # (data parallel: RCCL's own stream would be a fifth hardware queue next to main + side + two chain streams - aid_amd/streams.py - so the
+        # paired loop of the calling stream + one chain stream stays)
+        early = self.early_belief_chains and self.overlap_streams and not dp
+        nz_a = ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train) if early else None
+        h_a = ai.denoise_start(enc_obs, 0, nz_a) if early else None
+        self._mark("main: encode(obs) done")
+        enc_next, ctx_b = self.encoder(obs_b, n_b, keep_for_backward=True, slot="b")
+        self._mark("main: encode(next_obs) done")
         nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
-        both = ai.denoise_pair(enc_obs, enc_next)
-        latents, next_latents = both[:B], both[B:]
+        if h_a is not None:
+            nz_b = ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
+            h_b = ai.denoise_start(enc_next, 1, nz_b)
+            latents = ai.denoise_join(h_a)
+            next_latents = None if h_b is not None else ai.denoise_only(enc_next, noise=nz_b, ws=ai._ws)
+        else:
+            h_b = None
+            both = ai.denoise_pair(enc_obs, enc_next, nz_a, ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)) if nz_a is not None else ai.denoise_pair(enc_obs, enc_next)
+            latents, next_latents = both[:B], both[B:]
+        self._mark("main: belief over obs joined")
         # score / diffusion / encoder / feature-decoder group
         self.score_optimizer.zero_grad()
         elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents)
         d_next = torch.zeros_like(enc_next)
         contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
+        self._mark("main: ELBO + InfoNCE done")
         # The two encoder backward passes (36 ms at B=256) and the score / encoder / feature-decoder optimiser step depend only on the
         # feature gradients produced above; the policy, value and dynamics phases read none of those parameters.  They run on a side
         # stream underneath those phases (in data-parallel runs the gradient all-reduces ride on that stream too).
@@ -225,7 +249,9 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         with torch.cuda.stream(side):
             self.encoder.backward(ai._last_d_obs, ctx_a)
             self.encoder.backward(d_next, ctx_b)
+            self._mark("side: encoder backward x2 done", side)
             self.score_optimizer.step()
+            self._mark("side: score / encoder step done", side)
         if self.overlap_streams:
             for t_ in (ai._last_d_obs, d_next, enc_obs, enc_next):
                 t_.record_stream(side)
@@ -233,7 +259,11 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
         self.policy_optimizer.step()
+        self._mark("main: EFE + policy step done")
         # value (the pixel agent reuses next_latents, pixel_agent.py:364-371) and dynamics
+        if h_b is not None:
+            next_latents = ai.denoise_join(h_b)
+        self._mark("main: belief over next_obs joined")
         self.value_optimizer.zero_grad()
         nl_x, nrew_x, dones_x = parallel.halo_from_next_rank(next_latents, nrew, dones, rows=5) if dp else (next_latents, nrew, dones)
         value_loss, _ = nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, nl_x, nrew_x, dones_x,
@@ -242,6 +272,7 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         self.dynamics_optimizer.zero_grad()
         dyn_loss = nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
         self.dynamics_optimizer.step()
+        self._mark("main: value + dynamics done")
         if self.overlap_streams:
             main.wait_stream(side)        # the next encoder forward needs the updated encoder
         self.total_steps += 1
@@ -256,6 +287,13 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         return metrics
 
     overlap_streams = True    # False: every phase on the current stream, in order
+    timeline = None           # perf diagnostics (tools/perf/timeline_cfg4.py): a list to which train_step appends (label, event, host time)
+
+    def _mark(self, label, stream=None):
+        if self.timeline is not None:
+            import time as _t
+            ev = torch.cuda.Event(enable_timing=True); ev.record(stream or torch.cuda.current_stream()); self.timeline.append((label, ev, _t.perf_counter()))
+    early_belief_chains = True   # the two belief updates as separately started chains (see train_step); False: one merged / paired loop after both encoder passes
 
     def _comm_stream(self):
         if getattr(self, "_comm", None) is None:

@@ -297,7 +297,7 @@ class DiffusionActiveInference(nn.Module):
 
     # -- hipGraph replay of small-batch reverse loops (act(), the collector) ----------------------------------------------------
     graph_small_batches = True     # a 50-step loop is ~1 750 launches: below ~64 rows the host (5.4 us per launch) is the bottleneck
-    GRAPH_MAX_ROWS = 64
+    GRAPH_MAX_ROWS = 128
 
     def _graphed_denoise(self, observation: torch.Tensor) -> torch.Tensor:
         """The loop captured once per (rows, steps, train, parameter storage) and replayed: inputs live in persistent buffers, the
@@ -431,52 +431,96 @@ class DiffusionActiveInference(nn.Module):
             g = cache[key] = (graph, buf)
         return g
 
+    def _launch_chain(self, slot: int, o: torch.Tensor, nz, st, first, N: int, train: bool, w, off: int, graph) -> torch.Tensor:
+        """One belief update on stream `st` (already ordered behind `first`): hipGraph replay when `graph` = (graph, buffers), else direct launches."""
+        nz = nz or {}
+        with torch.cuda.stream(st):
+            if st is not first:
+                o.record_stream(st)
+                for v in nz.values():
+                    if torch.is_tensor(v): v.record_stream(st)
+            if graph is not None:
+                g, buf = graph
+                buf["obs"].copy_(o)
+                for k, name, kind in (("z_init", "z", 0), ("step_noise", "eps", 0), ("drop_masks", "mask", 1)):
+                    if buf[name] is None:
+                        continue
+                    if nz.get(k) is not None:
+                        buf[name].copy_(nz[k])
+                    elif kind == 0:
+                        nat.fill_normal(buf[name], self.noise.seed, self.noise.next_offset(buf[name].numel()))
+                    else:
+                        nat.fill_dropout_mask(buf[name], 0.1, self.noise.seed, self.noise.next_offset(buf[name].numel()))
+                g.replay()
+                out = buf["out"]
+            else:
+                out = nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), o, N, nz.get("z_init"), nz.get("step_noise"),
+                                       nz.get("drop_masks"), train=train, seed=self.noise.seed, offset=off, ws=w)
+        if st is not first:
+            out.record_stream(first)
+        return out
+
+    def _chain_graphs_for(self, rows_list, N, train, streams):
+        if not self.graph_belief_loops:
+            return None
+        try:
+            return [self._chain_graph(i, r, N, train, st) for i, (r, st) in enumerate(zip(rows_list, streams))]
+        except RuntimeError as e:          # capture refused (e.g. another capture in flight): same kernels, launched one by one
+            import warnings
+            warnings.warn(f"aid_amd: hipGraph capture of the belief-update loops failed ({e}); launching them directly from now on")
+            self.graph_belief_loops = False
+            return None
+
     def _denoise_chains(self, obs_list, noises, ws, N, train, streams) -> torch.Tensor:
         first = streams[0]
         wss = [ws or self._ws] + (getattr(self, "_chain_ws", None) or [])[:len(streams) - 1]
         obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
         offs = [self.noise.next_offset() for _ in obs_list]
-        graphs = None
-        if self.graph_belief_loops:
-            try:
-                graphs = [self._chain_graph(i, o.shape[0], N, train, st) for i, (o, st) in enumerate(zip(obs_list, streams))]
-            except RuntimeError as e:          # capture refused (e.g. another capture in flight): same kernels, launched one by one
-                import warnings
-                warnings.warn(f"aid_amd: hipGraph capture of the belief-update loops failed ({e}); launching them directly from now on")
-                self.graph_belief_loops = False
+        graphs = self._chain_graphs_for([o.shape[0] for o in obs_list], N, train, streams)
         for st in streams[1:]:
             st.wait_stream(first)
-        outs = []
-        for i, (o, nz, st, w, off) in enumerate(zip(obs_list, noises, streams, wss, offs)):
-            nz = nz or {}
-            with torch.cuda.stream(st):
-                if st is not first:
-                    o.record_stream(st)
-                    for v in nz.values():
-                        if torch.is_tensor(v): v.record_stream(st)
-                if graphs is not None:
-                    graph, buf = graphs[i]
-                    buf["obs"].copy_(o)
-                    for k, name, kind in (("z_init", "z", 0), ("step_noise", "eps", 0), ("drop_masks", "mask", 1)):
-                        if buf[name] is None:
-                            continue
-                        if nz.get(k) is not None:
-                            buf[name].copy_(nz[k])
-                        elif kind == 0:
-                            nat.fill_normal(buf[name], self.noise.seed, self.noise.next_offset(buf[name].numel()))
-                        else:
-                            nat.fill_dropout_mask(buf[name], 0.1, self.noise.seed, self.noise.next_offset(buf[name].numel()))
-                    graph.replay()
-                    out = buf["out"]
-                else:
-                    out = nat.denoise_loop(self.latent_score_network.table(), self.latent_diffusion.coefs(), o, N, nz.get("z_init"), nz.get("step_noise"),
-                                           nz.get("drop_masks"), train=train, seed=self.noise.seed, offset=off, ws=w)
-            if st is not first:
-                out.record_stream(first)
-            outs.append(out)
+        outs = [self._launch_chain(i, o, nz, st, first, N, train, w, off, graphs[i] if graphs is not None else None)
+                for i, (o, nz, st, w, off) in enumerate(zip(obs_list, noises, streams, wss, offs))]
         for st in streams[1:]:
             first.wait_stream(st)
         return torch.cat(outs, dim=0)
+
+    def denoise_start(self, observation: torch.Tensor, slot: int, noise: Optional[dict] = None):
+        """Start ONE belief update on the process's chain stream `slot` (0 or 1), ordered behind everything enqueued so far on the current stream,
+        and return a handle; `denoise_join(handle)` makes the current stream wait for it and returns the latents.  What the pixel agent uses to
+        run the belief over obs underneath encode(next_obs), and the belief over next_obs underneath the ELBO / InfoNCE / encoder backward
+        (agents/pixel_agent.py).  None when the chains cannot be had (row count outside (128, CHAIN_MAX_ROWS], concurrent loops switched off): the
+        caller then takes the merged loop."""
+        rows = observation.shape[0]
+        if not (self.concurrent_belief_loops and 128 < rows <= self.CHAIN_MAX_ROWS and slot in (0, 1)):
+            return None
+        first = torch.cuda.current_stream()
+        from ..streams import chain_streams
+        sts = chain_streams(first.device)
+        if any(st.cuda_stream == first.cuda_stream for st in sts):
+            return None
+        self._chain_streams_for(self.MAX_CHAINS)             # workspaces + stream hints of the chain streams (once)
+        st = sts[slot]
+        N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
+        observation = observation.to(self.device).float().contiguous()
+        if noise is None:
+            noise = self.noise.belief(rows, self.latent_dim, self.config.hidden_dim, N, train)
+        off = self.noise.next_offset()
+        graph = None
+        if self.graph_belief_loops:
+            try:
+                graph = self._chain_graph(slot, rows, N, train, st)
+            except RuntimeError as e:
+                import warnings
+                warnings.warn(f"aid_amd: hipGraph capture of the belief-update loops failed ({e}); launching them directly from now on")
+                self.graph_belief_loops = False
+        st.wait_stream(first)
+        out = self._launch_chain(slot, observation, noise, st, first, N, train, self._chain_ws[slot], off, graph)
+        return {"out": out, "stream": st}
+
+    def denoise_join(self, handle) -> torch.Tensor:
+        torch.cuda.current_stream().wait_stream(handle["stream"])
+        return handle["out"].clone()          # the chain's output buffer is reused by its next replay
 
     def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:
         """Two independent belief updates (state_agent.py:135-140) as one 2B-row loop.  Returns [2B, L] (rows of obs_a first)."""

@@ -48,6 +48,10 @@ struct MidArgs {
                                           //   into C: a split-K GEMM that is complete when the kernel ends, bit-reproducible (gemm_f32's route)
     int accumulate;                       // C += (act must be NONE; ksplit == 1 or folded)
     int M, N, K, ksplit, act;
+    // AFN > 0 instantiations: the A operand is itself a split-K result that nobody folded: A(m, k) = aact(abias[k] + sum_{y < AFN} A[y * astride + m * lda + k])
+    // (fixed slab order).  The <= 128-row reverse loop's x W1^T product is cut into K slices like the others and its bias + GELU + fold happen
+    // in the loader of the u W2^T product that reads it.
+    const float* abias; size_t astride; int aact;
 };
 
 constexpr int MID_BK = 64, MID_BN = 64;
@@ -67,7 +71,7 @@ template <int ACT> __device__ __forceinline__ float mid_act(float x) {
 // BKM: the W operand is contraction-major ([K][N], n contiguous): the data gradient dX = dY W reads the weight as stored, without a
 // transposed copy.  Its stage is kept in LDS as it arrives ([64][BN + 4]: 16-B writes) and fragments are gathered with four 4-B reads per
 // k-group (16 consecutive n at one k: conflict-free), in the shadow of the MFMAs.
-template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM, int AFN = 0, int AACT = ACT_NONE>
 __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int tiles_n) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT = 256, BM = 16 * BMF * WM, BN = 16 * NJ * WN, BK = MID_BK, CPR = BK / 4;
@@ -114,9 +118,38 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
     // (loaded a whole stage ago) is written to the other LDS buffer: a global load has 1.5 stages (~2 us) to arrive - the weights of a block
     // are cold every denoise step (56 MB stream through 32 MB of L2) and one wave per SIMD has nobody to hide a late load behind.  With one
     // workgroup per CU registers are free (122 + 40 of 512).  The loop is unrolled by two so both sets are named statically.
-    f32x4 rg0[NS], rg1[NS];
-    auto load_piece = [&](f32x4 (&rg)[NS], int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + (p < PA ? (size_t)kt * BK : (size_t)kt * wstep)); };
-    auto store_piece = [&](const f32x4 (&rg)[NS], int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
+    // (AFN > 0: an A piece is AFN slab loads + one bias load; they stay in registers until the piece is written to LDS a stage later, where
+    // they are added in slab order and the activation is applied - the loads are in flight for a whole stage like any other piece)
+    struct Regs { f32x4 v[NS]; f32x4 x[AFN > 0 ? PA * AFN : 1]; };
+    Regs rg0, rg1;
+    const float* asrc_bias[PA];
+    if constexpr (AFN > 0) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p) asrc_bias[p] = g.abias + kbeg + 4 * ((tid + NT * p) % CPR);
+    }
+    auto load_piece = [&](Regs& rg, int p, int kt) {
+        rg.v[p] = *reinterpret_cast<const f32x4*>(src[p] + (p < PA ? (size_t)kt * BK : (size_t)kt * wstep));
+        if constexpr (AFN > 0) {
+            if (p < PA) {
+#pragma unroll
+                for (int y = 1; y < AFN; ++y) rg.x[p * AFN + y - 1] = *reinterpret_cast<const f32x4*>(src[p] + (size_t)kt * BK + (size_t)y * g.astride);
+                rg.x[p * AFN + AFN - 1] = *reinterpret_cast<const f32x4*>(asrc_bias[p < PA ? p : 0] + (size_t)kt * BK);
+            }
+        }
+    };
+    auto store_piece = [&](const Regs& rg, int p, int buf) {
+        f32x4 v = rg.v[p];
+        if constexpr (AFN > 0) {
+            if (p < PA) {
+                v = rg.x[p * AFN + AFN - 1] + v;                                  // bias + slab 0
+#pragma unroll
+                for (int y = 1; y < AFN; ++y) v += rg.x[p * AFN + y - 1];        // + slab 1, 2, ... (fixed order)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = mid_act<AACT>(v[e]);       // (a template argument: a run-time switch inlines every activation's code into a two-stage kernel)
+            }
+        }
+        *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = v;
+    };
     constexpr int NG = BK / 16, MPG = 4 * BMF * NJ, NM = NG * MPG, S0 = NM / 2;
     constexpr int LSTEP = S0 / NS > 0 ? S0 / NS : 1, SSTEP = (NM - S0) / NS > 0 ? (NM - S0) / NS : 1;
     static_assert(S0 / NS >= 1, "more staging pieces than MFMA slots in half a stage");
@@ -136,7 +169,7 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
         }
     };
     // contract LDS buffer `cur`; first half: load tile `kt_load` into `ld`; second half: write `st` (the tile after this one) to buffer cur ^ 1
-    auto stage = [&](int cur, int kt_load, f32x4 (&ld)[NS], const f32x4 (&st)[NS]) {
+    auto stage = [&](int cur, int kt_load, Regs& ld, const Regs& st) {
         const float* a_s = As + cur * A_FL + (wm + r16) * BK;
         // (row & 15) == r16 for every fragment row of this lane: the swizzle term is lane-constant
         const float* b_s = BKM ? Bs + cur * B_FL + wn + r16 : Bs + cur * B_FL + (wn + r16) * BK;
@@ -274,6 +307,9 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
 
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n); }
+// 32-row tiles whose A operand is AFN unfolded K slices of the previous product (+ bias, activation): the u W2^T product of the <= 128-row loop
+template <int AFN, int AACT>
+__global__ void __launch_bounds__(256) gemm_mid_afold_kernel(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<1, 2, 2, 2, ACT_NONE, false, AFN, AACT>(g, tiles_m, tiles_n); }
 // The 32-row tile (129..256 rows: the three concurrent 256-row belief chains of a train_step) with its registers capped at 512 / 3: its
 // workgroup is 48 KB of LDS, so three fit a CU - but at the 184 VGPRs the compiler takes by itself only two waves fit a SIMD and the third
 // chain's workgroup waits for a slot (three chains overlapped 1.63x, exactly what two resident workgroups give).
@@ -315,10 +351,13 @@ static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
     }
 }
 
-bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
+bool gemm_mid_shape_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
     const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
-    return al && M > 128 && M <= MID_MAX_M && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
+    return al && M >= 1 && M <= MID_MAX_M && N >= 64 && ksplit >= 1 && K % (2 * MID_BK * ksplit) == 0 &&      // an even number of 64-deep stages per slice
            (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU || act == ACT_RELU);
+}
+bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
+    return M > 128 && gemm_mid_shape_ok(M, N, K, ksplit, act, A, lda, W, ldw);
 }
 
 // ksplit == 1: C = act(A W^T + bias) + residual (preact, optional: the value before the activation).  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T
@@ -327,7 +366,7 @@ bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int l
 // w_kmajor: W is [K][N] (row stride ldw) - the data-gradient form; needs N % 64 == 0.
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                 float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre, int dact, int* ctr, int accumulate) {
-    AID_REQUIRE(gemm_mid_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
+    AID_REQUIRE(gemm_mid_shape_ok(M, N, K, ksplit, act, A, lda, W, ldw), AID_E_SHAPE, "gemm_mid: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
     AID_REQUIRE(ksplit == 1 ? C != nullptr : (slab != nullptr && (ctr ? C != nullptr : (act == ACT_NONE && !residual && !preact && !accumulate))), AID_E_SHAPE,
                 "gemm_mid: split-K writes raw slabs unless tile counters are given");
     AID_REQUIRE(!accumulate || act == ACT_NONE, AID_E_SHAPE, "gemm_mid: accumulate with an activation");
@@ -347,9 +386,123 @@ int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
         default: return launch_mid_bm<ACT_NONE, false>(g, s);
     }
 }
+// slab_out[y] = A'[:, Ky] W[:, Ky]^T with A'(m, k) = aact(abias[k] + sum_{y < nfold} a_slabs[y][m][k]) (a_slabs: [nfold][M][K], the raw K slices of the
+// product that made A; fixed fold order).  M <= 128 (32-row tiles), nfold == 4.
+bool gemm_mid_afold_ok(int M, int N, int K, int ksplit, int nfold, const float* a_slabs, const float* abias, const float* W, int ldw) {
+    return M <= 128 && nfold == 4 && ksplit > 1 && ((((uintptr_t)abias) & 15) == 0) && gemm_mid_shape_ok(M, N, K, ksplit, ACT_NONE, a_slabs, K, W, ldw);
+}
+int gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
+                   hipStream_t s) {
+    AID_REQUIRE(gemm_mid_afold_ok(M, N, K, ksplit, nfold, a_slabs, abias, W, ldw) && slab_out, AID_E_SHAPE, "gemm_mid_afold: unsupported M=%d N=%d K=%d ksplit=%d nfold=%d",
+                M, N, K, ksplit, nfold);
+    MidArgs g; memset(&g, 0, sizeof(g));
+    g.A = a_slabs; g.lda = K; g.W = W; g.ldw = ldw; g.slab = slab_out; g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = ACT_NONE;
+    g.abias = abias; g.astride = (size_t)M * K; g.aact = aact;
+    ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)nfold * M * K + (double)N * K + (double)ksplit * M * N));
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 + 128; prof.variant = 22;
+    constexpr size_t lds = sizeof(float) * 2 * ((size_t)32 * MID_BK + (size_t)64 * MID_BK);
+    const int tiles_m = (M + 31) / 32, tiles_n = (N + 63) / 64;
+    switch (aact) {
+        case ACT_GELU: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_GELU>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
+        case ACT_SILU: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_SILU>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
+        case ACT_NONE: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_NONE>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
+        default: ::aid::set_error("gemm_mid_afold: activation %d (none, silu, gelu are built)", aact); return AID_E_SHAPE;
+    }
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
     return gemm_mid_ex(A, lda, W, ldw, 0, bias, act, residual, ldr, C, ldc, nullptr, slab, M, N, K, ksplit, s, nullptr, 0, nullptr, 0);
+}
+
+// ---- <= 128 rows: a 32 x 16 output tile per workgroup, its four waves a quarter of the K slice each ---------------------------------------
+// act() / collector batches and the 32-row shards of a strong-scaling run (reference: agents/state_agent.py:72-108, utils/async_collector.py:530-595).
+// At these row counts a layer is 0.03 - 0.13 GFLOP: nothing but the latency chain of its kernel matters, and that chain is shortest when there is
+// no pipeline at all: every lane requests ALL its operand fragments at once (KW / 16 float4 loads per 16-row / 16-column block, straight from
+// global memory into the registers v_mfma_f32_16x16x4_f32 reads - no LDS staging, no stage barriers), the wave runs its KW / 4 MFMAs per
+// block, the NW (four or eight) partial tiles meet in LDS and are added in wave order, and the epilogue (bias, activation) or the raw K-slice slab
+// is written once.  16-column tiles make N / 16 workgroups per row tile: 128 for the 2048-wide layer, 32 x ksplit for the 512-wide ones.
+// Fragment layout as in gemm_mid_body: a lane's float4 holds k = 16 g + 4 (lane >> 4) + {0..3} of row / column (lane & 15); MFMA j of group g
+// contracts element j of every lane - the same k permutation on both operands.
+template <int KW, int NW, int ACT>
+__global__ void __launch_bounds__(64 * NW) gemm_w4_kernel(MidArgs g, int tiles_m) {
+    constexpr int NG = KW / 16;
+    __shared__ __attribute__((aligned(16))) float red[NW][2][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x;
+    const int tm = b % tiles_m, rest = b / tiles_m, ky = rest % g.ksplit, tn = rest / g.ksplit;
+    const int m0 = tm * 32, n0 = tn * 16;
+    const int kbeg = ky * (g.K / g.ksplit) + wave * KW + 4 * kq;
+    const float* a0 = g.A + (size_t)min(m0 + r16, g.M - 1) * g.lda + kbeg;
+    const float* a1 = g.A + (size_t)min(m0 + 16 + r16, g.M - 1) * g.lda + kbeg;
+    const float* w0 = g.W + (size_t)min(n0 + r16, g.N - 1) * g.ldw + kbeg;
+    f32x4 av0[NG], av1[NG], bv[NG];
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) {
+        bv[gk] = *reinterpret_cast<const f32x4*>(w0 + 16 * gk);
+        av0[gk] = *reinterpret_cast<const f32x4*>(a0 + 16 * gk);
+        av1[gk] = *reinterpret_cast<const f32x4*>(a1 + 16 * gk);
+    }
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[gk][q], bv[gk][q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[gk][q], bv[gk][q], acc1, 0, 0, 0);
+        }
+    *reinterpret_cast<f32x4*>(&red[wave][0][lane][0]) = acc0;
+    *reinterpret_cast<f32x4*>(&red[wave][1][lane][0]) = acc1;
+    __syncthreads();
+    // 2 blocks x 64 lanes x 4 = 512 outputs over the first 256 threads, two each: (block i, lane l, element pair); C/D of 16x16x4: column = l & 15,
+    // row = 4 (l >> 4) + e
+    if (tid >= 256) return;
+    const int i = tid >> 7, l = (tid >> 1) & 63, e0 = 2 * (tid & 1);
+#pragma unroll
+    for (int e = e0; e < e0 + 2; ++e) {
+        float v = red[0][i][l][e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][i][l][e];                          // fixed order: wave 0, 1, 2, ...
+        const int row = m0 + 16 * i + 4 * (l >> 4) + e, col = n0 + (l & 15);
+        if (row < g.M && col < g.N) {
+            if (g.ksplit > 1) g.slab[((size_t)ky * g.M + row) * g.N + col] = v;
+            else g.C[(size_t)row * g.ldc + col] = mid_act<ACT>(v + (g.bias ? g.bias[col] : 0.f));
+        }
+    }
+}
+// waves per workgroup x K per wave for a K slice of `kper`: 64 per wave (12 loads in flight per lane) wherever four or eight waves cover the slice, else 128
+static inline bool w4_shape(int kper, int& nw, int& kw) {
+    if (kper == 512) { nw = 8; kw = 64; return true; }
+    if (kper == 256) { nw = 4; kw = 64; return true; }
+    if (kper == 1024) { nw = 8; kw = 128; return true; }
+    return false;
+}
+bool gemm_w4_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
+    const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
+    int nw, kw;
+    return al && M >= 1 && M <= 128 && N >= 16 && ksplit >= 1 && K % ksplit == 0 && w4_shape(K / ksplit, nw, kw) && (ksplit == 1 || act == ACT_NONE) &&
+           (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU);
+}
+// ksplit == 1: C = act(A W^T + bias);  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T (raw).  K / ksplit in {256, 512, 1024}.
+int gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
+            hipStream_t s) {
+    AID_REQUIRE(gemm_w4_ok(M, N, K, ksplit, act, A, lda, W, ldw) && (ksplit == 1 ? C != nullptr : slab != nullptr), AID_E_SHAPE,
+                "gemm_w4: unsupported M=%d N=%d K=%d ksplit=%d act=%d", M, N, K, ksplit, act);
+    MidArgs g; memset(&g, 0, sizeof(g));
+    g.A = A; g.lda = lda; g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.slab = slab; g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
+    ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)ksplit * M * N));
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = act; prof.variant = 26;
+    int nw = 0, kw = 0; w4_shape(K / ksplit, nw, kw);
+    const int tiles_m = (M + 31) / 32;
+    const dim3 grid(tiles_m * ((N + 15) / 16) * ksplit);
+#define AID_W4(KW_, NW_, ACT_) hipLaunchKernelGGL((gemm_w4_kernel<KW_, NW_, ACT_>), grid, dim3(64 * NW_), 0, s, g, tiles_m)
+#define AID_W4A(KW_, NW_) { if (act == ACT_GELU) AID_W4(KW_, NW_, ACT_GELU); else if (act == ACT_SILU) AID_W4(KW_, NW_, ACT_SILU); else AID_W4(KW_, NW_, ACT_NONE); }
+    if (kw == 64 && nw == 8) AID_W4A(64, 8) else if (kw == 64) AID_W4A(64, 4) else AID_W4A(128, 8)
+#undef AID_W4A
+#undef AID_W4
+    AID_LAUNCH_CHECK();
+    return AID_OK;
 }
 
 // ---- consumers of the split-K slabs ---------------------------------------------------------------------------------------------
@@ -415,44 +568,9 @@ __global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const
 template <int NV>
 __global__ void adaln_lp_kernel(const float* __restrict__ z, int L, const float* __restrict__ Wt, const float* __restrict__ blp,
                                 const float* __restrict__ mod, int ldmod, float* __restrict__ xout, int ldxo, float* __restrict__ y, int ldy, int M) {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    constexpr int D = 256 * NV;
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
-    const f4* sh = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod + D);
-    f4 v[NV], a[NV], b[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { v[i] = reinterpret_cast<const f4*>(blp)[lane + 64 * i]; a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i]; }
-    const float* zr = z + (size_t)row * L;
-    for (int k = 0; k < L; ++k) {
-        const float zk = zr[k];
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const f4 w = reinterpret_cast<const f4*>(Wt + (size_t)k * D)[lane + 64 * i];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[i][j] = fmaf(zk, w[j], v[i][j]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) reinterpret_cast<f4*>(xout + (size_t)row * ldxo)[lane + 64 * i] = v[i];
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
-    const float mean = wave_sum(s) / (float)D;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        f4 o;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + b[i][j];
-        reinterpret_cast<f4*>(y + (size_t)row * ldy)[lane + 64 * i] = o;
-    }
+    adaln_lp_row<NV>(z + (size_t)row * L, L, Wt, blp, mod + (size_t)row * ldmod, xout + (size_t)row * ldxo, y + (size_t)row * ldy, lane);
 }
 __global__ void transpose_small_kernel(const float* __restrict__ W /*[R][C]*/, float* __restrict__ Wt /*[C][R]*/, int R, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -480,63 +598,73 @@ template <int KV, int NSLAB>
 __global__ void __launch_bounds__(256) head2_slab_p_sample_kernel(const float* __restrict__ slab, size_t slab_stride, const float* __restrict__ b0,
                                                                   const float* __restrict__ W2, int Kp, const float* __restrict__ mult, float tv, int cont,
                                                                   const float* __restrict__ coef, int step, const float* __restrict__ z,
-                                                                  const float* __restrict__ eps, float* __restrict__ zo, float* __restrict__ traj, int M, int L) {
+                                                                  const float* __restrict__ eps, float* __restrict__ zo, float* __restrict__ traj, int M, int L,
+                                                                  NextLp nx) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;                                  // no barrier below
-    f4 pv[KV], sl[NSLAB][KV];
+    __shared__ float zs[4][128];                            // the new z rows of this block's four waves, for the optional next-step tail
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
+    const bool live = row < M;
+    if (live) {
+        f4 pv[KV], sl[NSLAB][KV];
 #pragma unroll
-    for (int j = 0; j < KV; ++j) pv[j] = reinterpret_cast<const f4*>(b0)[lane + 64 * j];
+        for (int j = 0; j < KV; ++j) pv[j] = reinterpret_cast<const f4*>(b0)[lane + 64 * j];
 #pragma unroll
-    for (int y0 = 0; y0 < NSLAB; ++y0)
+        for (int y0 = 0; y0 < NSLAB; ++y0)
 #pragma unroll
-        for (int j = 0; j < KV; ++j) sl[y0][j] = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * Kp)[lane + 64 * j];
+            for (int j = 0; j < KV; ++j) sl[y0][j] = reinterpret_cast<const f4*>(slab + (size_t)y0 * slab_stride + (size_t)row * Kp)[lane + 64 * j];
 #pragma unroll
-    for (int j = 0; j < KV; ++j) {
+        for (int j = 0; j < KV; ++j) {
 #pragma unroll
-        for (int y0 = 0; y0 < NSLAB; ++y0) pv[j] += sl[y0][j];
+            for (int y0 = 0; y0 < NSLAB; ++y0) pv[j] += sl[y0][j];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pv[j][e] = act_apply(pv[j][e], ACT_SILU);
-    }
-    for (int l0 = 0; l0 < L; l0 += 8) {
-        float acc[8];
+            for (int e = 0; e < 4; ++e) pv[j][e] = act_apply(pv[j][e], ACT_SILU);
+        }
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            float acc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f4* w = reinterpret_cast<const f4*>(W2 + (size_t)min(l0 + q, L - 1) * Kp);
-            float a = 0.f;
+            for (int q = 0; q < 8; ++q) {
+                const f4* w = reinterpret_cast<const f4*>(W2 + (size_t)min(l0 + q, L - 1) * Kp);
+                float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < KV; ++j) {
-                const f4 wv = w[lane + 64 * j];
-                a = fmaf(pv[j][0], wv[0], a); a = fmaf(pv[j][1], wv[1], a); a = fmaf(pv[j][2], wv[2], a); a = fmaf(pv[j][3], wv[3], a);
+                for (int j = 0; j < KV; ++j) {
+                    const f4 wv4 = w[lane + 64 * j];
+                    a = fmaf(pv[j][0], wv4[0], a); a = fmaf(pv[j][1], wv4[1], a); a = fmaf(pv[j][2], wv4[2], a); a = fmaf(pv[j][3], wv4[3], a);
+                }
+                acc[q] = a;
             }
-            acc[q] = a;
-        }
-        const float mine = fold8(acc, lane);
-        const int l = l0 + (lane >> 3);
-        if ((lane & 7) == 0 && l < L) {
-            const size_t i = (size_t)row * L + l;
-            float scv = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
-            if (cont) scv *= sqrtf(1.0f / (1e-5f + tv));
-            const float zt = z[i];
-            const float z0 = (zt + coef[0] * scv) * coef[1];
-            float v = coef[2] * z0 + coef[3] * zt;
-            if (step > 0) v += coef[4] * eps[i];
-            zo[i] = v;
-            if (traj) traj[i] = v;
+            const float mine = fold8(acc, lane);
+            const int l = l0 + (lane >> 3);
+            if ((lane & 7) == 0 && l < L) {
+                const size_t i = (size_t)row * L + l;
+                float scv = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
+                if (cont) scv *= sqrtf(1.0f / (1e-5f + tv));
+                const float zt = z[i];
+                const float z0 = (zt + coef[0] * scv) * coef[1];
+                float v = coef[2] * z0 + coef[3] * zt;
+                if (step > 0) v += coef[4] * eps[i];
+                zo[i] = v;
+                if (traj) traj[i] = v;
+                zs[wv][l] = v;
+            }
         }
     }
+    if (nx.Wt == nullptr) return;                           // uniform over the grid
+    __syncthreads();
+    if (live) adaln_lp_row<2 * KV>(zs[wv], L, nx.Wt, nx.blp, nx.mod + (size_t)row * nx.ldmod, nx.xout + (size_t)row * nx.ldxo, nx.y + (size_t)row * nx.ldy, lane);
 }
 bool head2_slab_ok(int Kp, int nslab, const float* slab, const float* b0, const float* W2) {
     return (Kp == 256 || Kp == 512) && nslab == 4 && ((((uintptr_t)slab | (uintptr_t)b0 | (uintptr_t)W2) & 15) == 0);
 }
 int head2_slab_p_sample(const float* slab, int nslab, const float* b0, const float* W2, int Kp, const float* mult, float t_value, int continuous,
-                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s) {
+                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s, const NextLp* next) {
     AID_REQUIRE(head2_slab_ok(Kp, nslab, slab, b0, W2) && L >= 1 && L <= 128, AID_E_SHAPE, "head2_slab_p_sample: Kp=%d nslab=%d L=%d", Kp, nslab, L);
+    NextLp nx; memset(&nx, 0, sizeof(nx));
+    if (next) { nx = *next; AID_REQUIRE(head2_next_ok(Kp, L, nx), AID_E_SHAPE, "head2_slab_p_sample: next-step tail unsupported (Kp=%d D=%d)", Kp, nx.D); }
     const size_t stride = (size_t)M * Kp;
     if (Kp == 256) hipLaunchKernelGGL((head2_slab_p_sample_kernel<1, 4>), dim3((M + 3) / 4), dim3(256), 0, s, slab, stride, b0, W2, Kp, mult, t_value, continuous,
-                                      coef, step, z, eps, z_out, traj_out, M, L);
+                                      coef, step, z, eps, z_out, traj_out, M, L, nx);
     else hipLaunchKernelGGL((head2_slab_p_sample_kernel<2, 4>), dim3((M + 3) / 4), dim3(256), 0, s, slab, stride, b0, W2, Kp, mult, t_value, continuous,
-                            coef, step, z, eps, z_out, traj_out, M, L);
+                            coef, step, z, eps, z_out, traj_out, M, L, nx);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -555,7 +683,9 @@ static int launch_adaln_sum(const float* res, int ldres, const float* slab, int 
         case 1: hipLaunchKernelGGL((adaln_sum_kernel<NV, 1>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
         case 2: hipLaunchKernelGGL((adaln_sum_kernel<NV, 2>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
         case 4: hipLaunchKernelGGL((adaln_sum_kernel<NV, 4>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
-        default: ::aid::set_error("adaln_sum: %d slabs (0, 1, 2 or 4 are built)", nslab); return AID_E_SHAPE;
+        case 8: hipLaunchKernelGGL((adaln_sum_kernel<NV, 8>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        case 16: hipLaunchKernelGGL((adaln_sum_kernel<NV, 16>), grid, dim3(256), 0, s, res, ldres, slab, stride, bias, mod, ldmod, xout, ldxo, y, ldy, M); break;
+        default: ::aid::set_error("adaln_sum: %d slabs (0, 1, 2, 4, 8 or 16 are built)", nslab); return AID_E_SHAPE;
     }
     AID_LAUNCH_CHECK();
     return AID_OK;
@@ -578,6 +708,16 @@ int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* 
                  float* slab, int M, int N, int K, int ksplit, void* stream) {
     AID_REQUIRE(A && W, AID_E_NULL, "aid_gemm_mid: null operand");
     return gemm_mid(A, lda, W, ldw, bias, act, residual, ldr, C, ldc, slab, M, N, K, ksplit, (hipStream_t)stream);
+}
+int aid_gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
+                void* stream) {
+    AID_REQUIRE(A && W, AID_E_NULL, "aid_gemm_w4: null operand");
+    return gemm_w4(A, lda, W, ldw, bias, act, C, ldc, slab, M, N, K, ksplit, (hipStream_t)stream);
+}
+int aid_gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
+                       void* stream) {
+    AID_REQUIRE(a_slabs && abias && W && slab_out, AID_E_NULL, "aid_gemm_mid_afold: null operand");
+    return gemm_mid_afold(a_slabs, nfold, abias, aact, W, ldw, slab_out, M, N, K, ksplit, (hipStream_t)stream);
 }
 int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
                   float* y, int ldy, int M, int D, void* stream) {

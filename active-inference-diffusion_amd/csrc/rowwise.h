@@ -41,10 +41,68 @@ int affine1(const float* t, float a, float b, float* out, int M, hipStream_t s);
 // score = clamp(raw,-10,10) * mult * (continuous ? sqrt(1/(1e-5+t)) : 1)     (score_networks.py:166-170)
 int score_head(const float* raw, const float* mult, const float* t, int mode, float* score, int M, int L, hipStream_t s);
 
+// Optional tail of the reverse-step kernels: block 0's adaLN of the NEXT denoise step with the latent projection folded in (what adaln_lp does as a
+// launch of its own), applied to the z row the kernel has just produced - the row is all the next step's first kernel needs, so the two are one launch.
+// Wt == nullptr: no tail.  mod = the next step's modulation row block.
+struct NextLp { const float* Wt; const float* blp; const float* mod; int ldmod; float* xout; int ldxo; float* y; int ldy; int D; };
+#if defined(__HIPCC__)
+// x = z W_lp^T + b_lp (Wt = W_lp^T, [L][D]); y = LN(x) (1 + scale) + shift; one wave per row, D = 256 NV.  `zr`: the row's L values (global or LDS).
+// The K loop runs in chunks of 8: the 8 z values and 8 NV weight float4s of a chunk are requested together (a K = 17 row was 17 dependent load
+// round trips before: 7.5 us of a ~250 us denoise step).
+template <int NV>
+__device__ __forceinline__ void adaln_lp_row(const float* zr, int L, const float* __restrict__ Wt, const float* __restrict__ blp, const float* __restrict__ modrow,
+                                             float* __restrict__ xrow, float* __restrict__ yrow, int lane) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    constexpr int D = 256 * NV;
+    const f4* sc = reinterpret_cast<const f4*>(modrow);
+    const f4* sh = reinterpret_cast<const f4*>(modrow + D);
+    f4 v[NV], a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { v[i] = reinterpret_cast<const f4*>(blp)[lane + 64 * i]; a[i] = sc[lane + 64 * i]; b[i] = sh[lane + 64 * i]; }
+    for (int k0 = 0; k0 < L; k0 += 8) {
+        float zk[8]; f4 w[8][NV];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = min(k0 + q, L - 1);
+            zk[q] = k0 + q < L ? zr[k] : 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) w[q][i] = reinterpret_cast<const f4*>(Wt + (size_t)k * D)[lane + 64 * i];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q)                      // k ascending, as before: the sum order is unchanged
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[i][j] = k0 + q < L ? fmaf(zk[q], w[q][i][j], v[i][j]) : v[i][j];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) reinterpret_cast<f4*>(xrow)[lane + 64 * i] = v[i];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    const float mean = wave_sum(s) / (float)D;
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q2 += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)D + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        f4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + b[i][j];
+        reinterpret_cast<f4*>(yrow)[lane + 64 * i] = o;
+    }
+}
+#endif
+
 // fused head + p_sample (diffusion.py:208-255) for one reverse step; coef = coefs + 5*step (device)
 //   s = clamp(raw)*mult*tw ; z0 = (z + c0*s)*c1 ; mean = c2*z0 + c3*z ; z' = mean + (step>0 ? c4*eps : 0)
 int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const float* mult, float t_value, int continuous, const float* coef,
-                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s);
+                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s,
+                   const NextLp* next = nullptr);
+bool head2_next_ok(int Kp, int L, const NextLp& nx);      // can the reverse-step kernels take this tail? (D == 2 Kp in {512, 1024}, L <= 128, alignment)
 int head_p_sample(const float* raw, const float* mult, float t_value, int continuous, const float* coef, int step,
                   const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
 
@@ -53,13 +111,26 @@ int head_p_sample(const float* raw, const float* mult, float t_value, int contin
 constexpr int MID_MAX_M = 8192;
 // K slices for the 512-wide products of a DiT block at M rows: enough (column tile, slice) pairs for ~one workgroup per CU
 inline int mid_ksplit(int M) { return M <= 1024 ? 4 : (M <= 2048 ? 2 : 1); }
-bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
+// <= 128 rows (act() / collector batches, 32-row shards of a strong-scaling run): one to four 32-row tiles x 64-column tiles is far too few
+// workgroups, so K is cut into 128-deep slices (two 64-deep stages, the kernel's minimum), at most 16: a 512-wide product of a DiT block is
+// 8 column tiles x 4 (K = 512) or x 16 (K = 2048) slices per row tile
+inline int mid_ksplit_small(int K) { const int ks = K / 128; return ks > 16 ? 16 : (ks < 1 ? 1 : ks); }
+bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);           // 129..MID_MAX_M rows
+bool gemm_mid_shape_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);     // any M >= 1 (the small-batch loop)
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s);
 // general form: w_kmajor = W stored [K][N] (the data gradient dX = dY W of a Linear: the weight as it is), preact = optional second output
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                 float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre = nullptr, int dact = 0, int* ctr = nullptr,
                 int accumulate = 0);      // ctr: fold the K slices in the kernel (one zeroed int per output tile) and run the full epilogue into C
+// the product whose A operand is the unfolded K slices of the previous product (see gemm_mid.hip): slab_out[y] = act(abias + sum a_slabs)[:, Ky] W[:, Ky]^T
+bool gemm_mid_afold_ok(int M, int N, int K, int ksplit, int nfold, const float* a_slabs, const float* abias, const float* W, int ldw);
+int gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
+                   hipStream_t s);
+// <= 128 rows: 32 x 16 tiles, four waves a quarter of the K slice each, operands straight into registers (gemm_mid.hip)
+bool gemm_w4_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
+int gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
+            hipStream_t s);
 // x_new = res + bias + sum of `nslab` slabs [M,D] (fixed order) -> xout (optional);  y = LN(x_new) (1 + scale) + shift (adaLN, mod row = [scale | shift])
 bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
                   const float* y, int ldy);
@@ -72,7 +143,8 @@ int adaln_lp(const float* z, int L, const float* Wt, const float* blp, const flo
              hipStream_t s);
 bool head2_slab_ok(int Kp, int nslab, const float* slab, const float* b0, const float* W2);
 int head2_slab_p_sample(const float* slab, int nslab, const float* b0, const float* W2, int Kp, const float* mult, float t_value, int continuous,
-                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s);
+                        const float* coef, int step, const float* z, const float* eps, float* z_out, float* traj_out, int M, int L, hipStream_t s,
+                        const NextLp* next = nullptr);
 
 int fill_const(float* p, float v, size_t n, hipStream_t s);
 int mul_elem(const float* a, const float* b, float* out, size_t n, hipStream_t s);

@@ -443,52 +443,68 @@ __global__ void __launch_bounds__(256) head2_p_sample_wave_kernel(const float* _
                                                                   const float* __restrict__ mult, float tv, int cont, const float* __restrict__ coef,
                                                                   int step, const float* __restrict__ z, const float* __restrict__ eps,
                                                                   float* __restrict__ zo, float* __restrict__ traj, float* __restrict__ raw_out,
-                                                                  int M, int L) {
+                                                                  int M, int L, NextLp nx) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;                                  // no barrier below
-    f4 pv[KV];
+    __shared__ float zs[4][128];                            // the new z rows of this block's four waves, for the optional next-step tail
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
+    const bool live = row < M;
+    if (live) {
+        f4 pv[KV];
 #pragma unroll
-    for (int j = 0; j < KV; ++j) pv[j] = reinterpret_cast<const f4*>(p0 + (size_t)row * ldp)[lane + 64 * j];
-    for (int l0 = 0; l0 < L; l0 += 8) {
-        float acc[8];
+        for (int j = 0; j < KV; ++j) pv[j] = reinterpret_cast<const f4*>(p0 + (size_t)row * ldp)[lane + 64 * j];
+        for (int l0 = 0; l0 < L; l0 += 8) {
+            float acc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const f4* w = reinterpret_cast<const f4*>(W2 + (size_t)min(l0 + q, L - 1) * Kp);
-            float a = 0.f;
+            for (int q = 0; q < 8; ++q) {
+                const f4* w = reinterpret_cast<const f4*>(W2 + (size_t)min(l0 + q, L - 1) * Kp);
+                float a = 0.f;
 #pragma unroll
-            for (int j = 0; j < KV; ++j) {
-                const f4 wv = w[lane + 64 * j];
-                a = fmaf(pv[j][0], wv[0], a); a = fmaf(pv[j][1], wv[1], a); a = fmaf(pv[j][2], wv[2], a); a = fmaf(pv[j][3], wv[3], a);
+                for (int j = 0; j < KV; ++j) {
+                    const f4 wv4 = w[lane + 64 * j];
+                    a = fmaf(pv[j][0], wv4[0], a); a = fmaf(pv[j][1], wv4[1], a); a = fmaf(pv[j][2], wv4[2], a); a = fmaf(pv[j][3], wv4[3], a);
+                }
+                acc[q] = a;
             }
-            acc[q] = a;
-        }
-        const float mine = fold8(acc, lane);
-        const int l = l0 + (lane >> 3);
-        if ((lane & 7) == 0 && l < L) {
-            const size_t i = (size_t)row * L + l;
-            if (raw_out) raw_out[i] = mine;
-            float sc = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
-            if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
-            const float zt = z[i];
-            const float z0 = (zt + coef[0] * sc) * coef[1];
-            float v = coef[2] * z0 + coef[3] * zt;
-            if (step > 0) v += coef[4] * eps[i];
-            zo[i] = v;
-            if (traj) traj[i] = v;
+            const float mine = fold8(acc, lane);
+            const int l = l0 + (lane >> 3);
+            if ((lane & 7) == 0 && l < L) {
+                const size_t i = (size_t)row * L + l;
+                if (raw_out) raw_out[i] = mine;
+                float sc = fminf(fmaxf(mine, -10.f), 10.f) * mult[0];
+                if (cont) sc *= sqrtf(1.0f / (1e-5f + tv));
+                const float zt = z[i];
+                const float z0 = (zt + coef[0] * sc) * coef[1];
+                float v = coef[2] * z0 + coef[3] * zt;
+                if (step > 0) v += coef[4] * eps[i];
+                zo[i] = v;
+                if (traj) traj[i] = v;
+                zs[wv][l] = v;
+            }
         }
     }
+    if (nx.Wt == nullptr) return;                           // uniform over the grid
+    __syncthreads();
+    if (live) adaln_lp_row<2 * KV>(zs[wv], L, nx.Wt, nx.blp, nx.mod + (size_t)row * nx.ldmod, nx.xout + (size_t)row * nx.ldxo, nx.y + (size_t)row * nx.ldy, lane);
+}
+bool head2_next_ok(int Kp, int L, const NextLp& nx) {
+    return (Kp == 256 || Kp == 512) && nx.D == 2 * Kp && L <= 128 && nx.Wt && nx.blp && nx.mod && nx.xout && nx.y &&
+           ((((uintptr_t)nx.Wt | (uintptr_t)nx.blp | (uintptr_t)nx.mod | (uintptr_t)nx.xout | (uintptr_t)nx.y) & 15) == 0) && nx.ldmod % 4 == 0 && nx.ldxo % 4 == 0 &&
+           nx.ldy % 4 == 0;
 }
 int head2_p_sample(const float* p0, int ldp, const float* W2, int Kp, const float* mult, float t_value, int continuous, const float* coef,
-                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s) {
+                   int step, const float* z, const float* eps, float* z_out, float* traj_out, float* raw_out, int M, int L, hipStream_t s, const NextLp* next) {
     AID_REQUIRE(L >= 1 && L <= 128, AID_E_SHAPE, "head2_p_sample: latent_dim %d outside [1, 128]", L);
+    NextLp nx; memset(&nx, 0, sizeof(nx));
+    if (next) nx = *next;
     if ((Kp == 256 || Kp == 512) && ldp % 4 == 0 && ((((uintptr_t)p0 | (uintptr_t)W2) & 15) == 0)) {
+        AID_REQUIRE(!next || head2_next_ok(Kp, L, nx), AID_E_SHAPE, "head2_p_sample: next-step tail unsupported (Kp=%d D=%d)", Kp, nx.D);
         if (Kp == 256) hipLaunchKernelGGL(head2_p_sample_wave_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, p0, ldp, W2, Kp, mult, t_value, continuous, coef,
-                                          step, z, eps, z_out, traj_out, raw_out, M, L);
+                                          step, z, eps, z_out, traj_out, raw_out, M, L, nx);
         else hipLaunchKernelGGL(head2_p_sample_wave_kernel<2>, dim3((M + 3) / 4), dim3(256), 0, s, p0, ldp, W2, Kp, mult, t_value, continuous, coef,
-                                step, z, eps, z_out, traj_out, raw_out, M, L);
+                                step, z, eps, z_out, traj_out, raw_out, M, L, nx);
         AID_LAUNCH_CHECK(); return AID_OK;
     }
+    AID_REQUIRE(!next, AID_E_SHAPE, "head2_p_sample: the next-step tail needs the wave kernel (Kp=%d)", Kp);
     const size_t lds = sizeof(float) * ((size_t)L * (H2_KC + 1) + (size_t)H2_ROWS * (H2_KC + 1));
     static bool attr_done = false;
     if (lds > 65536 && !attr_done) {

@@ -137,20 +137,28 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
 // arithmetic as score_trunk below; what changes is the work decomposition: every GEMM is exactly one workgroup per CU (gemm_mid), the two
 // 512-wide products of a block are split four ways over K into raw slabs, and the adaLN that follows them - it reads the residual stream
 // anyway - adds the slabs, the bias and the residual in a fixed order (adaln_sum).  36 launches per step as before, each about half as long.
+// K slices of the D-deep (x Wov^T) and the 4D-deep (u W2^T) product of a block at B rows
+static inline int trunk_ks_d(const AidScoreNet& n, int B) { return B > 128 ? mid_ksplit(B) : mid_ksplit_small(n.D); }
+static inline int trunk_ks_4d(const AidScoreNet& n, int B) { return B > 128 ? mid_ksplit(B) : mid_ksplit_small(4 * n.D); }
+static int g_fuse_next_lp = 1;    // aid_denoise_debug(-5 / -6): the next step's adaLN + latent projection as the tail of the reverse-step kernel, on / off
+// the <= 128-row loop: 1 = gemm_w4 pipeline (score_trunk_small); 0 = weight-streaming skinny / panel kernels (score_trunk); 2 / 3 = score_trunk_mid's
+// 32-row tiles with 128-deep K slices, x W1^T unsplit / split with the fold in the next product's loader.  aid_denoise_debug(-1 / -2 / -3 / -4): A/B timing
+// (tools/perf/small_batch_ab.py)
+static int g_mid_small = 1;
 static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const ScoreFused* f) {
     const int D = n.D;
     if (!f || !f->slab || n.n_blocks < 1) return false;
     const ScoreBlockActs& b = a.blk[0];
-    const int KS = mid_ksplit(B);
-    return gemm_mid_ok(B, D, D, KS, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
-           gemm_mid_ok(B, D, 4 * D, KS, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
+    const int KS = trunk_ks_d(n, B), KS4 = trunk_ks_4d(n, B);
+    return gemm_mid_shape_ok(B, D, D, KS, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_shape_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
+           gemm_mid_shape_ok(B, D, 4 * D, KS4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
 static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
-    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = mid_ksplit(B), KSH = 4;
-    // the raw product of a 512-wide layer: KS slabs (KS == 1: the one "slab" is the kernel's ordinary output, no bias / activation)
-    auto product = [&](const float* x, int ldx, const float* W, int K) {
-        return gemm_mid(x, ldx, W, K, nullptr, ACT_NONE, nullptr, 0, KS == 1 ? f.slab : nullptr, D, KS == 1 ? nullptr : f.slab, B, D, K, KS, s);
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = trunk_ks_d(n, B), KS4 = trunk_ks_4d(n, B), KSH = 4;
+    // the raw product of a 512-wide layer: `ks` slabs (ks == 1: the one "slab" is the kernel's ordinary output, no bias / activation)
+    auto product = [&](const float* x, int ldx, const float* W, int K, int ks) {
+        return gemm_mid(x, ldx, W, K, nullptr, ACT_NONE, nullptr, 0, ks == 1 ? f.slab : nullptr, D, ks == 1 ? nullptr : f.slab, B, D, K, ks, s);
     };
     // (the folded form walks K = latent_dim one k at a time, a wave per row: 7.7 us at L = 17, 36 us at the pixel agents' L = 128, where the
     //  projection is a GEMM again: a 512 x 512 x 128 product + the plain adaLN are ~17 us)
@@ -161,18 +169,26 @@ static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreAct
         const AidDiTBlock& w = n.blk[i];
         ScoreBlockActs& b = a.blk[i];
         const float* mod1 = a.mod + (size_t)(2 * i) * 2 * D; const float* mod2 = a.mod + (size_t)(2 * i + 1) * 2 * D;
-        if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS4, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        else if (lp_fused && f.lp_done) {}                                                                            // written by the previous step's reverse-step kernel
         else if (lp_fused) AID_TRY(adaln_lp(z, L, f.wlp_t, n.lp_b, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));      // h_in = a.h0 = z W_lp^T + b_lp
         else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
-        AID_TRY(product(b.nx1, D, f.wov[i], D));
+        AID_TRY(product(b.nx1, D, f.wov[i], D, KS));
         AID_TRY(adaln_sum(b.h_in, D, f.slab, KS, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
-        AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
-        AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D));
+        if (f.slab_u && gemm_mid_afold_ok(B, D, 4 * D, KS4, KS, f.slab_u, w.mlp0_b, w.mlp2_w, 4 * D)) {
+            // <= 128 rows: x W1^T as KS raw slices too (8 row-tile x 32 column-tile x KS workgroups instead of 32); bias, GELU and the fold of
+            // the slices happen in the loader of the u W2^T product
+            AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 4 * D, f.slab_u, B, 4 * D, D, KS, s));
+            AID_TRY(gemm_mid_afold(f.slab_u, KS, w.mlp0_b, ACT_GELU, w.mlp2_w, 4 * D, f.slab, B, D, 4 * D, KS4, s));
+        } else {
+            AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
+            AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D, KS4));
+        }
         pend_res = b.h_mid; pend_bias = w.mlp2_b;                                                               // h_out = h_mid + u W2^T + b2
     }
-    AID_TRY(adaln_sum(pend_res, D, f.slab, KS, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
+    AID_TRY(adaln_sum(pend_res, D, f.slab, KS4, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
     f.p0_slabs = false;
-    if (skip_last && gemm_mid_ok(B, D / 2, D, KSH, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KSH, f.slab, n.op0_b, n.op2_w)) {
+    if (skip_last && gemm_mid_shape_ok(B, D / 2, D, KSH, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KSH, f.slab, n.op0_b, n.op2_w)) {
         // the head's first layer (N = D/2: 32 column tiles only) split four ways over K; bias, SiLU and the slab sum move into the reverse-step kernel
         AID_TRY(gemm_mid(a.nxf, D, n.op0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D / 2, D, KSH, s));
         f.p0_slabs = true;
@@ -183,9 +199,56 @@ static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreAct
     return AID_OK;
 }
 
+// The z-dependent trunk at <= 128 rows (act(), the collector's batches, 32-row shards of a strong-scaling run): same arithmetic and the same
+// launch sequence as score_trunk_mid, on gemm_w4 (32 x 16 tiles, the four waves of a workgroup a quarter of the K slice each, operands straight
+// into registers): x Wov^T in 2 raw K slices (64 workgroups per 32 rows), x W1^T + GELU complete (128), u W2^T in 4 raw slices (128), the
+// head's first layer complete with its SiLU (16).  The slices are folded by the adaLN that follows, as at 129..1024 rows.
+static inline int small_ks(int K) { return K % 512 == 0 ? K / 512 : (K % 256 == 0 ? K / 256 : 0); }      // K slices of 512 (8 waves x 64) or 256 (4 x 64)
+static bool trunk_small_ok(const AidScoreNet& n, int B, const ScoreActs& a, const ScoreFused* f) {
+    const int D = n.D;
+    if (!f || !f->slab || n.n_blocks < 1 || B > 128) return false;
+    const ScoreBlockActs& b = a.blk[0];
+    const int KSO = D == 512 ? 2 : 1, KS4 = small_ks(4 * D);
+    auto built = [](int k) { return k == 1 || k == 2 || k == 4 || k == 8 || k == 16; };
+    return KSO >= 1 && KS4 >= 1 && built(KSO) && built(KS4) && gemm_w4_ok(B, D, D, KSO, ACT_NONE, b.nx1, D, f->wov[0], D) &&
+           gemm_w4_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) && gemm_w4_ok(B, D, 4 * D, KS4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
+           gemm_w4_ok(B, D / 2, D, 1, ACT_SILU, a.nxf, D, n.op0_w, D) &&
+           adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
+}
+static int score_trunk_small(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
+    const int KSO = D == 512 ? 2 : 1, KS4 = small_ks(4 * D);
+    auto product = [&](const float* x, int ldx, const float* W, int K, int ks) {      // ks == 1: the one "slab" is the complete product (no bias)
+        return gemm_w4(x, ldx, W, K, nullptr, ACT_NONE, ks == 1 ? f.slab : nullptr, D, ks == 1 ? nullptr : f.slab, B, D, K, ks, s);
+    };
+    const bool lp_fused = f.wlp_t != nullptr && L <= 32;
+    if (!lp_fused) AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
+    const float* pend_res = nullptr; const float* pend_bias = nullptr;
+    for (int i = 0; i < n.n_blocks; ++i) {
+        const AidDiTBlock& w = n.blk[i];
+        ScoreBlockActs& b = a.blk[i];
+        const float* mod1 = a.mod + (size_t)(2 * i) * 2 * D; const float* mod2 = a.mod + (size_t)(2 * i + 1) * 2 * D;
+        if (pend_res) AID_TRY(adaln_sum(pend_res, D, f.slab, KS4, pend_bias, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        else if (lp_fused && f.lp_done) {}
+        else if (lp_fused) AID_TRY(adaln_lp(z, L, f.wlp_t, n.lp_b, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+        else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
+        AID_TRY(product(b.nx1, D, f.wov[i], D, KSO));
+        AID_TRY(adaln_sum(b.h_in, D, f.slab, KSO, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
+        AID_TRY(gemm_w4(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
+        AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D, KS4));
+        pend_res = b.h_mid; pend_bias = w.mlp2_b;
+    }
+    AID_TRY(adaln_sum(pend_res, D, f.slab, KS4, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
+    f.p0_slabs = false;
+    AID_TRY(gemm_w4(a.nxf, D, n.op0_w, D, n.op0_b, ACT_SILU, a.p0, D / 2, nullptr, B, D / 2, D, 1, s));
+    if (!skip_last) AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));   // else: fused into head2_p_sample
+    return AID_OK;
+}
+
 int score_trunk(const AidScoreNet& n, int B, const float* z, ScoreActs& a, bool keep, hipStream_t s, ScoreFused* fused, bool skip_last) {
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
     if (fused) fused->p0_slabs = false;
+    if (!keep && g_mid_small == 1 && trunk_small_ok(n, B, a, fused)) return score_trunk_small(n, B, z, a, s, *fused, skip_last);
     if (!keep && trunk_mid_ok(n, B, a, fused)) return score_trunk_mid(n, B, z, a, s, *fused, skip_last);
     AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
     for (int i = 0; i < n.n_blocks; ++i) {
@@ -280,7 +343,8 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D) + (size_t)n_steps * B * L);
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
-    n += sizeof(float) * (4 * (size_t)B * D + (size_t)L * D) + 512;   // split-K slabs of the mid-M pipeline, transposed latent_proj weight
+    n += sizeof(float) * (16 * (size_t)B * D + (size_t)L * D) + 512;  // split-K slabs of the mid-M pipeline (<= 16 slices), transposed latent_proj weight
+    if (B <= 128) n += sizeof(float) * 16 * (size_t)B * D + 256;       // K slices of x W1^T in the <= 128-row loop
     return n + (1 << 16);
 }
 
@@ -348,8 +412,11 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* mod_all = ws.f32((size_t)C * B * ldmod);
     ScoreFused fused;
     AID_TRY(score_fuse_attention(n, ws, fused, s));
-    if (B > 128 && B <= MID_MAX_M) {      // mid-M pipeline (score_trunk_mid)
-        fused.slab = ws.f32((size_t)4 * B * D); fused.wlp_t = ws.f32((size_t)L * D); AID_WS_OK(ws);
+    if (B <= MID_MAX_M && (B > 128 || g_mid_small)) {      // split-K pipeline (score_trunk_mid): one workgroup per CU at 129..1024 rows; 128-deep K slices below
+        const int nsl = trunk_ks_4d(n, B) > 4 ? trunk_ks_4d(n, B) : 4;
+        fused.slab = ws.f32((size_t)nsl * B * D); fused.wlp_t = ws.f32((size_t)L * D);
+        if (B <= 128 && trunk_ks_d(n, B) == 4 && g_mid_small == 3) fused.slab_u = ws.f32((size_t)4 * B * 4 * D);      // K slices of x W1^T
+        AID_WS_OK(ws);
         AID_TRY(transpose_small(n.lp_w, fused.wlp_t, D, L, s));
     }
     ScoreActs a;
@@ -410,12 +477,26 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
             const float* eps = (t > 0) ? eps_all + (size_t)t * B * L : nullptr;
             float* dst = (t == 0) ? z_out : zn;
             const float tval = collector ? (float)t / (float)collector_max_index : (float)t;
+            // The next step's first kernel (block 0's adaLN with the latent projection folded in) needs nothing but the z row this step's last
+            // kernel produces: it becomes that kernel's tail (NextLp) whenever the next step's modulations already exist (same chunk) and the
+            // collector's re-initialisation cannot change z in between - one launch less per denoise step.
+            NextLp nx; memset(&nx, 0, sizeof(nx));
+            const bool ran_small_or_mid = fused.slab != nullptr;
+            bool tail = g_fuse_next_lp && ran_small_or_mid && !collector && t > t_lo && fused.wlp_t != nullptr && L <= 32 && n.n_blocks >= 1;
+            if (tail) {
+                nx.Wt = fused.wlp_t; nx.blp = n.lp_b; nx.mod = mod_all + (size_t)(t - 1 - t_lo) * B * ldmod; nx.ldmod = ldmod;
+                nx.xout = a.blk[0].h_in; nx.ldxo = D; nx.y = a.blk[0].nx1; nx.ldy = D; nx.D = D;
+                tail = head2_next_ok(D / 2, L, nx);
+            }
             if (fused.p0_slabs)
                 AID_TRY(head2_slab_p_sample(fused.slab, 4, n.op0_b, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps,
-                                            dst, traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s));
-            else
+                                            dst, traj ? traj + (size_t)(N - t) * B * L : nullptr, B, L, s, tail ? &nx : nullptr));
+            else {
+                if (tail && !((D / 2 == 256 || D / 2 == 512) && ((((uintptr_t)a.p0 | (uintptr_t)n.op2_w) & 15) == 0))) tail = false;     // the tail lives in the wave kernel
                 AID_TRY(head2_p_sample(a.p0, D / 2, n.op2_w, D / 2, n.output_multiplier, tval, collector ? 1 : (t <= 1), coefs + 5 * t, t, z, eps, dst,
-                                       traj ? traj + (size_t)(N - t) * B * L : nullptr, nullptr, B, L, s));
+                                       traj ? traj + (size_t)(N - t) * B * L : nullptr, nullptr, B, L, s, tail ? &nx : nullptr));
+            }
+            fused.lp_done = tail;
             if (collector) {   // whole-batch NaN/Inf re-initialisation, decided on device (a host sync in the reference)
                 const float* rn = reinit_noise ? reinit_noise + (size_t)t * B * L : nullptr;
                 if (!rn) { AID_TRY(philox_fill(re_buf, (size_t)B * L, 0, 0.f, seed, ctr, s)); ctr += ((size_t)B * L + 3) / 4; rn = re_buf; }
@@ -432,7 +513,12 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     return AID_OK;
 }
 
-int aid_denoise_debug(int chunk_cap) { g_chunk_cap = chunk_cap; return AID_OK; }
+int aid_denoise_debug(int chunk_cap) {
+    if (chunk_cap == -1) g_mid_small = 1; else if (chunk_cap == -2) g_mid_small = 0; else if (chunk_cap == -3) g_mid_small = 2; else if (chunk_cap == -4) g_mid_small = 3;
+    else if (chunk_cap == -5) g_fuse_next_lp = 1; else if (chunk_cap == -6) g_fuse_next_lp = 0;
+    else g_chunk_cap = chunk_cap;
+    return AID_OK;
+}
 
 int aid_gemm_f32(const float* A, int lda, int a_kmajor, const float* B, int ldb, int b_kmajor, float* C, int ldc, int M,
                  int N, int K, const float* bias, int act, const float* residual, int ldr, float alpha, int accumulate,

@@ -481,7 +481,7 @@ static inline bool w4_shape(int kper, int& nw, int& kw) {
 bool gemm_w4_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw) {
     const bool al = ((((uintptr_t)A | (uintptr_t)W) & 15) == 0) && lda % 4 == 0 && ldw % 4 == 0;
     int nw, kw;
-    return al && M >= 1 && M <= 128 && N >= 16 && ksplit >= 1 && K % ksplit == 0 && w4_shape(K / ksplit, nw, kw) && (ksplit == 1 || act == ACT_NONE) &&
+    return al && M >= 1 && M <= 1024 && N >= 16 && ksplit >= 1 && K % ksplit == 0 && w4_shape(K / ksplit, nw, kw) && (ksplit == 1 || act == ACT_NONE) &&
            (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU);
 }
 // ksplit == 1: C = act(A W^T + bias);  ksplit > 1: slab[y] = A[:, Ky] W[:, Ky]^T (raw).  K / ksplit in {256, 512, 1024}.

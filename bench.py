@@ -282,13 +282,13 @@ def roofline_phases(agent):
                      "frac": tfl * 1e12 / PEAK_F32_MFMA, "what": what, "streams": streams}
     try:
         fl, n = counted(elbo)
-        phase("elbo", timed(elbo), fl, n, "compute_diffusion_elbo forward + backward + gradient-penalty double backward, 256 rows (state_agent.py:142-158)", "current stream")
+        phase("elbo", timed(elbo), fl, n, f"compute_diffusion_elbo forward + backward + gradient-penalty double backward, {B} rows (state_agent.py:142-158)", "current stream")
         fl_r, n_r = counted(lambda: efe(True))
         ms_r = timed(lambda: efe(True))
         phase("rollout_bptt", ms_r, fl_r, n_r, "EFE rollout (K=10 trajectories x H=5) + BPTT into the policy, estimator skipped (state_agent.py:160-181)", "current stream")
         fl_t, n_t = counted(lambda: efe(False))
         ms_t = timed(lambda: efe(False))
-        phase("estimator", ms_t - ms_r, fl_t - fl_r, n_t - n_r, "gradient-free epistemic estimator over H*K*S*B = 128 000 sample rows + 4 perturbed copies: whole aid_efe_step "
+        phase("estimator", ms_t - ms_r, fl_t - fl_r, n_t - n_r, f"gradient-free epistemic estimator over H*K*S*B = {cfg.efe_horizon * 100 * B} sample rows + 4 perturbed copies: whole aid_efe_step "
               f"({ms_t:.2f} ms) minus the same call with skip_epistemic ({ms_r:.2f} ms)", "current stream")
         fl_c, n_c = counted(lambda: ai.denoise_only(obs, ws=ai._ws))        # direct launches of the same 256-row loop (a graph replay is not counted)
         phase("reverse_loop_one_chain", timed(one_chain), fl_c, n_c, f"one {N}-step reverse-diffusion loop at {B} rows, hipGraph replay (core/diffusion.py:176-206)", "current stream")
@@ -297,16 +297,102 @@ def roofline_phases(agent):
         phase("reverse_loops_two_chains", timed(two_chains), 2 * fl_c, 2 * n_c, f"the two LIVE belief updates of a train_step (the next_obs belief of state_agent.py:138-139 is never read) as two "
               f"concurrent {B}-row loops: the schedule `value_dead_belief_elided` times", "current + one chain stream")
         fl_v, n_v = counted(value_dyn)
-        phase("value_dynamics", timed(value_dyn), fl_v, n_v, "value step (two value forwards, lambda-returns, Huber, backward) + dynamics step at 256 rows: a latency "
-              "chain of ~60 small launches, 2 GFLOP", "current stream")
+        phase("value_dynamics", timed(value_dyn), fl_v, n_v, f"value step (two value forwards, lambda-returns, Huber, backward) + dynamics step at {B} rows: a latency "
+              "chain of ~60 small launches", "current stream")
         nbytes = agent.score_optimizer.arena.flat.numel() * 4.0 * 10.0
         ms_o = timed(lambda: agent.score_optimizer.step(reduce=False))
         out["optimiser_score"] = {"ms": ms_o, "bytes": nbytes, "achieved": nbytes / (ms_o * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "bound": "hbm",
-                                  "frac": nbytes / (ms_o * 1e-3) / 8e12, "what": "global-norm clip + AdamW + EMA over the 27.15 M-parameter score arena "
+                                  "frac": nbytes / (ms_o * 1e-3) / 8e12, "what": f"global-norm clip + AdamW + EMA over the {agent.score_optimizer.arena.flat.numel() / 1e6:.2f} M-parameter score arena "
                                   "(5 reads + 4 writes + the norm pass's read per parameter = 40 B)", "streams": "current stream"}
     finally:
         ai.concurrent_belief_loops = was
         agent.invalidate_prefetch(); agent._lookahead = None
+        torch.cuda.synchronize()
+    return out
+
+
+def roofline_phases_pixel(agent):
+    """Per-phase roofline of one cfg-4 (pixels) train_step (phases of agents/pixel_agent.py:273-411), each run in isolation outside any timed region and
+    timed with HIP events on the launching stream (median of 3); `flop` = sum of 2 M N K over the GEMM / implicit-GEMM launches the library counted."""
+    from aid_amd import _native as nat
+    ai, cfg = agent.active_inference, agent.config
+    B, N = cfg.batch_size, cfg.diffusion.num_diffusion_steps
+    dev = agent.device
+    torch.cuda.synchronize()
+    batch = agent.replay_buffer.sample(B)
+    obs_a = agent._process_batch_observations(batch["observations"]); obs_b = agent._process_batch_observations(batch["next_observations"])
+    actions, dones = batch["actions"], batch["dones"]
+    nrew = torch.randn(B, device=dev)
+    enc_obs, ctx_a = agent.encoder(obs_a, agent._encoder_noise(B), keep_for_backward=True, slot="a")
+    enc_next, ctx_b = agent.encoder(obs_b, agent._encoder_noise(B), keep_for_backward=True, slot="b")
+    enc_obs, enc_next = enc_obs.clone(), enc_next.clone()
+    was = ai.concurrent_belief_loops
+    ai.concurrent_belief_loops = True
+    both = ai.denoise_pair(enc_obs, enc_next)
+    latents, next_latents = both[:B].contiguous(), both[B:].contiguous()
+    d_feat = torch.randn_like(enc_obs) * 1e-3
+
+    def timed(fn, reps=3):
+        fn(); torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1))
+        return float(np.median(ts))
+
+    def counted(fn):
+        torch.cuda.synchronize(); nat.prof_enable(True); nat.prof_reset()
+        fn(); torch.cuda.synchronize()
+        fl = nat.prof_read(nat.PROF_GEMM)["flops"] + nat.prof_read(nat.PROF_GEMM_TILE)["flops"]
+        n = nat.prof_read(nat.PROF_GEMM)["launches"] + nat.prof_read(nat.PROF_GEMM_TILE)["launches"]
+        nat.prof_enable(False); nat.prof_reset()
+        return fl, int(n)
+    out = {}
+
+    def phase(name, fn, what, streams="current stream", flop_fn=None):
+        fl, n = counted(flop_fn or fn)
+        ms = timed(fn)
+        tfl = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        out[name] = {"ms": ms, "flop": fl, "gemm_launches": n, "achieved": tfl, "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "bound": "mfma",
+                     "frac": tfl * 1e12 / PEAK_F32_MFMA, "what": what, "streams": streams}
+    try:
+        phase("encoder_forward", lambda: agent.encoder(obs_a, agent._encoder_noise(B), keep_for_backward=True, slot="a"),
+              f"one DrQ-v2 encoder pass over {B} augmented 9x84x84 stacks: 4 implicit-GEMM convs + GroupNorm / Mish, spatial attention, LayerNorm over 451 584 "
+              "features, Linear 451 584 -> 256 -> 128 (encoder/visual_encoders.py:135-189); a train_step runs two")
+        ctx = agent.encoder(obs_a, agent._encoder_noise(B), keep_for_backward=True, slot="a")[1]
+
+        def bwd():
+            agent.score_optimizer.zero_grad(); agent.encoder.backward(d_feat, ctx)
+        phase("encoder_backward", bwd, "the backward of one encoder pass (data + weight gradients of every conv and Linear, spectral-norm backward); a train_step runs two")
+        phase("reverse_loops_two_chains", lambda: ai.denoise_pair(enc_obs, enc_next), f"the two belief updates of a train_step as concurrent {B}-row {N}-step loops "
+              "(hipGraph replays), L = 128", "current + one chain stream", flop_fn=lambda: (ai.denoise_only(enc_obs, ws=ai._ws), ai.denoise_only(enc_next, ws=ai._ws)))
+
+        def elbo():
+            agent.score_optimizer.zero_grad(); ai.compute_diffusion_elbo(enc_obs, nrew, latents)
+        phase("elbo", elbo, f"compute_diffusion_elbo forward + backward at {B} rows incl. the feature-decoder reconstruction and d(loss)/d(features) (pixel_agent.py:300-331)")
+        d_next = torch.zeros_like(enc_next)
+        phase("infonce", lambda: agent.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight),
+              "InfoNCE between the predicted next latent and the encoded next observation + its feature gradient (pixel_agent.py:413-437)")
+
+        def efe():
+            agent.policy_optimizer.zero_grad(); ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
+        phase("rollout_bptt", efe, f"EFE rollout (K=10 trajectories x H={cfg.efe_horizon}) + BPTT into the policy; the ConvDecoder estimator is opt-in and off")
+
+        def value_dyn():
+            agent.value_optimizer.zero_grad(); agent.dynamics_optimizer.zero_grad()
+            nat.value_step(ai.value_network.table(), ai.value_network.grad_table(), latents, next_latents, nrew, dones, cfg.discount_factor, 0.95, 5, ws=ai._ws)
+            nat.dynamics_step(ai.latent_dynamics.table(), ai.latent_dynamics.grad_table(), latents, actions, next_latents, ws=ai._ws)
+        phase("value_dynamics", value_dyn, f"value step + dynamics step at {B} rows")
+        so = agent.score_optimizer
+        nparam = so.score.flat.numel() + so.encoder.flat.numel() + so.fdec.flat.numel()
+        nbytes = 4.0 * (10.0 * so.score.flat.numel() + 8.0 * (so.encoder.flat.numel() + so.fdec.flat.numel()))      # the score arena also carries its EMA
+        ms_o = timed(lambda: so.step())
+        out["optimiser_score_encoder"] = {"ms": ms_o, "bytes": nbytes, "achieved": nbytes / (ms_o * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s", "bound": "hbm",
+                                          "frac": nbytes / (ms_o * 1e-3) / 8e12, "what": f"shared-norm clip + AdamW over score net + diffusion + encoder + feature decoder "
+                                          f"({nparam / 1e6:.1f} M parameters; EMA on the score arena)", "streams": "current stream"}
+    finally:
+        ai.concurrent_belief_loops = was
         torch.cuda.synchronize()
     return out
 
@@ -358,6 +444,10 @@ def other_configs(device):
     fl3 = 18.1e12 - NSTEPS * b3 * ALGO_FLOP_PER_DENOISE_ROW_STEP        # SURVEY 8(d)'s 18.1 TFLOP minus the never-read next_obs belief update (not run by default)
     res["cfg3_hopper_b1024"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_flop_per_step": fl3, "algorithmic_tflops": fl3 / dt / 1e12, "frac_of_f32_mfma_peak": fl3 / dt / PEAK_F32_MFMA,
                                 "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    try:
+        res["cfg3_hopper_b1024"]["roofline_phases"] = roofline_phases(agent)
+    except Exception as e:      # diagnostics must not cost the bench line
+        res["cfg3_hopper_b1024"]["roofline_phases"] = {"error": repr(e)}
     del agent; torch.cuda.empty_cache()
     l4, a4, b4 = 128, 6, 256
     cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b4, efe_horizon=HORIZON, latent_dim=l4, hidden_dim=D, pixel_observation=True)
@@ -374,6 +464,10 @@ def other_configs(device):
     res["cfg4_pixel_b256"] = {"ms_per_step": 1e3 * dt, "steps_per_s": 1 / dt, "algorithmic_tflops": fl4 / dt / 1e12, "frac_of_f32_mfma_peak": fl4 / dt / PEAK_F32_MFMA,
                               "algorithmic_flop_per_step": fl4, "replay": "uint8 frames", "pixel_epistemic": False,
                               "finite": bool(all(np.isfinite(v) for v in m.values()))}
+    try:
+        res["cfg4_pixel_b256"]["roofline_phases"] = roofline_phases_pixel(agent)
+    except Exception as e:
+        res["cfg4_pixel_b256"]["roofline_phases"] = {"error": repr(e)}
     res["pixel_epistemic_f1"] = pixel_epistemic_probe(agent)
     del agent; torch.cuda.empty_cache()
     return res

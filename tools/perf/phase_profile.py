@@ -1,6 +1,6 @@
 """One phase of a cfg-2 train_step, in isolation, a few times: the program to put behind `rocprofv3 --kernel-trace --stats --` (or a --pmc pass)
-so that a phase's kernels can be read off one summary (profiles/r03_phase_<phase>_kernel_stats.csv; bench.py's `roofline_phases` times the same
-calls with HIP events).  usage: python3 tools/perf/phase_profile.py <elbo|rollout_bptt|efe|chain1|chain1_direct|chains3|value_dynamics|optimiser> [reps]"""
+so that a phase's kernels can be read off one summary (profiles/rNN_phase_<phase>_kernel_stats.csv; bench.py's `roofline_phases` times the same
+calls with HIP events).  usage: python3 tools/perf/phase_profile.py <elbo|rollout_bptt|efe|chain1|chain1_direct|chains3|chains2|value_dynamics|optimiser>[_cold] [reps]"""
 import os
 import sys
 
@@ -59,6 +59,7 @@ fn = {"elbo": elbo, "rollout_bptt": lambda: efe(True), "efe": lambda: efe(False)
       "chain1": lambda: ai._denoise_chains([obs], [None], None, N, train, [torch.cuda.current_stream()]),
       "chain1_direct": lambda: ai.denoise_only(obs, ws=ai._ws),          # the same 256-row loop launched kernel by kernel (PMC passes: no graph replay)
       "chains3": lambda: ai.denoise_many([next_obs, obs, next_obs]),
+      "chains2": lambda: ai.denoise_many([next_obs, obs]),               # the two LIVE belief updates of a step (dead next_obs belief elided)
       "merged3": lambda: (setattr(ai, "concurrent_belief_loops", False), ai.denoise_many([next_obs, obs, next_obs]))[1],      # ONE 768-row loop
       "value_dynamics": value_dyn, "optimiser": lambda: agent.score_optimizer.step(reduce=False)}[what.replace("_cold", "")]
 dump = os.environ.get("AID_PHASE_DUMP")        # per-launch HIP-event timings of ONE call (tools/perf/launch_table.py reads the CSV)

@@ -746,14 +746,6 @@ def gemm_w4(A, W, bias=None, act="none", ksplit=1):
     return slab
 
 
-def gemm_mid_afold(a_slabs, abias, act, W, ksplit):
-    """aid_gemm_mid_afold: slabs [ksplit, M, N] of act(abias + sum(a_slabs, 0)) W^T, the A operand folded in the loader (M <= 128, 4 input slabs)."""
-    nfold, M, K = a_slabs.shape; N = W.shape[0]
-    out = torch.empty(ksplit, M, N, device=W.device, dtype=torch.float32)
-    check(lib().aid_gemm_mid_afold(_ptr(a_slabs), nfold, _ptr(abias), ACT[act], _ptr(W), W.stride(0), _ptr(out), M, N, K, ksplit, _stream()), "aid_gemm_mid_afold")
-    return out
-
-
 def adaln_sum(res, slab, bias, mod, want_x=True):
     """aid_adaln_sum: x = res + bias + sum(slab, 0); y = LN(x) (1 + mod[:, :D]) + mod[:, D:] -> (x or None, y)"""
     M, D = res.shape

@@ -48,10 +48,6 @@ struct MidArgs {
                                           //   into C: a split-K GEMM that is complete when the kernel ends, bit-reproducible (gemm_f32's route)
     int accumulate;                       // C += (act must be NONE; ksplit == 1 or folded)
     int M, N, K, ksplit, act;
-    // AFN > 0 instantiations: the A operand is itself a split-K result that nobody folded: A(m, k) = aact(abias[k] + sum_{y < AFN} A[y * astride + m * lda + k])
-    // (fixed slab order).  The <= 128-row reverse loop's x W1^T product is cut into K slices like the others and its bias + GELU + fold happen
-    // in the loader of the u W2^T product that reads it.
-    const float* abias; size_t astride; int aact;
 };
 
 constexpr int MID_BK = 64, MID_BN = 64;
@@ -71,7 +67,7 @@ template <int ACT> __device__ __forceinline__ float mid_act(float x) {
 // BKM: the W operand is contraction-major ([K][N], n contiguous): the data gradient dX = dY W reads the weight as stored, without a
 // transposed copy.  Its stage is kept in LDS as it arrives ([64][BN + 4]: 16-B writes) and fragments are gathered with four 4-B reads per
 // k-group (16 consecutive n at one k: conflict-free), in the shadow of the MFMAs.
-template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM, int AFN = 0, int AACT = ACT_NONE>
+template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int tiles_n) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int NT = 256, BM = 16 * BMF * WM, BN = 16 * NJ * WN, BK = MID_BK, CPR = BK / 4;
@@ -118,38 +114,9 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
     // (loaded a whole stage ago) is written to the other LDS buffer: a global load has 1.5 stages (~2 us) to arrive - the weights of a block
     // are cold every denoise step (56 MB stream through 32 MB of L2) and one wave per SIMD has nobody to hide a late load behind.  With one
     // workgroup per CU registers are free (122 + 40 of 512).  The loop is unrolled by two so both sets are named statically.
-    // (AFN > 0: an A piece is AFN slab loads + one bias load; they stay in registers until the piece is written to LDS a stage later, where
-    // they are added in slab order and the activation is applied - the loads are in flight for a whole stage like any other piece)
-    struct Regs { f32x4 v[NS]; f32x4 x[AFN > 0 ? PA * AFN : 1]; };
-    Regs rg0, rg1;
-    const float* asrc_bias[PA];
-    if constexpr (AFN > 0) {
-#pragma unroll
-        for (int p = 0; p < PA; ++p) asrc_bias[p] = g.abias + kbeg + 4 * ((tid + NT * p) % CPR);
-    }
-    auto load_piece = [&](Regs& rg, int p, int kt) {
-        rg.v[p] = *reinterpret_cast<const f32x4*>(src[p] + (p < PA ? (size_t)kt * BK : (size_t)kt * wstep));
-        if constexpr (AFN > 0) {
-            if (p < PA) {
-#pragma unroll
-                for (int y = 1; y < AFN; ++y) rg.x[p * AFN + y - 1] = *reinterpret_cast<const f32x4*>(src[p] + (size_t)kt * BK + (size_t)y * g.astride);
-                rg.x[p * AFN + AFN - 1] = *reinterpret_cast<const f32x4*>(asrc_bias[p < PA ? p : 0] + (size_t)kt * BK);
-            }
-        }
-    };
-    auto store_piece = [&](const Regs& rg, int p, int buf) {
-        f32x4 v = rg.v[p];
-        if constexpr (AFN > 0) {
-            if (p < PA) {
-                v = rg.x[p * AFN + AFN - 1] + v;                                  // bias + slab 0
-#pragma unroll
-                for (int y = 1; y < AFN; ++y) v += rg.x[p * AFN + y - 1];        // + slab 1, 2, ... (fixed order)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = mid_act<AACT>(v[e]);       // (a template argument: a run-time switch inlines every activation's code into a two-stage kernel)
-            }
-        }
-        *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = v;
-    };
+    f32x4 rg0[NS], rg1[NS];
+    auto load_piece = [&](f32x4 (&rg)[NS], int p, int kt) { rg[p] = *reinterpret_cast<const f32x4*>(src[p] + (p < PA ? (size_t)kt * BK : (size_t)kt * wstep)); };
+    auto store_piece = [&](const f32x4 (&rg)[NS], int p, int buf) { *reinterpret_cast<f32x4*>(smem + dst[p] + buf * (p < PA ? A_FL : B_FL)) = rg[p]; };
     constexpr int NG = BK / 16, MPG = 4 * BMF * NJ, NM = NG * MPG, S0 = NM / 2;
     constexpr int LSTEP = S0 / NS > 0 ? S0 / NS : 1, SSTEP = (NM - S0) / NS > 0 ? (NM - S0) / NS : 1;
     static_assert(S0 / NS >= 1, "more staging pieces than MFMA slots in half a stage");
@@ -169,7 +136,7 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
         }
     };
     // contract LDS buffer `cur`; first half: load tile `kt_load` into `ld`; second half: write `st` (the tile after this one) to buffer cur ^ 1
-    auto stage = [&](int cur, int kt_load, Regs& ld, const Regs& st) {
+    auto stage = [&](int cur, int kt_load, f32x4 (&ld)[NS], const f32x4 (&st)[NS]) {
         const float* a_s = As + cur * A_FL + (wm + r16) * BK;
         // (row & 15) == r16 for every fragment row of this lane: the swizzle term is lane-constant
         const float* b_s = BKM ? Bs + cur * B_FL + wn + r16 : Bs + cur * B_FL + (wn + r16) * BK;
@@ -307,9 +274,6 @@ __device__ __forceinline__ void gemm_mid_body(const MidArgs& g, int tiles_m, int
 
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n); }
-// 32-row tiles whose A operand is AFN unfolded K slices of the previous product (+ bias, activation): the u W2^T product of the <= 128-row loop
-template <int AFN, int AACT>
-__global__ void __launch_bounds__(256) gemm_mid_afold_kernel(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<1, 2, 2, 2, ACT_NONE, false, AFN, AACT>(g, tiles_m, tiles_n); }
 // The 32-row tile (129..256 rows: the three concurrent 256-row belief chains of a train_step) with its registers capped at 512 / 3: its
 // workgroup is 48 KB of LDS, so three fit a CU - but at the 184 VGPRs the compiler takes by itself only two waves fit a SIMD and the third
 // chain's workgroup waits for a slot (three chains overlapped 1.63x, exactly what two resident workgroups give).
@@ -385,31 +349,6 @@ int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, 
         case ACT_RELU: return launch_mid_bm<ACT_RELU, false>(g, s);
         default: return launch_mid_bm<ACT_NONE, false>(g, s);
     }
-}
-// slab_out[y] = A'[:, Ky] W[:, Ky]^T with A'(m, k) = aact(abias[k] + sum_{y < nfold} a_slabs[y][m][k]) (a_slabs: [nfold][M][K], the raw K slices of the
-// product that made A; fixed fold order).  M <= 128 (32-row tiles), nfold == 4.
-bool gemm_mid_afold_ok(int M, int N, int K, int ksplit, int nfold, const float* a_slabs, const float* abias, const float* W, int ldw) {
-    return M <= 128 && nfold == 4 && ksplit > 1 && ((((uintptr_t)abias) & 15) == 0) && gemm_mid_shape_ok(M, N, K, ksplit, ACT_NONE, a_slabs, K, W, ldw);
-}
-int gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
-                   hipStream_t s) {
-    AID_REQUIRE(gemm_mid_afold_ok(M, N, K, ksplit, nfold, a_slabs, abias, W, ldw) && slab_out, AID_E_SHAPE, "gemm_mid_afold: unsupported M=%d N=%d K=%d ksplit=%d nfold=%d",
-                M, N, K, ksplit, nfold);
-    MidArgs g; memset(&g, 0, sizeof(g));
-    g.A = a_slabs; g.lda = K; g.W = W; g.ldw = ldw; g.slab = slab_out; g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = ACT_NONE;
-    g.abias = abias; g.astride = (size_t)M * K; g.aact = aact;
-    ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)nfold * M * K + (double)N * K + (double)ksplit * M * N));
-    prof.m = M; prof.n = N; prof.k = K; prof.layout = 8 + 128; prof.variant = 22;
-    constexpr size_t lds = sizeof(float) * 2 * ((size_t)32 * MID_BK + (size_t)64 * MID_BK);
-    const int tiles_m = (M + 31) / 32, tiles_n = (N + 63) / 64;
-    switch (aact) {
-        case ACT_GELU: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_GELU>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
-        case ACT_SILU: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_SILU>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
-        case ACT_NONE: hipLaunchKernelGGL((gemm_mid_afold_kernel<4, ACT_NONE>), dim3(tiles_m * tiles_n * ksplit), dim3(256), lds, s, g, tiles_m, tiles_n); break;
-        default: ::aid::set_error("gemm_mid_afold: activation %d (none, silu, gelu are built)", aact); return AID_E_SHAPE;
-    }
-    AID_LAUNCH_CHECK();
-    return AID_OK;
 }
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
@@ -713,11 +652,6 @@ int aid_gemm_w4(const float* A, int lda, const float* W, int ldw, const float* b
                 void* stream) {
     AID_REQUIRE(A && W, AID_E_NULL, "aid_gemm_w4: null operand");
     return gemm_w4(A, lda, W, ldw, bias, act, C, ldc, slab, M, N, K, ksplit, (hipStream_t)stream);
-}
-int aid_gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
-                       void* stream) {
-    AID_REQUIRE(a_slabs && abias && W && slab_out, AID_E_NULL, "aid_gemm_mid_afold: null operand");
-    return gemm_mid_afold(a_slabs, nfold, abias, aact, W, ldw, slab_out, M, N, K, ksplit, (hipStream_t)stream);
 }
 int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
                   float* y, int ldy, int M, int D, void* stream) {

@@ -111,23 +111,16 @@ int head_p_sample(const float* raw, const float* mult, float t_value, int contin
 constexpr int MID_MAX_M = 8192;
 // K slices for the 512-wide products of a DiT block at M rows: enough (column tile, slice) pairs for ~one workgroup per CU
 inline int mid_ksplit(int M) { return M <= 1024 ? 4 : (M <= 2048 ? 2 : 1); }
-// <= 128 rows (act() / collector batches, 32-row shards of a strong-scaling run): one to four 32-row tiles x 64-column tiles is far too few
-// workgroups, so K is cut into 128-deep slices (two 64-deep stages, the kernel's minimum), at most 16: a 512-wide product of a DiT block is
-// 8 column tiles x 4 (K = 512) or x 16 (K = 2048) slices per row tile
-inline int mid_ksplit_small(int K) { const int ks = K / 128; return ks > 16 ? 16 : (ks < 1 ? 1 : ks); }
 bool gemm_mid_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);           // 129..MID_MAX_M rows
-bool gemm_mid_shape_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);     // any M >= 1 (the small-batch loop)
+bool gemm_mid_shape_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);     // any M >= 1
 int gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
              float* slab, int M, int N, int K, int ksplit, hipStream_t s);
 // general form: w_kmajor = W stored [K][N] (the data gradient dX = dY W of a Linear: the weight as it is), preact = optional second output
 int gemm_mid_ex(const float* A, int lda, const float* W, int ldw, int w_kmajor, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                 float* preact, float* slab, int M, int N, int K, int ksplit, hipStream_t s, const float* dact_pre = nullptr, int dact = 0, int* ctr = nullptr,
                 int accumulate = 0);      // ctr: fold the K slices in the kernel (one zeroed int per output tile) and run the full epilogue into C
-// the product whose A operand is the unfolded K slices of the previous product (see gemm_mid.hip): slab_out[y] = act(abias + sum a_slabs)[:, Ky] W[:, Ky]^T
-bool gemm_mid_afold_ok(int M, int N, int K, int ksplit, int nfold, const float* a_slabs, const float* abias, const float* W, int ldw);
-int gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
-                   hipStream_t s);
-// <= 128 rows: 32 x 16 tiles, four waves a quarter of the K slice each, operands straight into registers (gemm_mid.hip)
+// <= 128 rows (act() / collector batches, 32-row shards of a strong-scaling run): 32 x 16 tiles, the waves of a workgroup a part of the K slice
+// each, operands straight into registers (gemm_mid.hip, gemm_w4_kernel)
 bool gemm_w4_ok(int M, int N, int K, int ksplit, int act, const float* A, int lda, const float* W, int ldw);
 int gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
             hipStream_t s);

@@ -137,25 +137,21 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
 // arithmetic as score_trunk below; what changes is the work decomposition: every GEMM is exactly one workgroup per CU (gemm_mid), the two
 // 512-wide products of a block are split four ways over K into raw slabs, and the adaLN that follows them - it reads the residual stream
 // anyway - adds the slabs, the bias and the residual in a fixed order (adaln_sum).  36 launches per step as before, each about half as long.
-// K slices of the D-deep (x Wov^T) and the 4D-deep (u W2^T) product of a block at B rows
-static inline int trunk_ks_d(const AidScoreNet& n, int B) { return B > 128 ? mid_ksplit(B) : mid_ksplit_small(n.D); }
-static inline int trunk_ks_4d(const AidScoreNet& n, int B) { return B > 128 ? mid_ksplit(B) : mid_ksplit_small(4 * n.D); }
 static int g_fuse_next_lp = 1;    // aid_denoise_debug(-5 / -6): the next step's adaLN + latent projection as the tail of the reverse-step kernel, on / off
-// the <= 128-row loop: 1 = gemm_w4 pipeline (score_trunk_small); 0 = weight-streaming skinny / panel kernels (score_trunk); 2 / 3 = score_trunk_mid's
-// 32-row tiles with 128-deep K slices, x W1^T unsplit / split with the fold in the next product's loader.  aid_denoise_debug(-1 / -2 / -3 / -4): A/B timing
-// (tools/perf/small_batch_ab.py)
+// the <= 128-row loop: 1 = gemm_w4 pipeline (score_trunk_small); 0 = weight-streaming skinny / panel kernels (score_trunk).  aid_denoise_debug(-1 / -2):
+// A/B timing (tools/perf/small_batch_ab.py)
 static int g_mid_small = 1;
 static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const ScoreFused* f) {
     const int D = n.D;
     if (!f || !f->slab || n.n_blocks < 1) return false;
     const ScoreBlockActs& b = a.blk[0];
-    const int KS = trunk_ks_d(n, B), KS4 = trunk_ks_4d(n, B);
-    return gemm_mid_shape_ok(B, D, D, KS, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_shape_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
-           gemm_mid_shape_ok(B, D, 4 * D, KS4, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
+    const int KS = mid_ksplit(B);
+    return gemm_mid_ok(B, D, D, KS, ACT_NONE, b.nx1, D, f->wov[0], D) && gemm_mid_ok(B, 4 * D, D, 1, ACT_GELU, b.nx2, D, n.blk[0].mlp0_w, D) &&
+           gemm_mid_ok(B, D, 4 * D, KS, ACT_NONE, b.u, 4 * D, n.blk[0].mlp2_w, 4 * D) &&
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
 static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
-    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = trunk_ks_d(n, B), KS4 = trunk_ks_4d(n, B), KSH = 4;
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = mid_ksplit(B), KS4 = KS, KSH = 4;
     // the raw product of a 512-wide layer: `ks` slabs (ks == 1: the one "slab" is the kernel's ordinary output, no bias / activation)
     auto product = [&](const float* x, int ldx, const float* W, int K, int ks) {
         return gemm_mid(x, ldx, W, K, nullptr, ACT_NONE, nullptr, 0, ks == 1 ? f.slab : nullptr, D, ks == 1 ? nullptr : f.slab, B, D, K, ks, s);
@@ -175,20 +171,13 @@ static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreAct
         else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
         AID_TRY(product(b.nx1, D, f.wov[i], D, KS));
         AID_TRY(adaln_sum(b.h_in, D, f.slab, KS, f.bov[i], mod2, ldmod, b.h_mid, D, b.nx2, D, B, D, s));      // h_mid = h_in + x Wov^T + bov
-        if (f.slab_u && gemm_mid_afold_ok(B, D, 4 * D, KS4, KS, f.slab_u, w.mlp0_b, w.mlp2_w, 4 * D)) {
-            // <= 128 rows: x W1^T as KS raw slices too (8 row-tile x 32 column-tile x KS workgroups instead of 32); bias, GELU and the fold of
-            // the slices happen in the loader of the u W2^T product
-            AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 4 * D, f.slab_u, B, 4 * D, D, KS, s));
-            AID_TRY(gemm_mid_afold(f.slab_u, KS, w.mlp0_b, ACT_GELU, w.mlp2_w, 4 * D, f.slab, B, D, 4 * D, KS4, s));
-        } else {
-            AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
-            AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D, KS4));
-        }
+        AID_TRY(gemm_mid(b.nx2, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, nullptr, 0, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
+        AID_TRY(product(b.u, 4 * D, w.mlp2_w, 4 * D, KS4));
         pend_res = b.h_mid; pend_bias = w.mlp2_b;                                                               // h_out = h_mid + u W2^T + b2
     }
     AID_TRY(adaln_sum(pend_res, D, f.slab, KS4, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, a.nxf, D, B, D, s));
     f.p0_slabs = false;
-    if (skip_last && gemm_mid_shape_ok(B, D / 2, D, KSH, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KSH, f.slab, n.op0_b, n.op2_w)) {
+    if (skip_last && gemm_mid_ok(B, D / 2, D, KSH, ACT_NONE, a.nxf, D, n.op0_w, D) && head2_slab_ok(D / 2, KSH, f.slab, n.op0_b, n.op2_w)) {
         // the head's first layer (N = D/2: 32 column tiles only) split four ways over K; bias, SiLU and the slab sum move into the reverse-step kernel
         AID_TRY(gemm_mid(a.nxf, D, n.op0_w, D, nullptr, ACT_NONE, nullptr, 0, nullptr, 0, f.slab, B, D / 2, D, KSH, s));
         f.p0_slabs = true;
@@ -344,7 +333,6 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
     n += sizeof(float) * (16 * (size_t)B * D + (size_t)L * D) + 512;  // split-K slabs of the mid-M pipeline (<= 16 slices), transposed latent_proj weight
-    if (B <= 128) n += sizeof(float) * 16 * (size_t)B * D + 256;       // K slices of x W1^T in the <= 128-row loop
     return n + (1 << 16);
 }
 
@@ -412,11 +400,9 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     float* mod_all = ws.f32((size_t)C * B * ldmod);
     ScoreFused fused;
     AID_TRY(score_fuse_attention(n, ws, fused, s));
-    if (B <= MID_MAX_M && (B > 128 || g_mid_small)) {      // split-K pipeline (score_trunk_mid): one workgroup per CU at 129..1024 rows; 128-deep K slices below
-        const int nsl = trunk_ks_4d(n, B) > 4 ? trunk_ks_4d(n, B) : 4;
-        fused.slab = ws.f32((size_t)nsl * B * D); fused.wlp_t = ws.f32((size_t)L * D);
-        if (B <= 128 && trunk_ks_d(n, B) == 4 && g_mid_small == 3) fused.slab_u = ws.f32((size_t)4 * B * 4 * D);      // K slices of x W1^T
-        AID_WS_OK(ws);
+    if (B <= MID_MAX_M && (B > 128 || g_mid_small)) {      // split-K pipelines: score_trunk_mid (one workgroup per CU at 129..1024 rows), score_trunk_small (<= 128 rows)
+        const int nsl = B > 128 ? 4 : (small_ks(4 * D) > 4 ? small_ks(4 * D) : 4);
+        fused.slab = ws.f32((size_t)nsl * B * D); fused.wlp_t = ws.f32((size_t)L * D); AID_WS_OK(ws);
         AID_TRY(transpose_small(n.lp_w, fused.wlp_t, D, L, s));
     }
     ScoreActs a;
@@ -514,7 +500,7 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
 }
 
 int aid_denoise_debug(int chunk_cap) {
-    if (chunk_cap == -1) g_mid_small = 1; else if (chunk_cap == -2) g_mid_small = 0; else if (chunk_cap == -3) g_mid_small = 2; else if (chunk_cap == -4) g_mid_small = 3;
+    if (chunk_cap == -1) g_mid_small = 1; else if (chunk_cap == -2) g_mid_small = 0;
     else if (chunk_cap == -5) g_fuse_next_lp = 1; else if (chunk_cap == -6) g_fuse_next_lp = 0;
     else g_chunk_cap = chunk_cap;
     return AID_OK;

@@ -88,17 +88,11 @@ int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, c
  * Unit-test / bench entries; the reverse loop calls them through aid_denoise_loop. */
 int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                  float* slab, int M, int N, int K, int ksplit, void* stream);
-/* The <= 128-row reverse loop (act() / collector batches; csrc/gemm_mid.hip): slab_out[y] [M,N] = A'[:, Ky] W[:, Ky]^T, y < ksplit, where the A operand
- * is itself an UNFOLDED split-K result, A'(m,k) = aact(abias[k] + sum_{j < nfold} a_slabs[j][m][k]) (a_slabs [nfold][M][K], fixed fold order): the
- * x W1^T -> GELU -> u W2^T pair of a DiT block (models/score_networks.py:226-233) with every product spread over K slices.  M <= 128, nfold == 4,
- * K % (128 ksplit) == 0.  Unit-test entry; aid_denoise_loop uses it internally. */
 /* <= 128 rows (csrc/gemm_mid.hip, gemm_w4_kernel): C [M,N] = act(A W^T + bias) (ksplit == 1) or ksplit raw K-slice slabs [ksplit][M][N]; a workgroup owns a
- * 32 x 16 tile, its four waves a quarter of the K slice each, operands go straight from global memory into the MFMA registers.  K / (4 ksplit) in
- * {64, 128}; act in {none, silu, gelu} (ksplit == 1 only).  The products of the act() / collector reverse loop.  Unit-test entry. */
+ * 32 x 16 tile, its four or eight waves a part of the K slice each, operands go straight from global memory into the MFMA registers.  K / ksplit in
+ * {256, 512, 1024}; act in {none, silu, gelu} (ksplit == 1 only).  The products of the act() / collector reverse loop.  Unit-test entry. */
 int aid_gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
                 void* stream);
-int aid_gemm_mid_afold(const float* a_slabs, int nfold, const float* abias, int aact, const float* W, int ldw, float* slab_out, int M, int N, int K, int ksplit,
-                       void* stream);
 /* timing experiments: force the row-tile height of the mid-M kernel to >= 32 bmt_min rows (1 = automatic); cap the number of denoise steps that share one
  * hoisted conditioning pass (0 = automatic) */
 int aid_mid_debug(int bmt_min);

@@ -431,10 +431,10 @@ def test_gemm_mid_and_adaln_sum(nat, M):
 
 
 @pytest.mark.parametrize("M", [1, 7, 32, 33, 64, 100, 128])
-def test_gemm_mid_small_rows_split_k_pipeline(nat, M):
-    """The <= 128-row reverse loop's products (act() / collector batches, 32-row shards of a strong-scaling run): 32-row tiles with K cut into 128-deep
-    slices - x Wov^T in 4 slices, x W1^T in 4 RAW slices whose bias + GELU + fold happen in the loader of the u W2^T product (16 slices), and the
-    adaLN that folds 16 slabs - against float64 torch.  Reference ops: models/score_networks.py:214-235."""
+def test_small_rows_split_k_pipeline(nat, M):
+    """The <= 128-row reverse loop's products (act() / collector batches, 32-row shards of a strong-scaling run; csrc/gemm_mid.hip, gemm_w4_kernel): 32 x 16
+    tiles, the waves of a workgroup a part of the K slice each, operands straight into registers - x Wov^T in 2 raw slices, x W1^T + GELU complete,
+    u W2^T in 4 (or 8) raw slices folded by the adaLN - against float64 torch.  Reference ops: models/score_networks.py:214-235."""
     rng = np.random.default_rng(1000 + M)
     D = 512
     T = lambda a: torch.from_numpy(a).double()
@@ -442,30 +442,25 @@ def test_gemm_mid_small_rows_split_k_pipeline(nat, M):
     W1 = (rng.standard_normal((4 * D, D)) / np.sqrt(D)).astype(np.float32); b1 = rng.standard_normal(4 * D).astype(np.float32)
     W2 = (rng.standard_normal((D, 4 * D)) / np.sqrt(4 * D)).astype(np.float32); b2 = rng.standard_normal(D).astype(np.float32)
     res = rng.standard_normal((M, D)).astype(np.float32)
-    s1 = nat.gemm_mid(dev(x), dev(W1), ksplit=4)                                    # raw K slices of x W1^T
-    assert s1.shape == (4, M, 4 * D)
     pre = T(x) @ T(W1).T
-    np.testing.assert_allclose(s1.double().sum(0).cpu().numpy(), pre.numpy(), rtol=1e-5, atol=4e-6)
-    s2 = nat.gemm_mid_afold(s1, dev(b1), "gelu", dev(W2), 16)                        # GELU(b1 + sum s1) W2^T in 16 slices
-    assert s2.shape == (16, M, D)
     u_ref = torch.nn.functional.gelu(pre + T(b1))
     prod = u_ref @ T(W2).T
-    np.testing.assert_allclose(s2.double().sum(0).cpu().numpy(), prod.numpy(), rtol=2e-5, atol=8e-6)
-    for yk in (0, 7, 15):        # each output slab is exactly its K slice of the folded operand
-        sl = slice(yk * 128, (yk + 1) * 128)
-        np.testing.assert_allclose(s2[yk].cpu().numpy(), (u_ref[:, sl] @ T(W2[:, sl]).T).float().numpy(), rtol=2e-5, atol=4e-6)
+    un = u_ref.float().numpy()
+    s2 = nat.gemm_w4(dev(un), dev(W2), ksplit=4)                   # u W2^T in 4 raw slices (8 waves x 64 per slice)
     mod = (0.3 * rng.standard_normal((M, 2 * D))).astype(np.float32)
-    xo, yo = nat.adaln_sum(dev(res), s2, dev(b2), dev(mod))
+    xo, yo = nat.adaln_sum(dev(res), s2, dev(b2), dev(mod))                         # the adaLN that folds them
     x_ref = T(res) + T(b2) + prod
     y_ref = torch.nn.functional.layer_norm(x_ref, (D,), None, None, 1e-5) * (1 + T(mod[:, :D])) + T(mod[:, D:])
     np.testing.assert_allclose(xo.cpu().numpy(), x_ref.float().numpy(), rtol=1e-5, atol=8e-6)
     np.testing.assert_allclose(yo.cpu().numpy(), y_ref.float().numpy(), rtol=2e-5, atol=3e-5)
+    s16 = nat.gemm_mid(dev(un), dev(W2), ksplit=16)                                  # gemm_mid's 32-row tiles accept any row count too (16 x 128-deep slices)
+    xo16, _ = nat.adaln_sum(dev(res), s16, dev(b2), dev(mod))
+    np.testing.assert_allclose(xo16.cpu().numpy(), x_ref.float().numpy(), rtol=1e-5, atol=8e-6)
     s3 = nat.gemm_mid(dev(x), dev(W2[:, :D].copy()), ksplit=4)                      # the x Wov^T shape: 512 x 512 in 4 slices
     np.testing.assert_allclose(s3.double().sum(0).cpu().numpy(), (T(x) @ T(W2[:, :D]).T).numpy(), rtol=1e-5, atol=4e-6)
     # gemm_w4 (what the loop runs): 32 x 16 tiles, four waves a quarter of the K slice each
-    u4 = nat.gemm_w4(dev(x), dev(W1), dev(b1), "gelu")                              # complete, bias + GELU epilogue (K = 512: 128 per wave)
+    u4 = nat.gemm_w4(dev(x), dev(W1), dev(b1), "gelu")                              # complete, bias + GELU epilogue (K = 512: 8 waves x 64)
     np.testing.assert_allclose(u4.cpu().numpy(), u_ref.float().numpy(), rtol=1e-5, atol=4e-6)
-    un = u_ref.float().numpy()
     for ks in (4, 8):                                                               # u W2^T in 4 (128 per wave) / 8 (64 per wave) raw slices
         s4 = nat.gemm_w4(dev(un), dev(W2), ksplit=ks)
         assert s4.shape == (ks, M, D)

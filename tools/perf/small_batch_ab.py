@@ -1,12 +1,13 @@
 """Reverse-loop latency at collector / act() batch sizes (eval mode, hipGraph replay as the product runs it): the <= 128-row loop on the split-K
-pipeline (gemm_mid slabs folded by the following adaLN: every layer spread over 32..256 workgroups) against the weight-streaming skinny / panel kernels."""
+pipeline (gemm_w4: 32 x 16 tiles, waves split K, slabs folded by the following adaLN: every layer spread over 16..128 workgroups per 32 rows) against the
+weight-streaming skinny / panel kernels."""
 import sys, os, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, R + "/active-inference-diffusion_amd"); sys.path.insert(0, R)
 import torch, bench
 from aid_amd import _native as nat
 agent = bench.make_agent(torch.device("cuda")); ai = agent.active_inference
 ai.eval()
-for mode, name in ((-2, "skinny / panel kernels"), (-3, "gemm_mid, x W1^T unsplit"), (-4, "gemm_mid, W1 fold in W2"), (-1, "gemm_w4 pipeline")):
+for mode, name in ((-2, "skinny / panel kernels"), (-1, "gemm_w4 pipeline")):
     nat.lib().aid_denoise_debug(mode)
     ai.__dict__.get("_denoise_graphs", {}).clear(); torch.cuda.synchronize()
     for B in (1, 4, 8, 16, 32, 64, 96, 128):

@@ -348,6 +348,25 @@ def conv3_igemm(W, x_cnhw, stride: int):
     return out
 
 
+def conv3_igemm_tm(W, x_cnhw, stride: int, flip_transpose: bool = False):
+    """The same through the tap-major kernels: the weights are re-ordered (aid_conv3_tapmajor_weights) and aid_conv3_igemm_tm runs.  flip_transpose: W is the
+    FORWARD weight [Cout_fwd, ldw] of a stride-1 conv and x is dy [Cout_fwd, B, H, H]: the result is the data gradient [Cin_fwd, B, H, H] (Cin_fwd = ldw-implied)."""
+    if not flip_transpose:
+        Cin, B, Hi, _ = x_cnhw.shape; Cout = W.shape[0]
+        Wtm = torch.empty_like(W)
+        check(lib().aid_conv3_tapmajor_weights(_ptr(W), W.shape[1], _ptr(Wtm), W.shape[1], Cin, Cout, 0, _stream()), "aid_conv3_tapmajor_weights")
+    else:
+        Cout_f, B, Hi, _ = x_cnhw.shape; Cin_f = W.shape[1] // 9
+        ldwt = (Cout_f * 9 + 3) // 4 * 4
+        Wtm = torch.empty(Cin_f, ldwt, device=W.device, dtype=torch.float32)
+        check(lib().aid_conv3_tapmajor_weights(_ptr(W), W.shape[1], _ptr(Wtm), ldwt, Cin_f, Cout_f, 1, _stream()), "aid_conv3_tapmajor_weights")
+        Cin, Cout = Cout_f, Cin_f
+    Ho = (Hi + 2 - 3) // stride + 1
+    out = torch.empty(Cout, B, Ho, Ho, device=W.device, dtype=torch.float32)
+    check(lib().aid_conv3_igemm_tm(_ptr(Wtm), Wtm.shape[1], _ptr(x_cnhw), _ptr(out), Cin, Cout, B, Hi, Ho, stride, _stream()), "aid_conv3_igemm_tm")
+    return out
+
+
 def conv3_flip_weights(W, Cin: int):
     Cout = W.shape[0]; ldwt = (Cout * 9 + 3) // 4 * 4
     Wt = torch.empty(Cin, ldwt, device=W.device, dtype=torch.float32)

@@ -495,21 +495,23 @@ __global__ void sn_rowdot_kernel(const float* __restrict__ w, const float* __res
     const float t = wg_sum256(s, sh);
     if (threadIdx.x == 0) part[c] = u[c] * t;
 }
-__global__ void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ part, int Cout, int K, int Kp, float* __restrict__ w_eff) {
+// tm_cin > 0: the image is written tap-major, position k' = tap tm_cin + ci holds w[c][ci 9 + tap] (3x3 convs; conv_igemm.hip, TAPM)
+__device__ __forceinline__ int weight_src_k(int k, int tm_cin) { return tm_cin > 0 ? (k % tm_cin) * 9 + k / tm_cin : k; }
+__global__ void sn_scale_kernel(const float* __restrict__ w, const float* __restrict__ part, int Cout, int K, int Kp, float* __restrict__ w_eff, int tm_cin) {
     __shared__ float sh[16];
     float s = 0.f;
     for (int c = threadIdx.x; c < Cout; c += blockDim.x) s += part[c];
     const float sigma = wg_sum256(s, sh);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (size_t)Cout * Kp; i += (size_t)gridDim.x * blockDim.x) {
         const int c = i / Kp, k = i % Kp;
-        w_eff[i] = k < K ? w[(size_t)c * K + k] / sigma : 0.f;
+        w_eff[i] = k < K ? w[(size_t)c * K + weight_src_k(k, tm_cin)] / sigma : 0.f;
     }
 }
-__global__ void pad_weight_kernel(const float* __restrict__ w, int Cout, int K, int Kp, float* __restrict__ w_eff) {
+__global__ void pad_weight_kernel(const float* __restrict__ w, int Cout, int K, int Kp, float* __restrict__ w_eff, int tm_cin) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)Cout * Kp) return;
     const int c = i / Kp, k = i % Kp;
-    w_eff[i] = k < K ? w[(size_t)c * K + k] : 0.f;
+    w_eff[i] = k < K ? w[(size_t)c * K + weight_src_k(k, tm_cin)] : 0.f;
 }
 // y[c][r][Y][X] = act( IN( src + bias ) [+ add] ),  src = x[c][r][Y][X]  or, with shuffle, x[4c + 2(Y&1) + (X&1)][r][Y/2][X/2]
 // one workgroup per (c, r); H, W are the OUTPUT sizes
@@ -614,10 +616,10 @@ __global__ void sigmoid_nchw_kernel(const float* __restrict__ x, const float* __
     out[((size_t)r * C + c) * HW + p] = 1.0f / (1.0f + expf(-v));
 }
 
-struct ConvW { const float* w_eff; int cin, cout, Kp; };
+struct ConvW { const float* w_eff; int cin, cout, Kp; int tm; };      // tm: w_eff rows are tap-major, k' = tap cin + ci (3x3 convs whose cin allows it)
 // out[Cout][R*H*W] = 3x3 conv of x (stride 1, pad 1) as an implicit GEMM (conv_igemm.hip: nothing of size 9 Cin x R H W is written)
 static int conv3_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
-    return conv3_igemm(cw.w_eff, cw.Kp, x, out, cw.cin, cw.cout, R, H, H, 1, s);
+    return conv3_igemm_ex(cw.w_eff, cw.Kp, x, out, cw.cin, cw.cout, R, H, H, 1, cw.tm, s);
 }
 static int conv1_fwd(const ConvW& cw, const float* x, int R, int H, float* out, hipStream_t s) {
     const size_t N = (size_t)R * H * H;
@@ -627,16 +629,17 @@ static int conv1_fwd(const ConvW& cw, const float* x, int R, int H, float* out, 
 }
 static int prep_weight(const AidSNConv& c, int cin, int cout, int k, Workspace& ws, ConvW& out, hipStream_t s) {
     const int K = cin * k * k, Kp = (K + 31) / 32 * 32;
+    const int tm = (k == 3 && conv3_tapmajor_ok(cin, cout)) ? 1 : 0;
     float* w_eff = ws.f32((size_t)cout * Kp); AID_WS_OK(ws);
     if (c.u) {
         float* part = ws.f32(cout); AID_WS_OK(ws);
         hipLaunchKernelGGL(sn_rowdot_kernel, dim3(cout), dim3(256), 0, s, c.w, c.u, c.v, K, part);
-        hipLaunchKernelGGL(sn_scale_kernel, dim3(64), dim3(256), 0, s, c.w, part, cout, K, Kp, w_eff);
+        hipLaunchKernelGGL(sn_scale_kernel, dim3(64), dim3(256), 0, s, c.w, part, cout, K, Kp, w_eff, tm ? cin : 0);
     } else {
-        L1D(pad_weight_kernel, (size_t)cout * Kp, s, c.w, cout, K, Kp, w_eff);
+        L1D(pad_weight_kernel, (size_t)cout * Kp, s, c.w, cout, K, Kp, w_eff, tm ? cin : 0);
     }
     AID_LAUNCH_CHECK();
-    out.w_eff = w_eff; out.cin = cin; out.cout = cout; out.Kp = Kp;
+    out.w_eff = w_eff; out.cin = cin; out.cout = cout; out.Kp = Kp; out.tm = tm;
     return AID_OK;
 }
 }  // namespace aid
@@ -682,7 +685,12 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
                            train, sv.w_eff[i], sv.sn[i]);
         AID_LAUNCH_CHECK();
         (void)N;
-        AID_TRY(conv3_igemm(sv.w_eff[i], g.Kp[i], cur, sv.conv_out[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], s));
+        if (conv3_tapmajor_ok(g.cin[i], g.cout[i])) {      // tap-major contraction (conv_igemm.hip, TAPM): the weights re-ordered once per pass (<= 1.2 MB)
+            float* wtm = ws.f32((size_t)g.cout[i] * g.Kp[i]); AID_WS_OK(ws);
+            AID_TRY(conv3_tapmajor_weights(sv.w_eff[i], g.Kp[i], wtm, g.Kp[i], g.cin[i], g.cout[i], s));
+            AID_TRY(conv3_igemm_ex(wtm, g.Kp[i], cur, sv.conv_out[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], 1, s));
+        } else
+            AID_TRY(conv3_igemm(sv.w_eff[i], g.Kp[i], cur, sv.conv_out[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], s));
         {
             const int hw = g.ho[i] * g.ho[i], cpg = g.cout[i] / g.G[i];
             if (gn_reg_ok(g.cout[i], g.G[i], hw, sv.conv_out[i], sv.act[i])) {
@@ -789,10 +797,11 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         AID_LAUNCH_CHECK();
         if (i > 0) {   // gradient wrt act[i-1]: the stride-1 conv of dconv with the flipped, channel-transposed weights
             AID_REQUIRE(g.stride[i] == 1, AID_E_SHAPE, "aid_encoder_backward: data gradient of a strided conv is not built (layer %d)", i);
-            AID_TRY(conv3_flip_weights(sv.w_eff[i], g.Kp[i], wflip, ldwt, g.cin[i], g.cout[i], s));
+            const int tmj = conv3_tapmajor_ok(g.cout[i], g.cin[i]) ? 1 : 0;      // the data-gradient conv contracts over (tap, co)
+            AID_TRY(conv3_flip_weights(sv.w_eff[i], g.Kp[i], wflip, ldwt, g.cin[i], g.cout[i], s, tmj));
             // dact (gradient wrt act[i]) was consumed by the two GroupNorm kernels above: the gradient wrt act[i-1] goes straight into it
             // (cin*hi*hi*B <= 256*HW*B for layers 1..3)
-            AID_TRY(conv3_igemm(wflip, ldwt, dconv, dact, g.cout[i], g.cin[i], B, g.ho[i], g.hi[i], 1, s));
+            AID_TRY(conv3_igemm_ex(wflip, ldwt, dconv, dact, g.cout[i], g.cin[i], B, g.ho[i], g.hi[i], 1, tmj, s));
             dcur = dact;
         }
         ws.release(mark);
@@ -1140,7 +1149,7 @@ struct PlainConv { const float* w_eff; int cin, cout, K, Kp; };
 static int prep_plain(const float* w, int cin, int cout, int k, Workspace& ws, PlainConv& out, hipStream_t s) {
     const int K = cin * k * k, Kp = (K + 31) / 32 * 32;
     float* w_eff = ws.f32((size_t)cout * Kp); AID_WS_OK(ws);
-    L1D(pad_weight_kernel, (size_t)cout * Kp, s, w, cout, K, Kp, w_eff);
+    L1D(pad_weight_kernel, (size_t)cout * Kp, s, w, cout, K, Kp, w_eff, 0);
     out.w_eff = w_eff; out.cin = cin; out.cout = cout; out.K = K; out.Kp = Kp;
     return AID_OK;
 }

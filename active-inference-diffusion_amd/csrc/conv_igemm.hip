@@ -33,7 +33,12 @@ struct ConvIgArgs {
 };
 
 // 4 waves as (4 / WN) x WN; a wave owns TM accumulator blocks of 32 x 32 stacked along the output channels: BM = 32 TM 4 / WN rows, BN = 32 WN columns
-template <int TM, int BK, int WN>
+// TAPM: the contraction index is tap-major, k' = (kh 3 + kw) Cin + ci, and Cin % BK == 0, so a K stage is BK channels of ONE tap: the tap's offset and
+// border validity are computed once per stage and a thread's gathers differ by whole planes only.  (With k = ci 9 + tap every gathered element had its
+// own tap: decomposing it, testing its mask bit, selecting its address and carrying (tap, ci) to the next stage was 20 % of the kernel's time on the
+// encoder's widest layer - tools/perf/conv_ablation.py: 89 -> 111 TFLOP/s with that arithmetic removed, 113 with the gathers themselves removed.)
+// The weights are stored in the same order: conv3_tapmajor_weights / conv3_flip_weights(tap_major).
+template <int TM, int BK, int WN, int DBG = 0, bool TAPM = false>
 __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
     constexpr int BM = 32 * TM * (4 / WN), BN = 32 * WN, ALD = BK + 4, BLD = BN + 4, A_FL = BM * ALD, B_FL = BK * BLD;
     constexpr int PA = BM * BK / 4 / 256, KR = 256 / BN, PBG = BK / KR, CPRA = BK / 4;      // float4 A pieces / gathered B elements per thread per stage
@@ -73,12 +78,27 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
     int kr9[PBG]; long kco[PBG];
 #pragma unroll
     for (int j = 0; j < PBG; ++j) { const int k = kr + KR * j, ci = k / 9; kr9[j] = k - 9 * ci; kco[j] = (long)ci * plane; }
+    int tm_tap = 0, tm_cb = 0;                       // TAPM: the (tap, channel block) of the next stage to load
+    const int tm_ncb = TAPM ? g.Cin / BK : 1;
+    const long tm_kr = (long)kr * plane, tm_js = (long)KR * plane, tm_cbs = (long)BK * plane;
     auto load_stage = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int f = tid + 256 * i, row = f / CPRA, c4 = f % CPRA;
             const int gr = min(m0 + row, g.Cout - 1), gk = min(kt * BK + 4 * c4, g.ldw - 4);
-            ra[i] = *reinterpret_cast<const ig_f32x4*>(g.W + (size_t)gr * g.ldw + gk);
+            if constexpr (DBG != 3) ra[i] = *reinterpret_cast<const ig_f32x4*>(g.W + (size_t)gr * g.ldw + gk);
+            else ra[i] = (ig_f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+        if constexpr (TAPM) {
+            const int kh = (tm_tap * 11) >> 5, kw = tm_tap - 3 * kh;
+            const bool ok = (vm >> tm_tap) & 1u;
+            const float* src = ok ? g.x + (base + kh * g.Wi + kw + tm_kr + (long)tm_cb * tm_cbs) : g.x;
+            const long js = ok ? tm_js : 0;
+#pragma unroll
+            for (int j = 0; j < PBG; ++j) rb[j] = src[(long)j * js];
+            rbm = ok ? 0xffffffffu : 0u;
+            if (++tm_cb == tm_ncb) { tm_cb = 0; ++tm_tap; }
+            return;
         }
         rbm = 0;
 #pragma unroll
@@ -86,7 +106,9 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
             const int k = kt * BK + kr + KR * j;
             const int r9 = kr9[j], kh = (r9 * 11) >> 5, kw = r9 - 3 * kh;          // r9 / 3 for r9 < 9
             const bool ok = k < g.K && ((vm >> r9) & 1u);
-            rb[j] = g.x[ok ? kco[j] + base + kh * g.Wi + kw : 0];
+            if constexpr (DBG == 1 || DBG == 2) rb[j] = 1.f;
+            else if constexpr (DBG == 4) rb[j] = g.x[base + (long)j * plane + g.Wi + 1];      // (>= 0: base >= -Wi - 1)
+            else rb[j] = g.x[ok ? kco[j] + base + kh * g.Wi + kw : 0];
             rbm |= (ok ? 1u : 0u) << j;
             // k += BK for the next stage (stages are loaded in order, each exactly once)
             kr9[j] += BK % 9; kco[j] += (long)(BK / 9) * plane;
@@ -102,7 +124,7 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
             *reinterpret_cast<ig_f32x4*>(As + buf * A_FL + row * ALD + 4 * c4) = v;
         }
 #pragma unroll
-        for (int j = 0; j < PBG; ++j) Bs[buf * B_FL + (kr + KR * j) * BLD + nl] = ((rbm >> j) & 1u) ? rb[j] : 0.f;
+        for (int j = 0; j < PBG; ++j) { if constexpr (DBG != 2) Bs[buf * B_FL + (kr + KR * j) * BLD + nl] = ((rbm >> j) & 1u) ? rb[j] : 0.f; }
     };
     load_stage(0); store_stage(0, 0);
     __syncthreads();
@@ -137,23 +159,48 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
         }
 }
 
+static int g_ig_dbg = 0;
+// tap-major kernels need whole BK-channel blocks per tap: BK = 32 for the <= 32-output-channel tile, 16 otherwise
+bool conv3_tapmajor_ok(int Cin, int Cout) { return Cin % (Cout <= 32 ? 32 : 16) == 0; }
+int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, int w_tap_major, hipStream_t s);
 int conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, hipStream_t s) {
+    return conv3_igemm_ex(W, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, 0, s);
+}
+// w_tap_major: W is [Cout][(kh 3 + kw) Cin + ci] (conv3_tapmajor_weights); needs conv3_tapmajor_ok(Cin, Cout)
+int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, int w_tap_major, hipStream_t s) {
     AID_REQUIRE(W && x && out, AID_E_NULL, "conv3_igemm: null operand");
     AID_REQUIRE(Cin > 0 && Cout > 0 && B > 0 && (stride == 1 || stride == 2) && ldw >= 9 * Cin && ldw % 4 == 0 && ((((uintptr_t)W) & 15) == 0), AID_E_SHAPE,
                 "conv3_igemm: Cin=%d Cout=%d stride=%d ldw=%d", Cin, Cout, stride, ldw);
+    AID_REQUIRE(!w_tap_major || conv3_tapmajor_ok(Cin, Cout), AID_E_SHAPE, "conv3_igemm: tap-major weights need Cin %% %d == 0 (Cin=%d)", Cout <= 32 ? 32 : 16, Cin);
     ConvIgArgs g; memset(&g, 0, sizeof(g));
     g.W = W; g.ldw = ldw; g.x = x; g.out = out; g.Cin = Cin; g.Cout = Cout; g.B = B; g.Hi = Hi; g.Wi = Hi; g.Ho = Ho; g.Wo = Ho; g.stride = stride; g.K = 9 * Cin;
     g.N = (long)B * Ho * Ho;
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * Cout * g.K * (double)g.N, 4.0 * ((double)Cout * g.K + (double)Cin * B * Hi * Hi + (double)Cout * g.N));
-    prof.m = Cout; prof.n = (int)(g.N > 2000000000L ? 2000000000L : g.N); prof.k = g.K; prof.layout = stride; prof.variant = 31;
+    prof.m = Cout; prof.n = (int)(g.N > 2000000000L ? 2000000000L : g.N); prof.k = g.K; prof.layout = stride + (w_tap_major ? 8 : 0); prof.variant = 31;
     // 128 x 64 tiles in 16-deep stages (29 KB of LDS: five workgroups per CU; measured 93 TFLOP/s on the 256 x 451 584 x 1152 layer against 83
     // with 32-deep stages at two per CU and 74 with 64 x 64 tiles, which gather every column four times); 64-row tiles for Cout <= 64
     // up to 32 output channels: 32 x 128 tiles (a 64-row tile would be half empty); up to 64: 64 x 64 in 16-deep stages (19 KB)
 #define IG_LAUNCH(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
         hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
-    if (Cout <= 32) IG_LAUNCH(1, 32, 4);
+    if (g_ig_dbg && Cout > 64) {      // timing experiments (aid_conv_debug; results are wrong by construction)
+#define IG_LAUNCH_D(D_) do { constexpr size_t lds = sizeof(float) * 2 * (128 * 20 + 16 * 68); \
+        hipLaunchKernelGGL((conv3_igemm_kernel<2, 16, 2, D_>), dim3((unsigned)((g.N + 63) / 64), (Cout + 127) / 128), dim3(256), lds, s, g); } while (0)
+        if (g_ig_dbg == 1) IG_LAUNCH_D(1); else if (g_ig_dbg == 2) IG_LAUNCH_D(2); else if (g_ig_dbg == 3) IG_LAUNCH_D(3); else IG_LAUNCH_D(4);
+#undef IG_LAUNCH_D
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
+#define IG_LAUNCH_T(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
+        hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_, 0, true>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
+    if (w_tap_major) {
+        if (Cout <= 32) IG_LAUNCH_T(1, 32, 4);
+        else if (Cout <= 64) IG_LAUNCH_T(1, 16, 2);
+        else IG_LAUNCH_T(2, 16, 2);
+    }
+    else if (Cout <= 32) IG_LAUNCH(1, 32, 4);
     else if (Cout <= 64) IG_LAUNCH(1, 16, 2);
     else IG_LAUNCH(2, 16, 2);
+#undef IG_LAUNCH_T
 #undef IG_LAUNCH
     AID_LAUNCH_CHECK();
     return AID_OK;
@@ -168,9 +215,32 @@ __global__ void conv3_flip_weights_kernel(const float* __restrict__ W, int ldw, 
     if (k < Cout * 9) { const int co = k / 9, r9 = k % 9, kh = r9 / 3, kw = r9 % 3; v = W[(size_t)co * ldw + ci * 9 + (2 - kh) * 3 + (2 - kw)]; }
     Wt[i] = v;
 }
-int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s) {
+// tap-major forms.  Wtm[co][tap Cin + ci] = W[co][ci 9 + tap];   flipped: Wt[ci][tap Cout + co] = W[co][ci 9 + (8 - tap)]
+__global__ void conv3_tapmajor_weights_kernel(const float* __restrict__ W, int ldw, float* __restrict__ Wtm, int ldwt, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cout * ldwt) return;
+    const int co = i / ldwt, k = i % ldwt;
+    float v = 0.f;
+    if (k < Cin * 9) { const int tap = k / Cin, ci = k % Cin; v = W[(size_t)co * ldw + ci * 9 + tap]; }
+    Wtm[i] = v;
+}
+__global__ void conv3_flip_weights_tm_kernel(const float* __restrict__ W, int ldw, float* __restrict__ Wt, int ldwt, int Cin, int Cout) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Cin * ldwt) return;
+    const int ci = i / ldwt, k = i % ldwt;
+    float v = 0.f;
+    if (k < Cout * 9) { const int tap = k / Cout, co = k % Cout; v = W[(size_t)co * ldw + ci * 9 + (8 - tap)]; }
+    Wt[i] = v;
+}
+int conv3_tapmajor_weights(const float* W, int ldw, float* Wtm, int ldwt, int Cin, int Cout, hipStream_t s) {
+    AID_REQUIRE(ldwt >= 9 * Cin && ldwt % 4 == 0, AID_E_SHAPE, "conv3_tapmajor_weights: ldwt=%d", ldwt);
+    hipLaunchKernelGGL(conv3_tapmajor_weights_kernel, dim3((Cout * ldwt + 255) / 256), dim3(256), 0, s, W, ldw, Wtm, ldwt, Cin, Cout);
+    AID_LAUNCH_CHECK(); return AID_OK;
+}
+int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s, int tap_major) {
     AID_REQUIRE(ldwt >= 9 * Cout && ldwt % 4 == 0, AID_E_SHAPE, "conv3_flip_weights: ldwt=%d", ldwt);
-    hipLaunchKernelGGL(conv3_flip_weights_kernel, dim3((Cin * ldwt + 255) / 256), dim3(256), 0, s, W, ldw, Wt, ldwt, Cin, Cout);
+    if (tap_major) hipLaunchKernelGGL(conv3_flip_weights_tm_kernel, dim3((Cin * ldwt + 255) / 256), dim3(256), 0, s, W, ldw, Wt, ldwt, Cin, Cout);
+    else hipLaunchKernelGGL(conv3_flip_weights_kernel, dim3((Cin * ldwt + 255) / 256), dim3(256), 0, s, W, ldw, Wt, ldwt, Cin, Cout);
     AID_LAUNCH_CHECK(); return AID_OK;
 }
 
@@ -306,6 +376,14 @@ int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin,
 using namespace aid;
 extern "C" {
 // Unit-test entries for the implicit-GEMM convolution (W: [Cout][ldw] with ldw >= 9 Cin a multiple of 4, x: CNHW [Cin][B][Hi][Hi], out / dy: [Cout][B Ho Ho]).
+int aid_conv_debug(int mode) { aid::g_ig_dbg = mode; return AID_OK; }
+int aid_conv3_igemm_tm(const float* Wtm, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {
+    return conv3_igemm_ex(Wtm, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, 1, (hipStream_t)stream);
+}
+int aid_conv3_tapmajor_weights(const float* W, int ldw, float* Wtm, int ldwt, int Cin, int Cout, int flip_transpose, void* stream) {
+    AID_REQUIRE(W && Wtm, AID_E_NULL, "aid_conv3_tapmajor_weights: null tensor");
+    return flip_transpose ? conv3_flip_weights(W, ldw, Wtm, ldwt, Cin, Cout, (hipStream_t)stream, 1) : conv3_tapmajor_weights(W, ldw, Wtm, ldwt, Cin, Cout, (hipStream_t)stream);
+}
 int aid_conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {
     return conv3_igemm(W, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, (hipStream_t)stream);
 }
@@ -314,6 +392,6 @@ int aid_conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int 
 }
 int aid_conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, void* stream) {
     AID_REQUIRE(W && Wt, AID_E_NULL, "aid_conv3_flip_weights: null");
-    return conv3_flip_weights(W, ldw, Wt, ldwt, Cin, Cout, (hipStream_t)stream);
+    return conv3_flip_weights(W, ldw, Wt, ldwt, Cin, Cout, (hipStream_t)stream, 0);
 }
 }

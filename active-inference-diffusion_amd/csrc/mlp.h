@@ -92,7 +92,11 @@ int conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, in
 // dW[co][k] (row stride ldw) = sum_n dy[co][n] X(k, n); slab: scratch [S][Cout][ldw] (S row chunks folded in order)
 int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, hipStream_t s);
 // Wt[ci][co 9 + kh 3 + kw] = W[co][ci 9 + (2 - kh) 3 + (2 - kw)]: the data gradient of a stride-1 conv is conv3_igemm(Wt, dy) with Cin <-> Cout
-int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s);
+int conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, hipStream_t s, int tap_major = 0);
+// tap-major contraction order k' = (kh 3 + kw) Cin + ci (conv_igemm.hip, TAPM): needs Cin % 16 == 0 (% 32 when Cout <= 32)
+bool conv3_tapmajor_ok(int Cin, int Cout);
+int conv3_tapmajor_weights(const float* W, int ldw, float* Wtm, int ldwt, int Cin, int Cout, hipStream_t s);                      // Wtm[co][tap Cin + ci] = W[co][ci 9 + tap]
+int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, int w_tap_major, hipStream_t s);
 
 // ---- ConvDecoder + pixel estimator feature side (conv.hip)
 int conv_decoder_fwd(const AidConvDecoder& d, int R, const float* z, float* out, Workspace& ws, hipStream_t s);

@@ -111,6 +111,12 @@ int aid_gemm_ksplit_add(const float* A, int lda, const float* B, int ldb, float*
  *   aid_conv3_flip_weights  Wt[ci][co 9 + kh 3 + kw] = W[co][ci 9 + (2-kh) 3 + (2-kw)]: dx = aid_conv3_igemm(Wt, dy) with Cin <-> Cout (stride 1)
  *   aid_conv3_igemm_dw   dW[co][k] = sum_n dy[co][n] X(k, n); slab: scratch [S][Cout][ldw]; B Ho Ho must be a multiple of 4 */
 int aid_conv3_igemm(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream);
+/* The same convolution with the contraction in TAP-MAJOR order, k' = (kh 3 + kw) Cin + ci (what the encoder / ConvDecoder run whenever Cin % 16 == 0, % 32 for
+ * Cout <= 32: a K stage is then whole channels of one tap and the operand loader needs no per-element tap arithmetic).  Wtm [Cout][ldw] holds the weights in that
+ * order: aid_conv3_tapmajor_weights(W, ...) with flip_transpose = 0 (forward) or 1 (Wt[ci][tap Cout + co] = W[co][ci 9 + (8 - tap)]: the data gradient,
+ * Cin <-> Cout as for aid_conv3_flip_weights). */
+int aid_conv3_igemm_tm(const float* Wtm, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream);
+int aid_conv3_tapmajor_weights(const float* W, int ldw, float* Wtm, int ldwt, int Cin, int Cout, int flip_transpose, void* stream);
 int aid_conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin, int Cout, int B, int Hi, int Ho, int stride, float* slab, int S, void* stream);
 int aid_conv3_flip_weights(const float* W, int ldw, float* Wt, int ldwt, int Cin, int Cout, void* stream);
 

@@ -683,10 +683,12 @@ def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):
     np.testing.assert_allclose(C.cpu().numpy(), outs[0].cpu().numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(K))
 
 
-@pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2)])
+@pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2),
+                                                   (32, 32, 3, 21, 1), (64, 32, 2, 30, 1), (32, 3, 2, 17, 1), (16, 80, 3, 13, 2)])
 def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     """csrc/conv_igemm.hip against torch's conv2d on the CPU (fp64): forward (border taps, stride 2, ragged channel counts), the data
-    gradient through the flipped weights, the weight gradient (slab-split contraction over B Ho Wo)."""
+    gradient through the flipped weights, the weight gradient (slab-split contraction over B Ho Wo) - and, where the channel counts allow it, the
+    TAP-MAJOR kernels the encoder / ConvDecoder run (weights re-ordered to k' = tap Cin + ci; forward and data gradient), every tile shape."""
     import torch.nn.functional as F
     rng = np.random.default_rng(Cin * 100 + Cout)
     x = rng.standard_normal((B, Cin, Hi, Hi)).astype(np.float32)
@@ -709,3 +711,10 @@ def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
         Wt = nat.conv3_flip_weights(dev(W), Cin)
         dx = nat.conv3_igemm(Wt, dy_cnhw, 1)
         np.testing.assert_allclose(dx.cpu().numpy().transpose(1, 0, 2, 3), xt.grad.numpy(), rtol=2e-5, atol=5e-5)
+    tm_ok = lambda ci, co: ci % (32 if co <= 32 else 16) == 0
+    if tm_ok(Cin, Cout):
+        out_tm = nat.conv3_igemm_tm(dev(W), x_cnhw, stride)
+        np.testing.assert_allclose(out_tm.cpu().numpy().transpose(1, 0, 2, 3), ref.detach().numpy(), rtol=2e-5, atol=2e-5)
+    if stride == 1 and tm_ok(Cout, Cin):
+        dx_tm = nat.conv3_igemm_tm(dev(W), dy_cnhw, 1, flip_transpose=True)
+        np.testing.assert_allclose(dx_tm.cpu().numpy().transpose(1, 0, 2, 3), xt.grad.numpy(), rtol=2e-5, atol=5e-5)

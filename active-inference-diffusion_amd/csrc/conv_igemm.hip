@@ -38,7 +38,13 @@ struct ConvIgArgs {
 // own tap: decomposing it, testing its mask bit, selecting its address and carrying (tap, ci) to the next stage was 20 % of the kernel's time on the
 // encoder's widest layer - tools/perf/conv_ablation.py: 89 -> 111 TFLOP/s with that arithmetic removed, 113 with the gathers themselves removed.)
 // The weights are stored in the same order: conv3_tapmajor_weights / conv3_flip_weights(tap_major).
-template <int TM, int BK, int WN, int DBG = 0, bool TAPM = false>
+// VEC4 (TAPM, stride 1, B Ho Wo % 4 == 0): with stride 1 and pad 1 the input index of tap (kh, kw) at output pixel n is n + (kh - 1) W + (kw - 1) - a constant
+// offset, rows and images included - so four consecutive pixels of one channel are ONE 16-byte load (4-byte aligned) and one ds_write_b128, masked by the four
+// pixels' border bits of that tap: a quarter of the vector-memory and LDS-write instructions of the element-wise gather (the ablation priced the gathers +
+// their LDS writes at 12 % of the tap-major kernel).  The two loads in the whole grid that would start before the tensor or end behind it are clamped and
+// their elements shifted back when they are written to LDS.
+typedef float ig_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+template <int TM, int BK, int WN, int DBG = 0, bool TAPM = false, bool VEC4 = false>
 __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
     constexpr int BM = 32 * TM * (4 / WN), BN = 32 * WN, ALD = BK + 4, BLD = BN + 4, A_FL = BM * ALD, B_FL = BK * BLD;
     constexpr int PA = BM * BK / 4 / 256, KR = 256 / BN, PBG = BK / KR, CPRA = BK / 4;      // float4 A pieces / gathered B elements per thread per stage
@@ -81,6 +87,26 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
     int tm_tap = 0, tm_cb = 0;                       // TAPM: the (tap, channel block) of the next stage to load
     const int tm_ncb = TAPM ? g.Cin / BK : 1;
     const long tm_kr = (long)kr * plane, tm_js = (long)KR * plane, tm_cbs = (long)BK * plane;
+    // VEC4: this thread's pixel quad (the same for all its pieces) and its k rows kq + KQ i within a stage
+    constexpr int QN = BN / 4, KQ = 256 / QN, PQ = VEC4 ? BK / KQ : 1;
+    const int vq = tid % QN, vkq = tid / QN;
+    ig_f32x4 rbv[PQ]; int rbd[PQ]; unsigned rbn = 0;
+    unsigned vlo = 0, vhi = 0;                       // border bits of the quad's four pixels: nibble `tap` of (vhi:vlo) = pixels 0..3 valid at that tap
+    const long vn4 = n0 + 4 * vq, vtotal = (long)g.Cin * plane - 4;
+    if constexpr (VEC4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const long ne = vn4 + e;
+            if (ne < g.N) {
+                const int wo_ = (int)(ne % g.Wo); const long t_ = ne / g.Wo; const int ho_ = (int)(t_ % g.Ho);
+#pragma unroll
+                for (int tp = 0; tp < 9; ++tp) {
+                    const int hh = ho_ + tp / 3 - 1, ww = wo_ + tp % 3 - 1;
+                    if (hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) { if (tp < 8) vlo |= 1u << (4 * tp + e); else vhi |= 1u << e; }
+                }
+            }
+        }
+    }
     auto load_stage = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -88,6 +114,20 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
             const int gr = min(m0 + row, g.Cout - 1), gk = min(kt * BK + 4 * c4, g.ldw - 4);
             if constexpr (DBG != 3) ra[i] = *reinterpret_cast<const ig_f32x4*>(g.W + (size_t)gr * g.ldw + gk);
             else ra[i] = (ig_f32x4){1.f, 1.f, 1.f, 1.f};
+        }
+        if constexpr (VEC4) {
+            const int kh = (tm_tap * 11) >> 5, kw = tm_tap - 3 * kh;
+            rbn = (tm_tap < 8 ? vlo >> (4 * tm_tap) : vhi) & 15u;
+            const long idx0 = vn4 + (long)(kh - 1) * g.Wi + (kw - 1) + ((long)tm_cb * BK + vkq) * plane;
+#pragma unroll
+            for (int i = 0; i < PQ; ++i) {
+                const long idx = idx0 + (long)(KQ * i) * plane;
+                const long idc = idx < 0 ? 0 : (idx > vtotal ? vtotal : idx);
+                rbd[i] = (int)(idc - idx);
+                rbv[i] = *reinterpret_cast<const ig_f32x4u*>(g.x + idc);
+            }
+            if (++tm_cb == tm_ncb) { tm_cb = 0; ++tm_tap; }
+            return;
         }
         if constexpr (TAPM) {
             const int kh = (tm_tap * 11) >> 5, kw = tm_tap - 3 * kh;
@@ -122,6 +162,23 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
             ig_f32x4 v = ra[i];
             if (m0 + row >= g.Cout || kt * BK + 4 * c4 >= g.ldw) v = (ig_f32x4){0.f, 0.f, 0.f, 0.f};
             *reinterpret_cast<ig_f32x4*>(As + buf * A_FL + row * ALD + 4 * c4) = v;
+        }
+        if constexpr (VEC4) {
+#pragma unroll
+            for (int i = 0; i < PQ; ++i) {
+                ig_f32x4 v = rbv[i];
+                const int d = rbd[i];
+                if (d != 0) {                        // a load clamped at an end of the tensor (two in the grid): element e wants loaded[e - d]
+                    ig_f32x4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const int j = e - d; w[e] = j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : (j == 3 ? v[3] : 0.f))); }
+                    v = w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = ((rbn >> e) & 1u) ? v[e] : 0.f;
+                *reinterpret_cast<ig_f32x4*>(Bs + buf * B_FL + (vkq + KQ * i) * BLD + 4 * vq) = v;
+            }
+            return;
         }
 #pragma unroll
         for (int j = 0; j < PBG; ++j) { if constexpr (DBG != 2) Bs[buf * B_FL + (kr + KR * j) * BLD + nl] = ((rbm >> j) & 1u) ? rb[j] : 0.f; }
@@ -160,6 +217,7 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
 }
 
 static int g_ig_dbg = 0;
+static int g_ig_vec4 = 1;        // aid_conv_debug(10 / 11): four-pixel vector gathers of the tap-major kernels off / on (A/B timing)
 // tap-major kernels need whole BK-channel blocks per tap: BK = 32 for the <= 32-output-channel tile, 16 otherwise
 bool conv3_tapmajor_ok(int Cin, int Cout) { return Cin % (Cout <= 32 ? 32 : 16) == 0; }
 int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, int w_tap_major, hipStream_t s);
@@ -192,7 +250,15 @@ int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin,
     }
 #define IG_LAUNCH_T(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
         hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_, 0, true>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
-    if (w_tap_major) {
+#define IG_LAUNCH_V(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
+        hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_, 0, true, true>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
+    const bool vec4 = w_tap_major && stride == 1 && Hi == Ho && g.N % 4 == 0 && (long)Cin * B * Hi * Hi >= 8 && g_ig_vec4;
+    if (vec4) {
+        if (Cout <= 32) IG_LAUNCH_V(1, 32, 4);
+        else if (Cout <= 64) IG_LAUNCH_V(1, 16, 2);
+        else IG_LAUNCH_V(2, 16, 2);
+    }
+    else if (w_tap_major) {
         if (Cout <= 32) IG_LAUNCH_T(1, 32, 4);
         else if (Cout <= 64) IG_LAUNCH_T(1, 16, 2);
         else IG_LAUNCH_T(2, 16, 2);
@@ -200,6 +266,7 @@ int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin,
     else if (Cout <= 32) IG_LAUNCH(1, 32, 4);
     else if (Cout <= 64) IG_LAUNCH(1, 16, 2);
     else IG_LAUNCH(2, 16, 2);
+#undef IG_LAUNCH_V
 #undef IG_LAUNCH_T
 #undef IG_LAUNCH
     AID_LAUNCH_CHECK();
@@ -376,7 +443,7 @@ int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin,
 using namespace aid;
 extern "C" {
 // Unit-test entries for the implicit-GEMM convolution (W: [Cout][ldw] with ldw >= 9 Cin a multiple of 4, x: CNHW [Cin][B][Hi][Hi], out / dy: [Cout][B Ho Ho]).
-int aid_conv_debug(int mode) { aid::g_ig_dbg = mode; return AID_OK; }
+int aid_conv_debug(int mode) { if (mode == 10) aid::g_ig_vec4 = 0; else if (mode == 11) aid::g_ig_vec4 = 1; else aid::g_ig_dbg = mode; return AID_OK; }
 int aid_conv3_igemm_tm(const float* Wtm, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {
     return conv3_igemm_ex(Wtm, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, 1, (hipStream_t)stream);
 }

@@ -12,7 +12,7 @@ for Cin, Cout, B, H, name in shapes:
     W = torch.randn(Cout, K, device="cuda") / K ** 0.5
     x = torch.randn(Cin, B, H, H, device="cuda")
     fl = 2.0 * Cout * K * B * H * H
-    for mode, what in ((0, "full kernel"), (4, "gather addresses fixed (no tap arithmetic), loads kept"), (1, "no global gathers"), (2, "no gathers, no B LDS writes"), (3, "no weight loads")):
+    for mode, what in ((0, "full kernel"),) + (((4, "gather addresses fixed (no tap arithmetic), loads kept"), (1, "no global gathers"), (2, "no gathers, no B LDS writes"), (3, "no weight loads")) if os.environ.get("ABLATE") else ()):
         L.aid_conv_debug(mode)
         for _ in range(3): nat.conv3_igemm(W, x, 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -20,9 +20,11 @@ for Cin, Cout, B, H, name in shapes:
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
         print(f"{name:40s} {what:55s} {dt*1e3:7.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s", flush=True)
     L.aid_conv_debug(0)
-    if Cin % 16 == 0:
+    for vec in ((10, "TAP-MAJOR kernel, element gathers"), (11, "TAP-MAJOR kernel, 4-pixel vector gathers")) if Cin % 16 == 0 else ():
+        L.aid_conv_debug(vec[0])
         for _ in range(3): nat.conv3_igemm_tm(W, x, 1)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): nat.conv3_igemm_tm(W, x, 1)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
-        print(f"{name:40s} {'TAP-MAJOR kernel (incl. the weight re-ordering launch)':55s} {dt*1e3:7.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s", flush=True)
+        print(f"{name:40s} {vec[1] + ' (+ re-ordering launch)':55s} {dt*1e3:7.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s", flush=True)
+    L.aid_conv_debug(11)

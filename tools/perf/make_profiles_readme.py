@@ -1,7 +1,7 @@
-"""Regenerates profiles/README.md from the committed rocprofv3 / bench artifacts of round 3 (run from the repo root, no GPU needed)."""
+"""Regenerates profiles/README.md from the committed rocprofv3 / bench artifacts of round 4 (run from the repo root, no GPU needed)."""
 import csv, json, os
 P = "profiles"
-R = "r03"          # the round whose artifacts this README describes (earlier rounds' files stay in profiles/ as history)
+R = "r04"          # the round whose artifacts this README describes (earlier rounds' files stay in profiles/ as history)
 bench = json.loads(open(os.path.join(P, R + "_bench.json")).read().strip().splitlines()[-1])
 rows = list(csv.DictReader(open(os.path.join(P, R + "_train_step_kernel_stats.csv"))))
 pmc = json.load(open(os.path.join(P, R + "_pmc_chain_summary.json")))
@@ -9,21 +9,26 @@ tot = sum(float(r["TotalDurationNs"]) for r in rows)
 out = []
 w = out.append
 short = lambda n: n.replace("void ", "").replace("aid::", "").split("(")[0]
-w("# profiles/ — rocprofv3 evidence, round 3\n")
-w("Regenerate this file with `python tools/perf/make_profiles_readme.py`; collect the inputs on the GPU box with `bash tools/perf/r03_profiles.sh`\n"
+w("# profiles/ — rocprofv3 evidence, round 4\n")
+w("Regenerate this file with `python tools/perf/make_profiles_readme.py`; collect the inputs on the GPU box with `bash tools/perf/r04_profiles.sh`\n"
   "(kernel stats of the bench command in both schedules, kernel stats per phase, PMC passes over one 256-row reverse loop) and\n"
-  "`python bench.py > profiles/r03_bench.json`.\n")
+  "`python bench.py > profiles/r04_bench.json`.\n")
 w("| file | what |\n|---|---|\n"
-  "| `r03_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags), extras included (`roofline_phases`, `other_configs`, `small_batch`) |\n"
-  "| `r03_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras`: the schedule that is timed (side stream + three concurrent 256-row chains).  bench.py reads this file to choose `roofline.kernel` by share of kernel time |\n"
-  "| `r03_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (every phase on one stream): the averages `roofline_single_stream*` is comparable with |\n"
-  "| `r03_phase_<phase>_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/phase_profile.py <phase>_cold 5`: ONE phase of the train_step in a cold process (5 calls: the phase's kernels only).  Phases: `elbo`, `rollout_bptt`, `efe` (rollout + estimator + BPTT; estimator = efe - rollout_bptt), `chain1` (one 256-row reverse loop), `chains3` (three concurrent), `value_dynamics`, `optimiser`, `pixel_epistemic` (SURVEY 8(f)-1 at 64 belief rows, S = 2) |\n"
-  "| `r03_pmc_chain_summary.json` | per-kernel averages of three PMC passes (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) over ONE 256-row reverse loop alone, launched directly: the kernels of the concurrent chains.  Counter collection on this pool does not survive concurrent streams; one chain alone runs exactly the kernels, shapes and launch geometry each of the three chains runs |\n"
-  "| `r03_bench_under_rocprof.json`, `r03_bench_no_overlap_under_rocprof.json` | the bench lines printed by the two profiled runs (slower: the profiler serialises the small kernels) |\n"
-  "| `r02_*`, `r01_*`, `gemm_*_r01.txt` | earlier rounds' artifacts, kept as history (`r02_pmc_summary.json` still prices the estimator's tall kernels, unchanged since) |\n")
+  "| `r04_bench.json` | the bench line of the un-profiled run (1x MI355X, default flags), extras included (`roofline_phases`, `other_configs`, `small_batch`) |\n"
+  "| `r04_train_step_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras`: both timed regions (side stream + three / two concurrent 256-row chains).  bench.py reads the newest round's file of this name to choose `roofline.kernel` by share of kernel time |\n"
+  "| `r04_train_step_kernel_stats_no_overlap.csv` | the same with `--no-overlap` (every phase on one stream): the averages `roofline_single_stream*` is comparable with |\n"
+  "| `r04_phase_<phase>_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/phase_profile.py <phase>_cold 5`: ONE phase of the train_step in a cold process (5 calls: the phase's kernels only).  Phases: `elbo`, `rollout_bptt`, `efe` (rollout + estimator + BPTT; estimator = efe - rollout_bptt), `chain1` (one 256-row reverse loop), `chains3` (three concurrent), `chains2` (two: the live belief updates of a step), `value_dynamics`, `optimiser`, `pixel_epistemic` (SURVEY 8(f)-1 at 64 belief rows, S = 2) |\n"
+  "| `r04_pmc_chain_summary.json` | per-kernel averages of three PMC passes (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) over ONE 256-row reverse loop alone, launched directly: the kernels of the concurrent chains.  Counter collection on this pool does not survive concurrent streams; one chain alone runs exactly the kernels, shapes and launch geometry each of the three chains runs |\n"
+  "| `r04_pmc_summary.json` | the same three passes over ONE policy phase alone (rollout + estimator + BPTT, `phase_profile.py efe_cold 1`): the estimator's tall full-row kernels (replaces `r02_pmc_summary.json`) |\n"
+  "| `r04_cfg3_kernel_stats*.csv`, `r04_cfg4_kernel_stats*.csv` (+ `*_ms_under_rocprof.txt`) | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/cfg{3,4}_profile.py 5`: 3 warm-up + 5 timed train_steps of BASELINE configs[2] / [3] at full size, overlapped and single-stream (`_no_overlap`) |\n"
+  "| `r04_small_batch_b{1,32}_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/small_batch_prof.py B`: five 50-step reverse loops at B rows, eval mode, direct launches |\n"
+  "| `r04_bench_under_rocprof.json`, `r04_bench_no_overlap_under_rocprof.json` | the bench lines printed by the two profiled runs (slower: the profiler serialises the small kernels) |\n"
+  "| `r03_*`, `r02_*`, `r01_*`, `gemm_*_r01.txt` | earlier rounds' artifacts, kept as history |\n")
 w("## Bench line (cfg 2: B=256, H=5, K=10, S=10, N=50, D=512, fp32)\n")
-w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/step; whole-step algorithmic rate {bench['train_step_algorithmic_tflops']:.1f} TFLOP/s "
-  f"= {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
+w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/step (the step as the reference executes it, dead next_obs belief update included); live-work algorithmic rate "
+  f"{bench['train_step_algorithmic_tflops']:.1f} TFLOP/s = {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
+w(f"* `value_dead_belief_elided`: **{bench['value_dead_belief_elided']:.2f} train steps/s** = {bench['ms_per_step_dead_belief_elided']:.1f} ms/step (second timed region of the same run: the agent's default, "
+  f"which does not run the belief update `state_agent.py:138-139` computes and `:195-196` overwrites) = {100*bench['train_step_frac_of_f32_mfma_peak_dead_belief_elided']:.1f} % of peak on the same live {bench['train_step_live_flop']/1e12:.2f} TFLOP.")
 for key in ("roofline", "roofline_second_kernel", "roofline_single_stream"):
     r = bench.get(key)
     if not r:
@@ -32,7 +37,7 @@ for key in ("roofline", "roofline_second_kernel", "roofline_single_stream"):
     w(f"* `{key}`: `{r['kernel']}` — {r['achieved']:.1f} TFLOP/s = **{100*r['frac']:.1f} %** of peak, {r['us_per_launch']:.1f} µs and {r['flop_per_launch']/1e9:.2f} GFLOP per launch "
       f"({r['launches_per_step']} launches per step; {r['profiled']})"
       + (f"; in the timed schedule {100*ov['share_of_kernel_time']:.1f} % of kernel time, {ov['calls']} calls x {ov['avg_us']:.2f} µs" if ov else "")
-      + (f"; priced at the profiler's average duration: {r['achieved_at_rocprofv3_average']:.1f} TFLOP/s = {100*r['frac_at_rocprofv3_average']:.1f} % (HIP events add ~2 µs per launch)" if r.get("achieved_at_rocprofv3_average") else "")
+      + (f"; live HIP-event figure of the run: {r['achieved_hip_events']:.1f} TFLOP/s = {100*r['frac_hip_events']:.1f} % (events add ~2 µs per launch)" if r.get("achieved_hip_events") else "")
       + (f"; PMC traffic {r['traffic']/1e6:.2f} MB per launch ({r['traffic_source']}) against {r['algorithmic_bytes_per_launch']/1e6:.2f} MB algorithmic" if r.get("traffic") else "") + ".")
 f = bench["roofline_gemm_family"]; h = bench["roofline_hbm"]
 w(f"* every GEMM launch of one single-stream step: {f['achieved']:.1f} TFLOP/s = {100*f['frac']:.1f} % ({f['launches_per_step']} launches, {f['flop_per_step']/1e12:.2f} TFLOP per step).")
@@ -44,8 +49,8 @@ w("")
 ph = bench.get("roofline_phases") or {}
 if ph:
     w("## Per-phase roofline (`roofline_phases`: each phase alone, HIP events on the launching stream, median of 3) next to the rocprofv3 phase summaries\n")
-    w("| phase | ms (bench) | work | achieved | % of peak | rocprofv3: kernel ms per call / launches per call (`r03_phase_*`) |\n|---|---|---|---|---|---|")
-    names = {"elbo": "elbo", "rollout_bptt": "rollout_bptt", "estimator": None, "reverse_loop_one_chain": "chain1", "reverse_loops_three_chains": "chains3",
+    w("| phase | ms (bench) | work | achieved | % of peak | rocprofv3: kernel ms per call / launches per call (`r04_phase_*`) |\n|---|---|---|---|---|---|")
+    names = {"elbo": "elbo", "rollout_bptt": "rollout_bptt", "estimator": None, "reverse_loop_one_chain": "chain1", "reverse_loops_three_chains": "chains3", "reverse_loops_two_chains": "chains2",
              "value_dynamics": "value_dynamics", "optimiser_score": "optimiser"}
     percall = {}
     for k, fn in names.items():
@@ -83,6 +88,15 @@ if os.path.exists(noov):
         w(f"| `{k}` | {r['launches_per_step']} | {r['us_per_launch']:.1f} | {r['achieved']:.1f} | " + (f"{float(m['AverageNs'])/1e3:.1f} | {m['Calls']}" if m else "— | —") + " |")
     w("\nThe rocprofv3 column averages over every call of the process (warm-up, timed steps, the profiled steps, the phase measurements), so the shape mix differs\n"
       "slightly from one train_step; HIP events add ≈ 1.5 µs to a kernel of a few µs.\n")
+pt = os.path.join(P, R + "_pmc_summary.json")
+if os.path.exists(pt):
+    w("## PMC passes over ONE policy phase alone (rollout + estimator + BPTT): the tall kernels\n")
+    w("| kernel | launches | avg µs | read MB/launch | write MB/launch | MFMA pipe busy | clock GHz |\n|---|---|---|---|---|---|---|")
+    for k, v in list(json.load(open(pt)).items())[:8]:
+        if "launches_mfma" in v:
+            w(f"| `{k[:72]}` | {v.get('launches_mfma','')} | {v.get('avg_us_mfma',0):.1f} | {v.get('fetch_bytes_per_launch_corrected',0)/1e6:.1f} | {v.get('write_bytes_per_launch',0)/1e6:.1f} | "
+              f"{100*v.get('mfma_util',0):.1f} % | {v.get('eff_clock_GHz',0):.2f} |")
+    w("")
 w("## PMC passes over ONE 256-row reverse loop alone (FETCH_SIZE x 1 KiB x 2 = corrected read bytes, WRITE_SIZE x 1 KiB; MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs ÷ GRBM_GUI_ACTIVE / 8 XCDs)\n")
 w("| kernel | launches | avg µs | read MB/launch | write MB/launch | MFMA pipe busy |\n|---|---|---|---|---|---|")
 for k, v in pmc.items():
@@ -98,6 +112,9 @@ if oc:
     for k, d in oc.items():
         if d and "ms_per_step" in d:
             w(f"* {k}: {d['ms_per_step']:.1f} ms/step = {d['steps_per_s']:.2f} steps/s, {d['algorithmic_tflops']:.1f} algorithmic TFLOP/s = {100*d['frac_of_f32_mfma_peak']:.1f} % of the fp32-MFMA peak")
+            php = d.get("roofline_phases") or {}
+            if php and "error" not in php:
+                w("  * phases alone (ms, % of the relevant peak): " + "; ".join(f"`{n}` {v['ms']:.2f} ms, {100*v['frac']:.1f} %" for n, v in php.items()))
     pe = oc.get("pixel_epistemic_f1")
     if pe:
         w(f"* pixel_epistemic_f1 (SURVEY 8(f)-1, REDUCED size: {pe['config']['belief_rows']} belief rows, S = {pe['config']['ambiguity_samples']}): "

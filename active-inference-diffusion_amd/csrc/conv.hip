@@ -44,8 +44,10 @@ __global__ void aug_to_cnhw_kernel(const float* __restrict__ x, const int32_t* _
 
 // ---- legacy spectral norm: one workgroup, W [Cout][K] (K <= 1152, Cout <= 256) ------------------------------------------------
 // save layout: u_used[Cout] | v_used[K] | sigma
-__global__ void spectral_norm_kernel(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ v, int Cout, int K, int Kp,
-                                     int power_iter, int write_uv, float* __restrict__ w_eff, float* __restrict__ save) {
+struct SnLayer { const float* w; float* u; float* v; int Cout, K, Kp; float* w_eff; float* save; };
+struct SnBatch { SnLayer l[4]; };
+__device__ __forceinline__ void spectral_norm_body(const float* __restrict__ w, float* __restrict__ u, float* __restrict__ v, int Cout, int K, int Kp,
+                                                   int power_iter, int write_uv, float* __restrict__ w_eff, float* __restrict__ save) {
     __shared__ float us[256], vs[1152], t2[256], sh[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     for (int c = tid; c < Cout; c += blockDim.x) us[c] = u[c];
@@ -86,18 +88,31 @@ __global__ void spectral_norm_kernel(const float* __restrict__ w, float* __restr
     for (int k = tid; k < K; k += blockDim.x) { save[Cout + k] = vs[k]; if (write_uv) v[k] = vs[k]; }
     if (tid == 0) save[Cout + K] = sigma;
 }
-// dW_orig += (dW_eff - <dW_eff, W_eff> u v^T) / sigma
-__global__ void spectral_norm_bwd_kernel(const float* __restrict__ dw_eff, const float* __restrict__ w_eff, const float* __restrict__ save,
-                                         int Cout, int K, int Kp, float* __restrict__ dw_orig) {
+// the encoder's four layers in one launch (one workgroup each: they depend on the weights only, not on each other or on the activations - launched one
+// by one in front of their convolutions they were 4 x 50-68 us of one CU on the critical path of every encoder pass)
+__global__ void __launch_bounds__(1024) spectral_norm4_kernel(SnBatch bt, int power_iter, int write_uv) {
+    const SnLayer& L = bt.l[blockIdx.x];
+    spectral_norm_body(L.w, L.u, L.v, L.Cout, L.K, L.Kp, power_iter, write_uv, L.w_eff, L.save);
+}
+// dW_orig += (dW_eff - <dW_eff, W_eff> u v^T) / sigma, in two launches that use the whole chip (the one-workgroup form was 107 us per layer on ONE CU, four layers per encoder backward, on the step's
+// critical path): 64 partial dots in a fixed partition, then every thread adds the 64 partials in the same order and updates its element.
+constexpr int SN_BWD_PARTS = 64;
+__global__ void __launch_bounds__(256) sn_bwd_dot_kernel(const float* __restrict__ dw_eff, const float* __restrict__ w_eff, int Cout, int K, int Kp, float* __restrict__ part) {
     __shared__ float sh[16];
     float loc = 0.f;
-    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) { const int c = i / K, k = i % K; loc += dw_eff[(size_t)c * Kp + k] * w_eff[(size_t)c * Kp + k]; }
-    const float dot = wg_sum256(loc, sh);
-    const float sigma = save[Cout + K];
-    for (int i = threadIdx.x; i < Cout * K; i += blockDim.x) {
-        const int c = i / K, k = i % K;
-        dw_orig[i] += (dw_eff[(size_t)c * Kp + k] - dot * save[c] * save[Cout + k]) / sigma;
-    }
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Cout * K; i += SN_BWD_PARTS * 256) { const int c = i / K, k = i - c * K; loc += dw_eff[(size_t)c * Kp + k] * w_eff[(size_t)c * Kp + k]; }
+    const float t = wg_sum256(loc, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = t;
+}
+__global__ void __launch_bounds__(256) sn_bwd_apply_kernel(const float* __restrict__ dw_eff, const float* __restrict__ part, const float* __restrict__ save, int Cout, int K, int Kp,
+                                                           float* __restrict__ dw_orig) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= Cout * K) return;
+    float dot = 0.f;
+#pragma unroll 8
+    for (int b = 0; b < SN_BWD_PARTS; ++b) dot += part[b];
+    const int c = i / K, k = i - c * K;
+    dw_orig[i] += (dw_eff[(size_t)c * Kp + k] - dot * save[c] * save[Cout + k]) / save[Cout + K];
 }
 
 // ---- GroupNorm + Mish + Dropout2d, one workgroup per (sample, group); x/y CNHW [C][B][HW] -----------------------------------------
@@ -392,28 +407,96 @@ __global__ void attn_bwd_c_fold_kernel(const float* __restrict__ part, int parts
 }
 
 // ---- LayerNorm over F = 451 584 features, one workgroup per row -----------------------------------------------------------------------
-__global__ void bigln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-                             float* __restrict__ stats, size_t F) {
+// LayerNorm over the F = 451 584 flattened conv features of a row (1.8 MB: neither registers nor LDS hold it), one 1024-thread workgroup per row.
+// 16-byte accesses, four in flight per thread; the statistics in ONE pass over the row (sums of (x - x0) and (x - x0)^2 around the row's first
+// element: the shift keeps the variance formula away from cancellation), the normalisation in a second: x is read twice instead of three times and
+// every access is a float4 (the first form was 0.74 ms per 256 rows = 1.25 TB/s).  F % 4 == 0 and 16-byte aligned rows (checked by the caller), else
+// the element loop.
+__global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
+                                                     float* __restrict__ stats, size_t F, int vec) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float sh[16];
     const float* xr = x + (size_t)blockIdx.x * F; float* yr = y + (size_t)blockIdx.x * F;
-    float s = 0.f;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
-    const float mean = wg_sum256(s, sh) / (float)F;
-    float q = 0.f;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
+    if (!vec) {
+        float s = 0.f;
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
+        const float mean = wg_sum256(s, sh) / (float)F;
+        float q = 0.f;
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
+        if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+        return;
+    }
+    const size_t F4 = F / 4;
+    const f4* x4 = reinterpret_cast<const f4*>(xr);
+    const float x0 = xr[0];
+    float s = 0.f, q = 0.f;
+    for (size_t i = threadIdx.x; i < F4; i += 4 * (size_t)blockDim.x) {
+        f4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const size_t j = i + u * (size_t)blockDim.x; v[u] = j < F4 ? x4[j] : (f4){x0, x0, x0, x0}; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - x0; s += d; q += d * d; }
+    }
+    const float ms = wg_sum256(s, sh) / (float)F;                      // mean - x0
+    const float var = fmaxf(wg_sum256(q, sh) / (float)F - ms * ms, 0.f);
+    const float mean = x0 + ms, rstd = 1.0f / sqrtf(var + 1e-5f);
     if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    const f4* g4 = reinterpret_cast<const f4*>(gamma); const f4* b4 = reinterpret_cast<const f4*>(beta); f4* y4 = reinterpret_cast<f4*>(yr);
+    for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
+        const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
+        const f4 a0 = x4[i], c0 = g4[i], d0 = b4[i];
+        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, d1 = two ? b4[j1] : d0;
+        f4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o0[e] = (a0[e] - mean) * rstd * c0[e] + d0[e]; o1[e] = (a1[e] - mean) * rstd * c1[e] + d1[e]; }
+        y4[i] = o0;
+        if (two) y4[j1] = o1;
+    }
 }
-__global__ void bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                                 const float* __restrict__ stats, float* __restrict__ dx, size_t F) {
+__global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+                                                         const float* __restrict__ stats, float* __restrict__ dx, size_t F, int vec) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float sh[16];
     const float* xr = x + (size_t)blockIdx.x * F; const float* dyr = dy + (size_t)blockIdx.x * F; float* dxr = dx + (size_t)blockIdx.x * F;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     float sg = 0.f, sgx = 0.f;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += g; sgx += g * (xr[i] - mean) * rstd; }
+    if (!vec) {
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += g; sgx += g * (xr[i] - mean) * rstd; }
+        const float mg = wg_sum256(sg, sh) / (float)F, mgx = wg_sum256(sgx, sh) / (float)F;
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr[i] - mean) * rstd * mgx);
+        return;
+    }
+    const size_t F4 = F / 4;
+    const f4* x4 = reinterpret_cast<const f4*>(xr); const f4* d4 = reinterpret_cast<const f4*>(dyr); const f4* g4 = reinterpret_cast<const f4*>(gamma);
+    f4* o4 = reinterpret_cast<f4*>(dxr);
+    for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
+        const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
+        const f4 a0 = x4[i], c0 = g4[i], e0 = d4[i];
+        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float g0 = e0[e] * c0[e]; sg += g0; sgx += g0 * (a0[e] - mean) * rstd;
+            if (two) { const float g1 = e1[e] * c1[e]; sg += g1; sgx += g1 * (a1[e] - mean) * rstd; }
+        }
+    }
     const float mg = wg_sum256(sg, sh) / (float)F, mgx = wg_sum256(sgx, sh) / (float)F;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr[i] - mean) * rstd * mgx);
+    for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
+        const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
+        const f4 a0 = x4[i], c0 = g4[i], e0 = d4[i];
+        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
+        f4 r0, r1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            r0[e] = rstd * (e0[e] * c0[e] - mg - (a0[e] - mean) * rstd * mgx);
+            r1[e] = rstd * (e1[e] * c1[e] - mg - (a1[e] - mean) * rstd * mgx);
+        }
+        o4[i] = r0;
+        if (two) o4[j1] = r1;
+    }
 }
 __global__ void bigln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
                                         float* __restrict__ dgamma, float* __restrict__ dbeta, int B, size_t F) {
@@ -678,12 +761,16 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     const float* masks[ENC_LAYERS] = {nullptr, train ? drop2d_1 : nullptr, train ? drop2d_2 : nullptr, nullptr};
     L1D(aug_to_cnhw_kernel, (size_t)B * e.in_ch * e.H * e.W, s, x, train ? shift_h : nullptr, shift_w, pad, sv.x0, B, e.in_ch, e.H, e.W);
     const float* cur = sv.x0;
+    {
+        SnBatch bt;
+        for (int i = 0; i < ENC_LAYERS; ++i) bt.l[i] = SnLayer{e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], sv.w_eff[i], sv.sn[i]};
+        static_assert(ENC_LAYERS == 4, "spectral_norm4_kernel batches four layers");
+        hipLaunchKernelGGL(spectral_norm4_kernel, dim3(ENC_LAYERS), dim3(1024), 0, s, bt, train, train);
+        AID_LAUNCH_CHECK();
+    }
     for (int i = 0; i < ENC_LAYERS; ++i) {
         const size_t N = (size_t)B * g.ho[i] * g.ho[i];
         const size_t mark = ws.mark();
-        hipLaunchKernelGGL(spectral_norm_kernel, dim3(1), dim3(1024), 0, s, e.conv_w[i], e.conv_u[i], e.conv_v[i], g.cout[i], g.K[i], g.Kp[i], train,
-                           train, sv.w_eff[i], sv.sn[i]);
-        AID_LAUNCH_CHECK();
         (void)N;
         if (conv3_tapmajor_ok(g.cin[i], g.cout[i])) {      // tap-major contraction (conv_igemm.hip, TAPM): the weights re-ordered once per pass (<= 1.2 MB)
             float* wtm = ws.f32((size_t)g.cout[i] * g.Kp[i]); AID_WS_OK(ws);
@@ -708,7 +795,10 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     L1D(attn_pool_kernel, B * HW, s, cur, sv.pool, sv.amax, 256, B, HW);
     L1D(attn_conv_kernel, B * HW, s, sv.pool, e.att_conv_w, e.att_conv_b, e.att_temperature, sv.apre, sv.att, B, Hh, Hh);
     L1D(attn_apply_kernel, (size_t)256 * B * HW, s, cur, sv.att, sv.xf, 256, B, HW);
-    hipLaunchKernelGGL(bigln_kernel, dim3(B), dim3(1024), 0, s, sv.xf, e.ln_g, e.ln_b, sv.xln, sv.ln_stats, g.F);
+    {
+        const int vec = g.F % 4 == 0 && ((((uintptr_t)sv.xf | (uintptr_t)e.ln_g | (uintptr_t)e.ln_b | (uintptr_t)sv.xln) & 15) == 0);
+        hipLaunchKernelGGL(bigln_kernel, dim3(B), dim3(1024), 0, s, sv.xf, e.ln_g, e.ln_b, sv.xln, sv.ln_stats, g.F, vec);
+    }
     AID_LAUNCH_CHECK();
     {   // Linear(F -> 2L): deterministic split-K
         const size_t mark = ws.mark();
@@ -755,7 +845,10 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
     AID_TRY(linear_bwd_data(d_o0, L2, e.out0.w, (int)g.F, dxln, (int)g.F, B, L2, s));
     // ---- LayerNorm(F)
     hipLaunchKernelGGL(bigln_param_grad_kernel, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, s, dxln, sv.xf, sv.ln_stats, gr.ln_g, gr.ln_b, B, g.F);
-    hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.xf, e.ln_g, sv.ln_stats, dxf, g.F);
+    {
+        const int vec = g.F % 4 == 0 && ((((uintptr_t)dxln | (uintptr_t)sv.xf | (uintptr_t)e.ln_g | (uintptr_t)dxf) & 15) == 0);
+        hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.xf, e.ln_g, sv.ln_stats, dxf, g.F, vec);
+    }
     AID_LAUNCH_CHECK();
     // ---- spatial attention
     const size_t nact3 = (size_t)256 * B * HW;
@@ -780,6 +873,7 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         const int S = conv_dw_slabs(N, g.cout[i], g.Kp[i]);
         float* slab = ws.f32((size_t)S * g.cout[i] * g.Kp[i]);
         float* ppart = ws.f32((size_t)B * g.cout[i] * 2);
+        float* snpart = ws.f32(SN_BWD_PARTS);
         AID_WS_OK(ws);
         if (gn_reg_ok(g.cout[i], g.G[i], hw, sv.conv_out[i], dcur) && ((((uintptr_t)dconv) & 15) == 0)) {
             if (g.cout[i] / g.G[i] == 4) hipLaunchKernelGGL(gn_mish_bwd_reg_kernel<4>, dim3(B * g.G[i]), dim3(256), 0, s, sv.conv_out[i], e.gn_g[i], e.gn_b[i], masks[i], sv.gn_stats[i], dcur, dconv, ppart, g.cout[i], B, hw, g.G[i]);
@@ -793,7 +887,8 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         AID_LAUNCH_CHECK();
         // dW_eff[Cout][Kp] = sum_n dconv[Cout][n] X(k, n): the layer's input is gathered again (implicit GEMM; huge reduction -> slabs)
         AID_TRY(conv3_igemm_dw(dconv, i > 0 ? sv.act[i - 1] : sv.x0, dweff, g.Kp[i], g.cin[i], g.cout[i], B, g.hi[i], g.ho[i], g.stride[i], slab, S, s));
-        hipLaunchKernelGGL(spectral_norm_bwd_kernel, dim3(1), dim3(1024), 0, s, dweff, sv.w_eff[i], sv.sn[i], g.cout[i], g.K[i], g.Kp[i], gr.conv_w[i]);
+        hipLaunchKernelGGL(sn_bwd_dot_kernel, dim3(SN_BWD_PARTS), dim3(256), 0, s, dweff, sv.w_eff[i], g.cout[i], g.K[i], g.Kp[i], snpart);
+        hipLaunchKernelGGL(sn_bwd_apply_kernel, dim3((g.cout[i] * g.K[i] + 255) / 256), dim3(256), 0, s, dweff, snpart, sv.sn[i], g.cout[i], g.K[i], g.Kp[i], gr.conv_w[i]);
         AID_LAUNCH_CHECK();
         if (i > 0) {   // gradient wrt act[i-1]: the stride-1 conv of dconv with the flipped, channel-transposed weights
             AID_REQUIRE(g.stride[i] == 1, AID_E_SHAPE, "aid_encoder_backward: data gradient of a strided conv is not built (layer %d)", i);

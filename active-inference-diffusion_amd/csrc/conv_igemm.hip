@@ -217,6 +217,7 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
 }
 
 static int g_ig_dbg = 0;
+static int g_dw_tm = 1;          // aid_conv_debug(12 / 13): tap-major weight-gradient kernel off / on (A/B timing)
 static int g_ig_vec4 = 1;        // aid_conv_debug(10 / 11): four-pixel vector gathers of the tap-major kernels off / on (A/B timing)
 // tap-major kernels need whole BK-channel blocks per tap: BK = 32 for the <= 32-output-channel tile, 16 otherwise
 bool conv3_tapmajor_ok(int Cin, int Cout) { return Cin % (Cout <= 32 ? 32 : 16) == 0; }
@@ -412,6 +413,123 @@ __global__ void __launch_bounds__(256) conv3_igemm_dw_kernel(ConvDwArgs g) {
         if (row < g.Cout && col < g.ldw) out[(size_t)row * g.ldw + col] = col < g.K ? acc[r] : 0.f;
     }
 }
+// The same contraction for stride-1 layers with Cin % 64 == 0, tap-major: the 64 columns of a workgroup's output tile are 64 CHANNELS of ONE tap, k' = tap Cin + ci,
+// so the gathered operand of a stage is 64 channel rows of 32 consecutive pixels shifted by the tap's constant offset (stride 1: input index = n + (dh - 1) W + (dw - 1)):
+// two 4-byte-aligned 16-byte loads per thread and two ds_write_b128 instead of eight element gathers with their own taps, and ONE border test per pixel for the
+// workgroup's tap.  The slabs come out in k' order; conv3_dw_fold_kernel puts them back into the weight's [co][ci 9 + tap] layout while it folds them.
+__global__ void __launch_bounds__(256) conv3_igemm_dw_tm_kernel(ConvDwArgs g) {
+    constexpr int BT = 64, BK = 32, LD = BK + 4, FL = BT * LD;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;              // [2][64 co][36]   (n contiguous)
+    float* Bs = smem + 2 * FL;     // [2][64 k'][36]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 32, wk = (wave & 1) * 32;
+    const int tco = blockIdx.x / g.tiles_k, tk = blockIdx.x % g.tiles_k;
+    const int co0 = tco * BT, k0 = tk * BT;                     // k0 = tap Cin + ci0 (Cin % 64 == 0: one tap per tile)
+    const int tap = k0 / g.Cin, ci0 = k0 - tap * g.Cin, dh = tap / 3, dw = tap - 3 * dh;
+    const long nb0 = (long)blockIdx.y * g.chunk, nb1 = min(g.N, nb0 + g.chunk);
+    const int nst = (int)((nb1 - nb0 + BK - 1) / BK);
+    const long plane = (long)g.B * g.Hi * g.Wi, total4 = (long)g.Cin * plane - 4;
+    const int q = tid & 7, krow = tid >> 3;                     // this thread's pixel quad within a stage and its two channel rows krow, krow + 32
+    const long toff = (long)(dh - 1) * g.Wi + (dw - 1) + (long)(ci0 + krow) * plane;
+    ig_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    ig_f32x4 ra[2], rbv[2]; int rbd[2]; unsigned rbn = 0; bool ram[2];
+    // (wo, ho) of the quad's first pixel n = nb0 + 32 st + 4 q, advanced by 32 per stage with carries
+    int cwo, cho;
+    { const long nn = min(nb0 + 4 * q, g.N - 1); cwo = (int)(nn % g.Wo); cho = (int)((nn / g.Wo) % g.Ho); }
+    auto load_stage = [&](int st) {
+        const long nb = nb0 + (long)st * BK;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            const long nn = nb + 4 * c4;
+            ram[i] = co0 + row < g.Cout && nn + 3 < nb1;
+            const long a = (long)min(co0 + row, g.Cout - 1) * g.N + (ram[i] ? nn : 0);
+            ra[i] = *reinterpret_cast<const ig_f32x4*>(g.dy + a);
+        }
+        const long n4 = nb + 4 * q;
+        // border bits of the quad's four pixels at this workgroup's tap
+        rbn = 0;
+        {
+            int wo = cwo, ho = cho;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int hh = ho + dh - 1, ww = wo + dw - 1;
+                if (n4 + e < nb1 && hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) rbn |= 1u << e;
+                if (++wo == g.Wo) { wo = 0; if (++ho == g.Ho) ho = 0; }
+            }
+        }
+        cwo += BK;                                              // next stage's quad
+        while (cwo >= g.Wo) { cwo -= g.Wo; if (++cho == g.Ho) cho = 0; }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long idx = toff + n4 + (long)(32 * i) * plane;
+            const long idc = idx < 0 ? 0 : (idx > total4 ? total4 : idx);
+            rbd[i] = (int)(idc - idx);
+            rbv[i] = *reinterpret_cast<const ig_f32x4u*>(g.x + idc);
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + 256 * i, row = f >> 3, c4 = f & 7;
+            *reinterpret_cast<ig_f32x4*>(As + buf * FL + row * LD + 4 * c4) = ram[i] ? ra[i] : (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            ig_f32x4 v = rbv[i];
+            const int d = rbd[i];
+            if (d != 0) {                                        // a load clamped at an end of the tensor: element e wants loaded[e - d]
+                ig_f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int j = e - d; w[e] = j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : (j == 3 ? v[3] : 0.f))); }
+                v = w;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((rbn >> e) & 1u) ? v[e] : 0.f;
+            *reinterpret_cast<ig_f32x4*>(Bs + buf * FL + (krow + 32 * i) * LD + 4 * q) = v;
+        }
+    };
+    if (nst > 0) { load_stage(0); store_stage(0); }
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nst) load_stage(st + 1);
+        const float* a_s = As + cur * FL;
+        const float* b_s = Bs + cur * FL;
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            const ig_f32x4 av = *reinterpret_cast<const ig_f32x4*>(a_s + (wm + li) * LD + 8 * g8 + 4 * h);
+            const ig_f32x4 bv = *reinterpret_cast<const ig_f32x4*>(b_s + (wk + li) * LD + 8 * g8 + 4 * h);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[qq], bv[qq], acc, 0, 0, 0);
+        }
+        if (st + 1 < nst) store_stage(cur ^ 1);
+        __syncthreads();
+    }
+    float* out = g.slab + (size_t)blockIdx.y * g.Cout * g.ldw;
+#pragma clang loop unroll(full)
+    for (int r = 0; r < 16; ++r) {
+        const int row = co0 + wm + (r & 3) + 8 * (r >> 2) + 4 * h, col = k0 + wk + li;
+        if (row < g.Cout && col < g.ldw) out[(size_t)row * g.ldw + col] = col < g.K ? acc[r] : 0.f;
+    }
+}
+// dW[co][k] = sum of the S slabs (slab order); tm_cin > 0: the slabs are tap-major (position tap tm_cin + ci), dW gets the weight's own order k = ci 9 + tap
+__global__ void conv3_dw_fold_tm_kernel(const float* __restrict__ slab, int S, int Cout, int ldw, int tm_cin, float* __restrict__ dW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)Cout * ldw;
+    if (i >= n) return;
+    const int co = (int)(i / ldw), k = (int)(i % ldw);
+    float v = 0.f;
+    if (k < 9 * tm_cin) {
+        const int ci = k / 9, tap = k - 9 * ci;
+        const size_t src = (size_t)co * ldw + tap * tm_cin + ci;
+        for (int sy = 0; sy < S; ++sy) v += slab[(size_t)sy * n + src];
+    }
+    dW[i] = v;
+}
 __global__ void conv3_dw_fold_kernel(const float* __restrict__ slab, int S, size_t n, float* __restrict__ dW) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -431,8 +549,15 @@ int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin,
     const int S_eff = (int)((N + g.chunk - 1) / g.chunk);
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * Cout * g.K * (double)N, 4.0 * ((double)Cout * N + (double)Cin * B * Hi * Hi));
     prof.m = Cout; prof.n = g.K; prof.k = (int)(N > 2000000000L ? 2000000000L : N); prof.layout = 4 + stride; prof.variant = 32;
-    hipLaunchKernelGGL(conv3_igemm_dw_kernel, dim3(((Cout + 63) / 64) * g.tiles_k, S_eff), dim3(256), sizeof(float) * 4 * 64 * (32 + 4), s, g);
     const size_t n = (size_t)Cout * ldw;
+    if (stride == 1 && Hi == Ho && Cin % 64 == 0 && g_dw_tm) {      // tap-major tiles + four-pixel vector gathers
+        prof.layout = 4 + stride + 8;
+        hipLaunchKernelGGL(conv3_igemm_dw_tm_kernel, dim3(((Cout + 63) / 64) * g.tiles_k, S_eff), dim3(256), sizeof(float) * 4 * 64 * (32 + 4), s, g);
+        hipLaunchKernelGGL(conv3_dw_fold_tm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, S_eff, Cout, ldw, Cin, dW);
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
+    hipLaunchKernelGGL(conv3_igemm_dw_kernel, dim3(((Cout + 63) / 64) * g.tiles_k, S_eff), dim3(256), sizeof(float) * 4 * 64 * (32 + 4), s, g);
     hipLaunchKernelGGL(conv3_dw_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, S_eff, n, dW);
     AID_LAUNCH_CHECK();
     return AID_OK;
@@ -443,7 +568,10 @@ int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin,
 using namespace aid;
 extern "C" {
 // Unit-test entries for the implicit-GEMM convolution (W: [Cout][ldw] with ldw >= 9 Cin a multiple of 4, x: CNHW [Cin][B][Hi][Hi], out / dy: [Cout][B Ho Ho]).
-int aid_conv_debug(int mode) { if (mode == 10) aid::g_ig_vec4 = 0; else if (mode == 11) aid::g_ig_vec4 = 1; else aid::g_ig_dbg = mode; return AID_OK; }
+int aid_conv_debug(int mode) {
+    if (mode == 10) aid::g_ig_vec4 = 0; else if (mode == 11) aid::g_ig_vec4 = 1; else if (mode == 12) aid::g_dw_tm = 0; else if (mode == 13) aid::g_dw_tm = 1; else aid::g_ig_dbg = mode;
+    return AID_OK;
+}
 int aid_conv3_igemm_tm(const float* Wtm, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {
     return conv3_igemm_ex(Wtm, ldw, x, out, Cin, Cout, B, Hi, Ho, stride, 1, (hipStream_t)stream);
 }

@@ -622,26 +622,40 @@ __global__ void __launch_bounds__(256) instnorm_kernel(const float* __restrict__
 }
 // The same with the plane in registers (HW <= 256 PER: 21^2, 42^2, 84^2, 168^2 -> PER = 2, 7, 28, 111): the conv output is read once instead of three
 // times and the sub-pixel index arithmetic runs once per element.  115 MB planes at 168 x 168: the three-pass form was 15 % of a pixel-estimator call.
-template <int PER>
-__global__ void __launch_bounds__(256) instnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ add,
-                                                            float* __restrict__ y, int C, int R, int H, int W, int shuffle, int act) {
+// (round 4) SHUF and ACT are template arguments and the PixelShuffle index is carried, not divided: with a run-time activation switch inlined 111 times and an
+// integer division per element the 168 x 168 planes moved 231 MB in 150 us (1.5 TB/s): VALU-bound.  Mish = x n / (n + 2), n = e^x (e^x + 2), with
+// v_exp_f32 / v_rcp_f32 (inference path: |relative error| ~ 1e-7).
+__device__ __forceinline__ float mish_fast(float x) {
+    if (x > 20.f) return x;
+    const float e = exp_fast(x), n = e * (e + 2.f);
+    return x * n * __builtin_amdgcn_rcpf(n + 2.f);
+}
+// NT threads per plane: 1024 for the 84 x 84 and 168 x 168 planes, so that a thread holds 7 / 28 elements - at 256 threads the 111 elements (and their 111
+// 64-bit addresses, which the compiler keeps live to have every load in flight) took all 256 VGPRs: one wave per SIMD.
+template <int PER, int NT, bool SHUF, int ACT>
+__global__ void __launch_bounds__(NT) instnorm_reg_kernel(const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ add,
+                                                            float* __restrict__ y, int C, int R, int H, int W) {
     __shared__ float sh[16];
     const int c = blockIdx.x / R, r = blockIdx.x % R, HW = H * W, tid = threadIdx.x;
     float v[PER];
-    if (!shuffle) {
+    if constexpr (!SHUF) {
         const float* xp = x + ((size_t)c * R + r) * HW; const float b = bias ? bias[c] : 0.f;
 #pragma unroll
-        for (int k = 0; k < PER; ++k) { const int i = tid + 256 * k; v[k] = i < HW ? xp[i] + b : 0.f; }
+        for (int k = 0; k < PER; ++k) { const int i = tid + NT * k; v[k] = i < HW ? xp[i] + b : 0.f; }
     } else {
         const int h = H >> 1, w = W >> 1;
         float b4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) b4[q] = bias ? bias[4 * c + q] : 0.f;
+        int Y = tid / W, X = tid - Y * W;                    // element i = tid + NT k as (Y, X), advanced by NT per k with carries
+        const int dY = NT / W, dX = NT - dY * W;
 #pragma unroll
         for (int k = 0; k < PER; ++k) {
-            const int i = tid + 256 * k;
-            const int Y = i / W, X = i - Y * W, sub = 2 * (Y & 1) + (X & 1);
+            const int i = tid + NT * k;
+            const int sub = 2 * (Y & 1) + (X & 1);
             v[k] = i < HW ? x[(((size_t)(4 * c + sub) * R + r) * h + (Y >> 1)) * w + (X >> 1)] + b4[sub] : 0.f;
+            Y += dY; X += dX;
+            if (X >= W) { X -= W; ++Y; }
         }
     }
     float s = 0.f;
@@ -650,45 +664,80 @@ __global__ void __launch_bounds__(256) instnorm_reg_kernel(const float* __restri
     const float mean = wg_sum256(s, sh) / (float)HW;
     float q = 0.f;
 #pragma unroll
-    for (int k = 0; k < PER; ++k) { const float d = v[k] - mean; q += tid + 256 * k < HW ? d * d : 0.f; }
+    for (int k = 0; k < PER; ++k) { const float d = v[k] - mean; q += tid + NT * k < HW ? d * d : 0.f; }
     const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)HW + 1e-5f);
     const size_t o = ((size_t)c * R + r) * HW;
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
-        const int i = tid + 256 * k;
+        const int i = tid + NT * k;
         if (i < HW) {
             float t = (v[k] - mean) * rstd;
             if (add) t += add[o + i];
-            y[o + i] = act_apply(t, act);
+            y[o + i] = ACT == ACT_MISH ? mish_fast(t) : t;
         }
+    }
+}
+template <int PER, int NT>
+static void launch_instnorm_reg(const float* x, const float* bias, const float* add, float* y, int C, int R, int H, int W, int shuffle, int act, hipStream_t s) {
+    const dim3 grid(C * R);
+    if (shuffle) {
+        if (act == ACT_MISH) hipLaunchKernelGGL((instnorm_reg_kernel<PER, NT, true, ACT_MISH>), grid, dim3(NT), 0, s, x, bias, add, y, C, R, H, W);
+        else hipLaunchKernelGGL((instnorm_reg_kernel<PER, NT, true, ACT_NONE>), grid, dim3(NT), 0, s, x, bias, add, y, C, R, H, W);
+    } else {
+        if (act == ACT_MISH) hipLaunchKernelGGL((instnorm_reg_kernel<PER, NT, false, ACT_MISH>), grid, dim3(NT), 0, s, x, bias, add, y, C, R, H, W);
+        else hipLaunchKernelGGL((instnorm_reg_kernel<PER, NT, false, ACT_NONE>), grid, dim3(NT), 0, s, x, bias, add, y, C, R, H, W);
     }
 }
 static int instnorm(const float* x, const float* bias, const float* add, float* y, int C, int R, int H, int W, int shuffle, int act, hipStream_t s) {
     const int HW = H * W; const dim3 grid(C * R);
-    if (HW <= 512) hipLaunchKernelGGL(instnorm_reg_kernel<2>, grid, dim3(256), 0, s, x, bias, add, y, C, R, H, W, shuffle, act);
-    else if (HW <= 1792) hipLaunchKernelGGL(instnorm_reg_kernel<7>, grid, dim3(256), 0, s, x, bias, add, y, C, R, H, W, shuffle, act);
-    else if (HW <= 7168) hipLaunchKernelGGL(instnorm_reg_kernel<28>, grid, dim3(256), 0, s, x, bias, add, y, C, R, H, W, shuffle, act);
-    else if (HW <= 28416) hipLaunchKernelGGL(instnorm_reg_kernel<111>, grid, dim3(256), 0, s, x, bias, add, y, C, R, H, W, shuffle, act);
+    const bool reg = (act == ACT_MISH || act == ACT_NONE) && W <= 256 && W >= 8;
+    if (reg && HW <= 512) launch_instnorm_reg<2, 256>(x, bias, add, y, C, R, H, W, shuffle, act, s);
+    else if (reg && HW <= 1792) launch_instnorm_reg<7, 256>(x, bias, add, y, C, R, H, W, shuffle, act, s);
+    else if (reg && HW <= 7168) launch_instnorm_reg<7, 1024>(x, bias, add, y, C, R, H, W, shuffle, act, s);
+    else if (reg && HW <= 28672) launch_instnorm_reg<28, 1024>(x, bias, add, y, C, R, H, W, shuffle, act, s);
     else hipLaunchKernelGGL(instnorm_kernel, grid, dim3(256), 0, s, x, bias, add, y, C, R, H, W, shuffle, act);
     AID_LAUNCH_CHECK();
     return AID_OK;
 }
 // latent_proj tail: LayerNorm over F = C*HW features of a row, Mish, stored CNHW ([C][R][HW]) for the conv stack
-__global__ void __launch_bounds__(1024) bigln_mish_cnhw_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                float* __restrict__ y, int R, int C, int HW) {
+// (round 4) two launches of R x C / 16 workgroups instead of one of R (16 rows = 16 workgroups on 256 CUs, three passes, an integer division per element: 264 us):
+// partial sums of 16-channel chunks around the row's first element, then every workgroup folds the row's partials in the same order and normalises its chunk.
+constexpr int BLM_CH = 16;
+__global__ void __launch_bounds__(256) bigln_mish_part_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int HW) {
     __shared__ float sh[16];
-    const int r = blockIdx.x; const size_t F = (size_t)C * HW;
-    const float* xr = x + (size_t)r * F;
-    float s = 0.f;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
-    const float mean = wg_sum256(s, sh) / (float)F;
-    float q = 0.f;
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
-    for (size_t i = threadIdx.x; i < F; i += blockDim.x) {
-        const int c = i / HW, p = i % HW;
-        y[((size_t)c * R + r) * HW + p] = act_apply((xr[i] - mean) * rstd * gamma[i] + beta[i], ACT_MISH);
+    const int nch = C / BLM_CH, r = blockIdx.x / nch, ch = blockIdx.x % nch;
+    const size_t F = (size_t)C * HW;
+    const float* xr = x + (size_t)r * F; const float x0 = xr[0];
+    const float* xc = xr + (size_t)ch * BLM_CH * HW;
+    float s = 0.f, q = 0.f;
+    for (int i = threadIdx.x; i < BLM_CH * HW; i += 256) { const float d = xc[i] - x0; s += d; q += d * d; }
+    const float ts = wg_sum256(s, sh), tq = wg_sum256(q, sh);
+    if (threadIdx.x == 0) { part[2 * blockIdx.x] = ts; part[2 * blockIdx.x + 1] = tq; }
+}
+__global__ void __launch_bounds__(256) bigln_mish_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ y, int R, int C, int HW) {
+    const int nch = C / BLM_CH, r = blockIdx.x / nch, ch = blockIdx.x % nch;
+    const size_t F = (size_t)C * HW;
+    const float* xr = x + (size_t)r * F; const float x0 = xr[0];
+    float s = 0.f, q = 0.f;
+    for (int j = 0; j < nch; ++j) { s += part[2 * (r * nch + j)]; q += part[2 * (r * nch + j) + 1]; }      // the same order in every workgroup of the row
+    const float ms = s / (float)F, var = fmaxf(q / (float)F - ms * ms, 0.f), mean = x0 + ms, rstd = 1.0f / sqrtf(var + 1e-5f);
+    for (int cc = 0; cc < BLM_CH; ++cc) {
+        const int c = ch * BLM_CH + cc;
+        const float* xc = xr + (size_t)c * HW; const float* gc = gamma + (size_t)c * HW; const float* bc = beta + (size_t)c * HW;
+        float* yc = y + ((size_t)c * R + r) * HW;
+        for (int p = threadIdx.x; p < HW; p += 256) yc[p] = mish_fast((xc[p] - mean) * rstd * gc[p] + bc[p]);
     }
+}
+static int bigln_mish_cnhw(const float* x, const float* gamma, const float* beta, float* y, int R, int C, int HW, Workspace& ws, hipStream_t s) {
+    AID_REQUIRE(C % BLM_CH == 0, AID_E_SHAPE, "bigln_mish_cnhw: %d channels", C);
+    const size_t mark = ws.mark();
+    float* part = ws.f32((size_t)2 * R * (C / BLM_CH)); AID_WS_OK(ws);
+    hipLaunchKernelGGL(bigln_mish_part_kernel, dim3(R * (C / BLM_CH)), dim3(256), 0, s, x, part, C, HW);
+    hipLaunchKernelGGL(bigln_mish_apply_kernel, dim3(R * (C / BLM_CH)), dim3(256), 0, s, x, part, gamma, beta, y, R, C, HW);
+    AID_LAUNCH_CHECK();
+    ws.release(mark);
+    return AID_OK;
 }
 // out[r][c][p] = sigmoid(x[c][r][p] + bias[c])      (CNHW -> NCHW)
 __global__ void sigmoid_nchw_kernel(const float* __restrict__ x, const float* __restrict__ bias, float* __restrict__ out, int C, int R, int HW) {
@@ -1100,7 +1149,7 @@ static int conv_decoder_trunk(const AidConvDecoder& d, const DecPrep& p, int R, 
     const size_t amax = (size_t)R * ((size_t)3528 * H > 32u * 168 * 168 ? (size_t)3528 * H : 32u * 168 * 168);
     float* xa = ws.f32(amax); float* xb = ws.f32(amax); float* cv = ws.f32(amax); float* cr = ws.f32(2 * amax);   // cr: 1x1-conv output + its IN
     AID_WS_OK(ws);
-    hipLaunchKernelGGL(bigln_mish_cnhw_kernel, dim3(R), dim3(1024), 0, s, big, d.ln5.g, d.ln5.b, xa, R, H, HW0);
+    AID_TRY(bigln_mish_cnhw(big, d.ln5.g, d.ln5.b, xa, R, H, HW0, ws, s));
     AID_LAUNCH_CHECK();
     // ---- decoder blocks
     int hsz = 21;

@@ -417,3 +417,31 @@ def test_dead_next_belief_elision_changes_nothing(B):
     np.testing.assert_allclose(b["tiw"].numpy(), a["tiw"].numpy(), rtol=1e-5, atol=1e-7)
     for k in a["last"]:
         np.testing.assert_allclose(b["last"][k].numpy(), a["last"][k].numpy(), rtol=1e-5, atol=1e-6, err_msg=k)
+
+
+def test_denoise_start_join_equals_the_paired_loop():
+    """DiffusionActiveInference.denoise_start / denoise_join (what the pixel agent uses to run the belief over obs underneath encode(next_obs) and the one over
+    next_obs underneath the ELBO): two separately started chains on the process's chain streams give the latents of the paired loop on the same explicit
+    noise; outside (128, CHAIN_MAX_ROWS] rows, or with concurrent loops switched off, the caller is told to take the merged loop (None)."""
+    O, A, D, N, H, B = 17, 6, 64, 4, 2, 160
+    agent = _agent(O, A, D, N, H, B, cap=256)
+    ai = agent.active_inference
+    rng = np.random.default_rng(6)
+    obs = [torch.from_numpy(rng.standard_normal((B, O)).astype(np.float32)).cuda() for _ in range(2)]
+    pn = ParityNoise(32)
+    noises = [pn.belief(B, ai.latent_dim, D, N, True) for _ in range(2)]
+    ai.concurrent_belief_loops = True
+    pair = ai.denoise_pair(obs[0], obs[1], noises[0], noises[1])
+    h0 = ai.denoise_start(obs[0], 0, noises[0])
+    h1 = ai.denoise_start(obs[1], 1, noises[1])
+    assert h0 is not None and h1 is not None and h0["stream"].cuda_stream != h1["stream"].cuda_stream
+    a, b = ai.denoise_join(h0), ai.denoise_join(h1)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(torch.cat([a, b]).cpu().numpy(), pair.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # replays reuse the chain's output buffer: the joined latents are copies
+    h0b = ai.denoise_start(obs[1], 0, noises[1]); a2 = ai.denoise_join(h0b); torch.cuda.synchronize()
+    np.testing.assert_allclose(a2.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    assert not torch.equal(a, a2)
+    assert ai.denoise_start(obs[0][:64], 0, None) is None
+    ai.concurrent_belief_loops = False
+    assert ai.denoise_start(obs[0], 0, noises[0]) is None

@@ -241,7 +241,7 @@ int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin,
     // up to 32 output channels: 32 x 128 tiles (a 64-row tile would be half empty); up to 64: 64 x 64 in 16-deep stages (19 KB)
 #define IG_LAUNCH(TM_, BK_, WN_) do { constexpr int BM_ = 32 * TM_ * (4 / WN_), BN_ = 32 * WN_; constexpr size_t lds = sizeof(float) * 2 * (BM_ * (BK_ + 4) + BK_ * (BN_ + 4)); \
         hipLaunchKernelGGL((conv3_igemm_kernel<TM_, BK_, WN_>), dim3((unsigned)((g.N + BN_ - 1) / BN_), (Cout + BM_ - 1) / BM_), dim3(256), lds, s, g); } while (0)
-    if (g_ig_dbg && Cout > 64) {      // timing experiments (aid_conv_debug; results are wrong by construction)
+    if (g_ig_dbg && g_ig_dbg < 10 && Cout > 64) {      // timing experiments (aid_conv_debug; results are wrong by construction)
 #define IG_LAUNCH_D(D_) do { constexpr size_t lds = sizeof(float) * 2 * (128 * 20 + 16 * 68); \
         hipLaunchKernelGGL((conv3_igemm_kernel<2, 16, 2, D_>), dim3((unsigned)((g.N + 63) / 64), (Cout + 127) / 128), dim3(256), lds, s, g); } while (0)
         if (g_ig_dbg == 1) IG_LAUNCH_D(1); else if (g_ig_dbg == 2) IG_LAUNCH_D(2); else if (g_ig_dbg == 3) IG_LAUNCH_D(3); else IG_LAUNCH_D(4);
@@ -257,6 +257,10 @@ int conv3_igemm_ex(const float* W, int ldw, const float* x, float* out, int Cin,
     if (vec4) {
         if (Cout <= 32) IG_LAUNCH_V(1, 32, 4);
         else if (Cout <= 64) IG_LAUNCH_V(1, 16, 2);
+        // >= 128 output channels over >= 65 536 pixels: 128 x 128 tiles, a wave owns 128 x 32 (four accumulator blocks per gathered fragment instead of two; 37 KB of
+        // LDS): encoder layer 3 forward 105 -> 116 TFLOP/s, its data gradient 112 -> 118, ConvDecoder 128 -> 256 at 84 x 84 104 -> 112; on the 21 x 21 / 42 x 42 planes of
+        // 16 images (441 - 1 764 tiles) the smaller tile fills the chip better (82 against 79); 32-deep stages lose everywhere but there (tools/perf/conv_tiles.py)
+        else if (Cout >= 128 && g.N >= 65536 && g_ig_dbg != 22) IG_LAUNCH_V(4, 16, 4);
         else IG_LAUNCH_V(2, 16, 2);
     }
     else if (w_tap_major) {

@@ -96,7 +96,7 @@ int aid_gemm_w4(const float* A, int lda, const float* W, int ldw, const float* b
 /* timing experiments (process-wide, outside the product path; tools/perf): force the row-tile height of the mid-M kernel to >= 32 bmt_min rows (1 = automatic);
  * aid_denoise_debug(n > 0): cap the number of denoise steps that share one hoisted conditioning pass (0 = automatic); -1 / -2: the <= 128-row loop on the
  * gemm_w4 pipeline (default) / on the weight-streaming skinny kernels; -5 / -6: the next step's adaLN as the reverse-step kernel's tail on (default) / off;
- * aid_conv_debug: 10 / 11 four-pixel vector gathers of the tap-major convolutions off / on (default), 1..4 ablation variants of the non-tap-major 128 x 64 tile
+ * aid_conv_debug: 10 / 11 four-pixel vector gathers of the tap-major convolutions off / on (default), 12 / 13 the tap-major weight-gradient kernel off / on (default), 22 no 128 x 128 tiles, 1..4 ablation variants of the non-tap-major 128 x 64 tile
  * (results wrong by construction, tools/perf/conv_ablation.py), 0 = normal; aid_rowln_debug(40 / 41): the estimator's 1024-wide stage as co-resident 512-column
  * blocks + a LayerNorm pass on / off (default), other codes see csrc/gemm_rowln.hip */
 int aid_mid_debug(int bmt_min);

@@ -684,7 +684,8 @@ def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):
 
 
 @pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2),
-                                                   (32, 32, 3, 21, 1), (64, 32, 2, 30, 1), (32, 3, 2, 17, 1), (16, 80, 3, 13, 2)])
+                                                   (32, 32, 3, 21, 1), (64, 32, 2, 30, 1), (32, 3, 2, 17, 1), (16, 80, 3, 13, 2),
+                                                   (32, 128, 40, 42, 1), (16, 160, 38, 42, 1)])        # >= 65 536 pixels x >= 128 channels: the 128 x 128 tile
 def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     """csrc/conv_igemm.hip against torch's conv2d on the CPU (fp64): forward (border taps, stride 2, ragged channel counts), the data
     gradient through the flipped weights, the weight gradient (slab-split contraction over B Ho Wo) - and, where the channel counts allow it, the

@@ -72,3 +72,33 @@ def test_bench_eight_ranks_under_torch_distributed_run():
                        env=env, capture_output=True, text=True, timeout=600)
     out = _line(r)
     assert out["n_gpus"] == 8 and out["scaling"] == "strong" and out["data_parallel"]["rccl_ranks_seen"] == 8 and out["config"]["rows_per_rank"] == 32
+
+
+def test_bench_line_is_compact_strict_json():
+    """The driver reads ONE stdout line through a bounded window (round 4: a 25.9 KB line came back `parsed: null`).  Build the line from a canned
+    full result (round 4's, committed under profiles/) and check: < 8000 characters, strict JSON (no NaN / Infinity tokens), the contract keys,
+    `roofline` for the dominant kernel only with `traffic`, `cpu_baseline`; the bulky objects stay out."""
+    import importlib.util
+    import math
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    full = json.load(open(os.path.join(ROOT, "profiles", "r04_bench.json")))
+    full["data_parallel"] = {"rccl_ranks_seen": 8, "backend": "nccl", "per_rank_ms_per_step": [50.123456789] * 8, "per_rank_ms_per_step_dead_belief_elided": [44.1] * 8,
+                             "rows_per_rank": 256, "scaling": "weak", "belief_loop_schedule": "chains", "belief_loop_schedule_ms": {"chains": 1.0, "merged": 2.0}}
+    full["roofline"]["frac_rocprof"] = 0.27; full["roofline"]["junk"] = "x" * 5000
+    full["train_step_live_flop"] = float("nan")          # a non-finite value must not reach the line as a bare NaN token
+    txt = bench.compact_line(full)
+    assert "\n" not in txt and len(txt) < 8000, len(txt)
+    line = json.loads(txt, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "value_dead_belief_elided", "train_step_frac_of_f32_mfma_peak", "data_parallel"):
+        assert k in line, k
+    assert line["config"]["workload"] and "model" not in line["config"]
+    r = line["roofline"]
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(r) and "junk" not in r and "note" not in r
+    assert math.isclose(r["frac"], r["achieved"] / r["peak"], rel_tol=1e-4)
+    assert set(("value", "unit", "cores", "kind", "sample")) <= set(line["cpu_baseline"])
+    for k in ("roofline_phases", "roofline_kernels", "other_configs", "small_batch", "roofline_single_stream_kernels"):
+        assert k not in line
+    assert set(line["other_configs_ms"]) >= {"cfg1_b32", "cfg3_hopper_b1024", "cfg4_pixel_b256"}
+    assert "train_step_live_flop" not in line or line["train_step_live_flop"] is None

@@ -250,6 +250,11 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
             self.encoder.backward(ai._last_d_obs, ctx_a)
             self.encoder.backward(d_next, ctx_b)
             self._mark("side: encoder backward x2 done", side)
+            # chain b (the belief over next_obs) reads the score-network weights in place on its chain stream: the AdamW / EMA step must not
+            # rewrite them before that loop has finished (the reference computes next_latents before score_optimizer.step(), pixel_agent.py:307 vs
+            # :332).  Only the step waits; the encoder backward passes above still overlap the chain.
+            if h_b is not None:
+                side.wait_stream(h_b["stream"])
             self.score_optimizer.step()
             self._mark("side: score / encoder step done", side)
         if self.overlap_streams:

@@ -404,7 +404,9 @@ class DiffusionActiveInference(nn.Module):
     # With explicit noise tensors (parity tests) both paths consume exactly those tensors.
     graph_belief_loops = True
 
-    def _chain_graph(self, slot: int, rows: int, N: int, train: bool, stream):
+    def _chain_graph(self, slot, rows: int, N: int, train: bool, stream):
+        """`slot`: an int for the chains of _denoise_chains (slot i replays on streams[i]), ("start", i) for denoise_start's (replays on chain stream i):
+        the two APIs map a slot number to DIFFERENT streams, so they never share a captured graph or its persistent buffers."""
         from ..streams import chain_streams
         tab = self.latent_score_network.table()
         stream = chain_streams(stream.device)[0]          # captured on a chain stream (never the default stream), replayed on whichever stream runs the chain
@@ -416,6 +418,7 @@ class DiffusionActiveInference(nn.Module):
                 # the graphs' buffers were allocated on chain stream 0 and are replayed on the side / main / chain-1 streams without
                 # record_stream: nothing may be in flight when the allocator gets them back
                 torch.cuda.synchronize(self.device)
+                self.__dict__.setdefault("_open_chains", {}).clear()
                 cache.clear()
             L, D = self.latent_dim, self.config.hidden_dim
             with torch.cuda.stream(stream):
@@ -471,8 +474,20 @@ class DiffusionActiveInference(nn.Module):
             self.graph_belief_loops = False
             return None
 
+    def _settle_open_chains(self, streams):
+        """A denoise_start handle that was never joined (an exception or early return between start and join) leaves its loop in flight on a chain
+        stream: anything that is about to use one of `streams` first orders itself behind it, so no two loops ever interleave on the workspaces
+        and stream-ordered buffers of a chain stream."""
+        open_ = self.__dict__.setdefault("_open_chains", {})
+        for key in [k for k in open_ if any(k == st.cuda_stream for st in streams)]:
+            h = open_.pop(key)
+            for st in streams:
+                st.wait_stream(h["stream"])
+            h["joined"] = True
+
     def _denoise_chains(self, obs_list, noises, ws, N, train, streams) -> torch.Tensor:
         first = streams[0]
+        self._settle_open_chains(streams)
         wss = [ws or self._ws] + (getattr(self, "_chain_ws", None) or [])[:len(streams) - 1]
         obs_list = [o.to(self.device).float().contiguous() for o in obs_list]
         offs = [self.noise.next_offset() for _ in obs_list]
@@ -509,17 +524,26 @@ class DiffusionActiveInference(nn.Module):
         graph = None
         if self.graph_belief_loops:
             try:
-                graph = self._chain_graph(slot, rows, N, train, st)
+                graph = self._chain_graph(("start", slot), rows, N, train, st)
             except RuntimeError as e:
                 import warnings
                 warnings.warn(f"aid_amd: hipGraph capture of the belief-update loops failed ({e}); launching them directly from now on")
                 self.graph_belief_loops = False
+        self._settle_open_chains([st])                      # a previous, never-joined loop on this chain stream: this one queues behind it
         st.wait_stream(first)
         out = self._launch_chain(slot, observation, noise, st, first, N, train, self._chain_ws[slot], off, graph)
-        return {"out": out, "stream": st}
+        h = {"out": out, "stream": st, "joined": False}
+        self.__dict__.setdefault("_open_chains", {})[st.cuda_stream] = h
+        return h
 
     def denoise_join(self, handle) -> torch.Tensor:
+        if handle.get("joined"):
+            raise RuntimeError("denoise_join: this belief-update handle was already joined (its output buffer belongs to the chain's next replay)")
         torch.cuda.current_stream().wait_stream(handle["stream"])
+        handle["joined"] = True
+        open_ = self.__dict__.setdefault("_open_chains", {})
+        if open_.get(handle["stream"].cuda_stream) is handle:
+            del open_[handle["stream"].cuda_stream]
         return handle["out"].clone()          # the chain's output buffer is reused by its next replay
 
     def denoise_pair(self, obs_a: torch.Tensor, obs_b: torch.Tensor, noise_a: Optional[dict] = None, noise_b: Optional[dict] = None) -> torch.Tensor:

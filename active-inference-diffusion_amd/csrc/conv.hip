@@ -408,43 +408,53 @@ __global__ void attn_bwd_c_fold_kernel(const float* __restrict__ part, int parts
 
 // ---- LayerNorm over F = 451 584 features, one workgroup per row -----------------------------------------------------------------------
 // LayerNorm over the F = 451 584 flattened conv features of a row (1.8 MB: neither registers nor LDS hold it), one 1024-thread workgroup per row.
-// 16-byte accesses, four in flight per thread; the statistics in ONE pass over the row (sums of (x - x0) and (x - x0)^2 around the row's first
-// element: the shift keeps the variance formula away from cancellation), the normalisation in a second: x is read twice instead of three times and
-// every access is a float4 (the first form was 0.74 ms per 256 rows = 1.25 TB/s).  F % 4 == 0 and 16-byte aligned rows (checked by the caller), else
-// the element loop.
+// 16-byte accesses, four in flight per thread; the statistics in ONE pass over the row, the normalisation in a second: x is read twice and every access is
+// a float4.  The two row sums (x and x^2; in the backward dy gamma and dy gamma x_hat) are ACCUMULATED IN FLOAT64: the kernels are HBM-bound, so the
+// eight extra VALU operations per float4 are free, E[x^2] - mean^2 in float64 has no cancellation problem at any offset of the row (the float32 form
+// shifted by x[0] did when x[0] was an outlier), and the 451 584-term sums carry no float32 rounding at all - what is left against the float32
+// reference is the reference's own rounding.  The rounded float32 mean / rstd are what the row is normalised with and what the backward reads.
+// F % 4 == 0 and 16-byte aligned rows (checked by the caller) for the float4 loop, else the element loop (same float64 sums: same statistics).
+__device__ __forceinline__ double wg_sum_d(double v, double* sh) {      // <= 1024 threads, every thread gets the total; fixed order
+    v = wave_sum_d(v);
+    const int w = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[w] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < nw; ++i) t += sh[i];
+    return t;
+}
 __global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
                                                      float* __restrict__ stats, size_t F, int vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ float sh[16];
+    __shared__ double shd[16];
     const float* xr = x + (size_t)blockIdx.x * F; float* yr = y + (size_t)blockIdx.x * F;
+    const size_t F4 = F / 4;
+    const f4* x4 = reinterpret_cast<const f4*>(xr);
+    double s = 0.0, q = 0.0;
     if (!vec) {
-        float s = 0.f;
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) s += xr[i];
-        const float mean = wg_sum256(s, sh) / (float)F;
-        float q = 0.f;
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float d = xr[i] - mean; q += d * d; }
-        const float rstd = 1.0f / sqrtf(wg_sum256(q, sh) / (float)F + 1e-5f);
-        if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const double v = (double)xr[i]; s += v; q += v * v; }
+    } else {
+        for (size_t i = threadIdx.x; i < F4; i += 4 * (size_t)blockDim.x) {
+            f4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const size_t j = i + u * (size_t)blockDim.x; v[u] = j < F4 ? x4[j] : (f4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                // four elements folded in float32 products would round: each term goes to float64 on its own (exact squares: 24-bit x 24-bit fits 53)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const double d = (double)v[u][e]; s += d; q += d * d; }
+            }
+        }
+    }
+    const double md = wg_sum_d(s, shd) / (double)F;
+    const double vard = fmax(wg_sum_d(q, shd) / (double)F - md * md, 0.0);
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(vard + 1e-5));
+    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
+    if (!vec) {
         for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
         return;
     }
-    const size_t F4 = F / 4;
-    const f4* x4 = reinterpret_cast<const f4*>(xr);
-    const float x0 = xr[0];
-    float s = 0.f, q = 0.f;
-    for (size_t i = threadIdx.x; i < F4; i += 4 * (size_t)blockDim.x) {
-        f4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const size_t j = i + u * (size_t)blockDim.x; v[u] = j < F4 ? x4[j] : (f4){x0, x0, x0, x0}; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float d = v[u][e] - x0; s += d; q += d * d; }
-    }
-    const float ms = wg_sum256(s, sh) / (float)F;                      // mean - x0
-    const float var = fmaxf(wg_sum256(q, sh) / (float)F - ms * ms, 0.f);
-    const float mean = x0 + ms, rstd = 1.0f / sqrtf(var + 1e-5f);
-    if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
     const f4* g4 = reinterpret_cast<const f4*>(gamma); const f4* b4 = reinterpret_cast<const f4*>(beta); f4* y4 = reinterpret_cast<f4*>(yr);
     for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
         const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
@@ -460,13 +470,13 @@ __global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x
 __global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
                                                          const float* __restrict__ stats, float* __restrict__ dx, size_t F, int vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
-    __shared__ float sh[16];
+    __shared__ double shd[16];
     const float* xr = x + (size_t)blockIdx.x * F; const float* dyr = dy + (size_t)blockIdx.x * F; float* dxr = dx + (size_t)blockIdx.x * F;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
-    float sg = 0.f, sgx = 0.f;
+    double sg = 0.0, sgx = 0.0;
     if (!vec) {
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += g; sgx += g * (xr[i] - mean) * rstd; }
-        const float mg = wg_sum256(sg, sh) / (float)F, mgx = wg_sum256(sgx, sh) / (float)F;
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += (double)g; sgx += (double)(g * ((xr[i] - mean) * rstd)); }
+        const float mg = (float)(wg_sum_d(sg, shd) / (double)F), mgx = (float)(wg_sum_d(sgx, shd) / (double)F);
         for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr[i] - mean) * rstd * mgx);
         return;
     }
@@ -479,11 +489,11 @@ __global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict
         const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float g0 = e0[e] * c0[e]; sg += g0; sgx += g0 * (a0[e] - mean) * rstd;
-            if (two) { const float g1 = e1[e] * c1[e]; sg += g1; sgx += g1 * (a1[e] - mean) * rstd; }
+            const float g0 = e0[e] * c0[e]; sg += (double)g0; sgx += (double)(g0 * ((a0[e] - mean) * rstd));
+            if (two) { const float g1 = e1[e] * c1[e]; sg += (double)g1; sgx += (double)(g1 * ((a1[e] - mean) * rstd)); }
         }
     }
-    const float mg = wg_sum256(sg, sh) / (float)F, mgx = wg_sum256(sgx, sh) / (float)F;
+    const float mg = (float)(wg_sum_d(sg, shd) / (double)F), mgx = (float)(wg_sum_d(sgx, shd) / (double)F);
     for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
         const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
         const f4 a0 = x4[i], c0 = g4[i], e0 = d4[i];
@@ -550,6 +560,16 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
 }
 
 static int conv_slabs(size_t N) { int s = (int)(N / 8192); return s < 1 ? 1 : (s > 96 ? 96 : s); }
+// K slices of the encoder head's Linear(F -> 2L) forward (gemm_f32's deep-K slab route): about two workgroups per CU (128 x 128 tiles from 128 rows,
+// 64 x 64 below), a multiple of 8 so that a slice's tiles share an XCD, every slice at least 1 024 deep
+static int head_slabs(size_t F, int B, int N) {
+    const int bm = B >= 128 ? 128 : 64, tiles = ((B + bm - 1) / bm) * ((N + bm - 1) / bm);
+    int s = ((512 / tiles) + 7) / 8 * 8;
+    const int cap = (int)(F / 1024) / 8 * 8;
+    if (s > cap) s = cap;
+    if (s > 256) s = 256;
+    return s < 1 ? 1 : s;
+}
 // slabs of a conv weight gradient [cout][kp]: enough (tile, slab) workgroups to fill the chip (~2 000) when the gradient itself is only a few
 // 64 x 64 tiles (layer 0: 32 x 81 = 2 tiles), each slab at least 1 024 columns; never more floats than 96 slabs of the widest layer
 static int conv_dw_slabs(size_t N, int cout, int kp) {
@@ -703,25 +723,27 @@ static int instnorm(const float* x, const float* bias, const float* add, float* 
 // (round 4) two launches of R x C / 16 workgroups instead of one of R (16 rows = 16 workgroups on 256 CUs, three passes, an integer division per element: 264 us):
 // partial sums of 16-channel chunks around the row's first element, then every workgroup folds the row's partials in the same order and normalises its chunk.
 constexpr int BLM_CH = 16;
-__global__ void __launch_bounds__(256) bigln_mish_part_kernel(const float* __restrict__ x, float* __restrict__ part, int C, int HW) {
-    __shared__ float sh[16];
+// (round 5) the chunk sums of x and x^2 are taken and folded in float64 (no shift by the row's first element: that form cancelled when x[0] was an
+// outlier of the row); HBM-bound, the float64 adds are free.
+__global__ void __launch_bounds__(256) bigln_mish_part_kernel(const float* __restrict__ x, double* __restrict__ part, int C, int HW) {
+    __shared__ double shd[16];
     const int nch = C / BLM_CH, r = blockIdx.x / nch, ch = blockIdx.x % nch;
     const size_t F = (size_t)C * HW;
-    const float* xr = x + (size_t)r * F; const float x0 = xr[0];
-    const float* xc = xr + (size_t)ch * BLM_CH * HW;
-    float s = 0.f, q = 0.f;
-    for (int i = threadIdx.x; i < BLM_CH * HW; i += 256) { const float d = xc[i] - x0; s += d; q += d * d; }
-    const float ts = wg_sum256(s, sh), tq = wg_sum256(q, sh);
+    const float* xc = x + (size_t)r * F + (size_t)ch * BLM_CH * HW;
+    double s = 0.0, q = 0.0;
+    for (int i = threadIdx.x; i < BLM_CH * HW; i += 256) { const double d = (double)xc[i]; s += d; q += d * d; }
+    const double ts = wg_sum_d(s, shd), tq = wg_sum_d(q, shd);
     if (threadIdx.x == 0) { part[2 * blockIdx.x] = ts; part[2 * blockIdx.x + 1] = tq; }
 }
-__global__ void __launch_bounds__(256) bigln_mish_apply_kernel(const float* __restrict__ x, const float* __restrict__ part, const float* __restrict__ gamma,
+__global__ void __launch_bounds__(256) bigln_mish_apply_kernel(const float* __restrict__ x, const double* __restrict__ part, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, float* __restrict__ y, int R, int C, int HW) {
     const int nch = C / BLM_CH, r = blockIdx.x / nch, ch = blockIdx.x % nch;
     const size_t F = (size_t)C * HW;
-    const float* xr = x + (size_t)r * F; const float x0 = xr[0];
-    float s = 0.f, q = 0.f;
+    const float* xr = x + (size_t)r * F;
+    double s = 0.0, q = 0.0;
     for (int j = 0; j < nch; ++j) { s += part[2 * (r * nch + j)]; q += part[2 * (r * nch + j) + 1]; }      // the same order in every workgroup of the row
-    const float ms = s / (float)F, var = fmaxf(q / (float)F - ms * ms, 0.f), mean = x0 + ms, rstd = 1.0f / sqrtf(var + 1e-5f);
+    const double md = s / (double)F, vard = fmax(q / (double)F - md * md, 0.0);
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(vard + 1e-5));
     for (int cc = 0; cc < BLM_CH; ++cc) {
         const int c = ch * BLM_CH + cc;
         const float* xc = xr + (size_t)c * HW; const float* gc = gamma + (size_t)c * HW; const float* bc = beta + (size_t)c * HW;
@@ -732,7 +754,7 @@ __global__ void __launch_bounds__(256) bigln_mish_apply_kernel(const float* __re
 static int bigln_mish_cnhw(const float* x, const float* gamma, const float* beta, float* y, int R, int C, int HW, Workspace& ws, hipStream_t s) {
     AID_REQUIRE(C % BLM_CH == 0, AID_E_SHAPE, "bigln_mish_cnhw: %d channels", C);
     const size_t mark = ws.mark();
-    float* part = ws.f32((size_t)2 * R * (C / BLM_CH)); AID_WS_OK(ws);
+    double* part = reinterpret_cast<double*>(ws.f32((size_t)4 * R * (C / BLM_CH))); AID_WS_OK(ws);       // 256-B aligned: two float64 per chunk
     hipLaunchKernelGGL(bigln_mish_part_kernel, dim3(R * (C / BLM_CH)), dim3(256), 0, s, x, part, C, HW);
     hipLaunchKernelGGL(bigln_mish_apply_kernel, dim3(R * (C / BLM_CH)), dim3(256), 0, s, x, part, gamma, beta, y, R, C, HW);
     AID_LAUNCH_CHECK();
@@ -791,7 +813,7 @@ size_t aid_encoder_workspace(const AidEncoderNet* enc, int B) {
     size_t act = 0;
     for (int i = 0; i < ENC_LAYERS; ++i) { const size_t a = (size_t)g.cout[i] * B * g.ho[i] * g.ho[i]; if (a > act) act = a; }
     // 3 activation-sized buffers, the flipped weights of one layer, <= 96 weight-gradient slabs, the slabs of the 451 584-wide Linear
-    size_t n = sizeof(float) * (3 * act + 2 * (size_t)B * g.F + 4 * N + (size_t)256 * 2304 + 97 * (size_t)256 * 1152 + (size_t)96 * B * enc->out0.out + (1 << 20));
+    size_t n = sizeof(float) * (3 * act + 2 * (size_t)B * g.F + 4 * N + (size_t)256 * 2304 + 97 * (size_t)256 * 1152 + (size_t)256 * B * enc->out0.out + (1 << 20));
     return n + (1 << 20);
 }
 
@@ -851,7 +873,7 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     AID_LAUNCH_CHECK();
     {   // Linear(F -> 2L): deterministic split-K
         const size_t mark = ws.mark();
-        const int S = conv_slabs(g.F);
+        const int S = head_slabs(g.F, B, e.out0.out);
         GemmArgs ga = gemm_args(sv.xln, (int)g.F, e.out0.w, (int)g.F, sv.s0.lin, e.out0.out, B, e.out0.out, (int)g.F);
         ga.bias = e.out0.b; ga.slab = ws.f32((size_t)S * B * e.out0.out); ga.nslab = S; AID_WS_OK(ws);
         AID_TRY(gemm_f32(ga, s));

@@ -361,9 +361,15 @@ __device__ __forceinline__ void tile_coords_big(int b, int tiles_m, int tiles_n,
     tile_coords(b, tiles_m, tiles_n, tm, tn);
 }
 
-template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD>
+// FL > 0 (slab mode, PD == 2 only): "deep-K" form for contractions hundreds of thousands deep (the encoder's Linear(451 584 -> 2L)).  The MFMA
+// accumulators are added into a second accumulator set and cleared every FL stages (FL x BKT k-values), so no float32 sum in the kernel is a chain of
+// more than FL x BKT roundings followed by a chain of (slice depth / (FL x BKT)) - a blocked summation whose error grows with the square root of those
+// lengths instead of the slice depth - and the slices are folded in float64 (slab_fold_kernel).  The grid is 1-D with the workgroups of one K slice
+// dealt to ONE XCD (b % 8), so the A / B slice a 128 x 128 tile shares with its neighbours is fetched through that XCD's L2 once.
+template <int BM, int BN, int BKT, bool AKM, bool BKM, int PD, int FL = 0>
 __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, int map) {
     constexpr int NT = 256;
+    static_assert(FL == 0 || (PD == 2 && FL % 2 == 0), "the flush sits behind the odd step of the two-stage loop");
     constexpr int TM = BM / 64, TN = BN / 64;
     using TA = TileK<BM, AKM, BKT>; using TB = TileK<BN, BKM, BKT>;
     constexpr int PA = (TA::F4 + NT - 1) / NT, PB = (TB::F4 + NT - 1) / NT;
@@ -373,19 +379,29 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, h = lane >> 5;
     const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
-    int tm_, tn_; tile_coords_big(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, map, tm_, tn_);
+    int tm_, tn_, slice = blockIdx.y, nslice = gridDim.y;
+    if constexpr (FL > 0) {
+        const int tiles = ((g.M + BM - 1) / BM) * tiles_n, b = blockIdx.x;
+        int t;
+        nslice = g.nslab;
+        if (nslice % 8 == 0) { const int i = b >> 3; t = i % tiles; slice = (i / tiles) * 8 + (b & 7); }
+        else { t = b % tiles; slice = b / tiles; }
+        tm_ = t / tiles_n; tn_ = t % tiles_n;
+    } else
+        tile_coords_big(blockIdx.x, (g.M + BM - 1) / BM, tiles_n, map, tm_, tn_);
     const int m0 = tm_ * BM, n0 = tn_ * BN;
     f32x16 acc[TM][TN];
+    f32x16 acc2[FL > 0 ? TM : 1][FL > 0 ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    // slab mode (deterministic split-K): blockIdx.y owns a contiguous range of K tiles and writes its partial tile to slab[y]
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (FL > 0) acc2[i][j][r] = 0.f; }
+    // slab mode (deterministic split-K): a slice owns a contiguous range of K tiles and writes its partial tile to slab[slice]
     const int nk_all = (g.K + BKT - 1) / BKT;
-    const int per = (nk_all + gridDim.y - 1) / gridDim.y;
-    const int ktb = blockIdx.y * per;                                  // first K tile of this slice
+    const int per = (nk_all + nslice - 1) / nslice;
+    const int ktb = slice * per;                                       // first K tile of this slice
     const int nk = max(0, min(per, nk_all - ktb));
     const int kend = min(g.K, (ktb + nk) * BKT);                       // loads beyond this slice's K range come back as zeros
     auto contract = [&](int cur) {
@@ -458,8 +474,26 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
             contract(1);
             store_tile_k<BM, AKM, BKT, NT, PA>(As, m0, (ktb + kt + 2) * BKT, g.M, kend, tid, ra0);
             store_tile_k<BN, BKM, BKT, NT, PB>(Bs, n0, (ktb + kt + 2) * BKT, g.N, kend, tid, rb0);
+            if constexpr (FL > 0) {
+                if ((kt + 2) % FL == 0) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) { acc2[i][j][r] += acc[i][j][r]; acc[i][j][r] = 0.f; }
+                }
+            }
             __syncthreads();
         }
+    }
+    if constexpr (FL > 0) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] += acc2[i][j][r];
     }
 #pragma clang loop unroll(full)
     for (int i = 0; i < TM; ++i)
@@ -469,7 +503,7 @@ __global__ void __launch_bounds__(256) gemm_big_kernel(GemmArgs g, int tiles_n, 
             for (int r = 0; r < 16; ++r)
             {
                 const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, col = n0 + wn + 32 * j + li;
-                if (g.slab) { if (row < g.M && col < g.N) g.slab[((size_t)blockIdx.y * g.M + row) * g.N + col] = acc[i][j][r]; }
+                if (g.slab) { if (row < g.M && col < g.N) g.slab[((size_t)slice * g.M + row) * g.N + col] = acc[i][j][r]; }
                 else epilogue_store(g, row, col, acc[i][j][r]);
             }
 }
@@ -1042,6 +1076,22 @@ static int launch_big(const GemmArgs& g, hipStream_t s, int map = -1) {
     hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, AKM, BKM, PD>), dim3(tm * tn, g.slab ? g.nslab : 1), dim3(256), lds, s, g, tn, map);
     return AID_OK;
 }
+// deep-K slab launch (gemm_big_kernel with FL): 128 x 128 tiles from 128 rows, 64 x 64 below; 1-D grid of tiles x slices
+constexpr int DEEPK_MIN = 65536, DEEPK_FL = 2;
+template <int BM, int BN>
+static int launch_deepk(const GemmArgs& g, hipStream_t s) {
+    t_variant = 12;
+    constexpr int BKT = 32;
+    const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+    const size_t lds = sizeof(float) * 2 * (TileK<BM, false, BKT>::FLOATS + TileK<BN, false, BKT>::FLOATS);
+    static bool attr_done = false;
+    if (lds > 65536 && !attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_big_kernel<BM, BN, BKT, false, false, 2, DEEPK_FL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_big_kernel<BM, BN, BKT, false, false, 2, DEEPK_FL>), dim3(tm * tn * g.nslab), dim3(256), lds, s, g, tn, 0);
+    return AID_OK;
+}
 template <bool AKM, bool BKM>
 static int launch_splitk(const GemmArgs& g, bool vec, hipStream_t s) {
     t_variant = vec ? 6 : 7;
@@ -1203,8 +1253,9 @@ __global__ void slab_fold_kernel(const float* __restrict__ slab, int nslab, Gemm
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t mn = (size_t)g.M * g.N;
     if (i >= mn) return;
-    float v = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) v += slab[(size_t)sl * mn + i];
+    double vd = 0.0;                      // the slices are folded in float64, in slice order: the fold adds no rounding of its own (HBM-bound: free)
+    for (int sl = 0; sl < nslab; ++sl) vd += (double)slab[(size_t)sl * mn + i];
+    float v = (float)vd;
     const int row = i / g.N, col = i % g.N;
     v *= g.alpha;
     if (g.bias) v += g.bias[col];
@@ -1228,7 +1279,9 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         ProfScope prof(PROF_GEMM_TILE, s, 2.0 * g.M * g.N * g.K, 4.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * g.N));
         prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.a_kmajor * 2 + g.b_kmajor + 4;
         int r;
-        if (vec && !g.a_kmajor && !g.b_kmajor) r = launch_big<64, 64, 32, false, false, 2>(g, s, 0);      // branch-free, two tiles of prefetch
+        if (vec && !g.a_kmajor && !g.b_kmajor && g.K >= DEEPK_MIN)      // blocked float32 accumulation, XCD-grouped slices (the encoder head's K = 451 584)
+            r = g.M >= 128 ? launch_deepk<128, 128>(g, s) : launch_deepk<64, 64>(g, s);
+        else if (vec && !g.a_kmajor && !g.b_kmajor) r = launch_big<64, 64, 32, false, false, 2>(g, s, 0);      // branch-free, two tiles of prefetch
         else if (!g.a_kmajor && !g.b_kmajor) r = launch_tile<64, 64, false, false>(g, vec, s);
         else if (!g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, false, true>(g, vec, s);
         else if (g.a_kmajor && g.b_kmajor) r = launch_tile<64, 64, true, true>(g, vec, s);

@@ -159,8 +159,8 @@ def kernel_name(variant, layout):
     a, k = b((layout & 3) >> 1), b(layout & 1)
     return {1: f"gemm_panel_kernel<{a}, {k}>", 2: f"gemm_ring_kernel<64, 64, 128, {a}, {k}>", 3: "gemm_smallk_kernel",
             4: f"gemm_tile_kernel<64, 64, {a}, {k}, true>", 5: f"gemm_tile_kernel<64, 64, {a}, {k}, false>",
-            6: f"gemm_splitk_kernel<{a}, {k}, true>", 7: f"gemm_splitk_kernel<{a}, {k}, false>", 8: "gemm_thin_tn_kernel", 10: "gemm_skinny_kernel", 9: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 2>",
-            11: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 1>", 14: f"gemm_panel128_kernel<{a}, {k}, 128>",
+            6: f"gemm_splitk_kernel<{a}, {k}, true>", 7: f"gemm_splitk_kernel<{a}, {k}, false>", 8: "gemm_thin_tn_kernel", 10: "gemm_skinny_kernel", 9: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 2, 0>",
+            11: f"gemm_big_kernel<64, 64, 32, {a}, {k}, 1, 0>", 12: "gemm_big_kernel<128, 128, 32, false, false, 2, 2>", 14: f"gemm_panel128_kernel<{a}, {k}, 128>",
             15: f"gemm_panel128_kernel<{a}, {k}, 64>"}.get(variant, f"variant{variant}<{a}, {k}>")
 
 

@@ -222,13 +222,18 @@ def test_cfg4_pixel_batch256_train_step_vs_oracle():
     batch = orc.replay_sample(store, cap, B, ns)
     batch["observations"] = batch["observations"].reshape(B, 9, 84, 84); batch["next_observations"] = batch["next_observations"].reshape(B, 9, 84, 84)
     m_ref, g_ref, aux = orc.pixel_train_step(st, batch, ns, horizon=H, return_grads=True)
-    np.testing.assert_allclose(last["encoded_obs"].numpy(), aux["encoded_obs"].numpy(), rtol=1e-3, atol=2e-5)
-    # The belief over next_obs is a 50-step loop CONDITIONED ON THE ENCODER'S FEATURES: the features agree with the oracle's to the tolerance above
-    # (fp32 summation order of a 451 584-deep contraction; which GEMM variant runs depends on the calling stream's dispatch hint, i.e. on what ran
-    # before in the process), and the loop carries that difference to the latents: seen up to 2e-3 absolute on |z| <= 6 (3e-4 of the range) where the
-    # state-mode loops, whose observations are exact inputs, hold 1e-5.  Everything downstream (losses at rtol 1e-4, all post-step tensors) is
-    # checked below at the usual tolerances.
-    np.testing.assert_allclose(last["next_latents"].numpy(), aux["next_latents"].numpy(), rtol=2e-3, atol=4e-3)
+    for k_ in ("encoded_obs", "encoded_next_obs", "latents", "next_latents"):          # the error actually achieved
+        d_ = (last[k_].double() - aux[k_].double()).abs()
+        print(f"cfg4 B=256 achieved: max|{k_} - oracle| = {float(d_.max()):.3e} (max|ref| {float(aux[k_].abs().max()):.3f}, "
+              f"worst rel on |ref|>0.1: {float((d_ / aux[k_].double().abs().clamp_min(0.1)).max()):.3e})")
+    # Encoder features at the forward tolerance (rtol 1e-4; absolute floor 1e-5: against the exact float64 value both this path and the float32 reference
+    # sit at ~4e-6, tests/test_hip_pixel.py::test_encoder_batch16_vs_oracle), both belief latents at SURVEY 8c's 50-step-loop tolerance.  (Round 4 needed
+    # rtol 2e-3 / atol 4e-3 on next_latents: that was the score step racing the still-running belief loop over next_obs, not rounding - fixed in
+    # agents/pixel_agent.py, the chain is now joined before the step; achieved errors are printed above.)
+    np.testing.assert_allclose(last["encoded_obs"].numpy(), aux["encoded_obs"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(last["encoded_next_obs"].numpy(), aux["encoded_next_obs"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(last["latents"].numpy(), aux["latents"].numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(last["next_latents"].numpy(), aux["next_latents"].numpy(), rtol=1e-3, atol=1e-5)
     bad = []
     for k, v in m_ref.items():
         if isinstance(v, float) and k in m and k in LOSS_KEYS + ("contrastive_loss",):
@@ -237,11 +242,8 @@ def test_cfg4_pixel_batch256_train_step_vs_oracle():
     assert not bad, bad
     assert "contrastive_loss" in m
     names = [n for n in st.p if st.p[n].dtype.is_floating_point and not n.endswith(("weight_u", "weight_v"))]
-    # (cap on elements whose first Adam step amplifies gradient rounding, see _check_post_step_tensors: ~150 M parameters here, and the latents the
-    # policy / value / dynamics gradients start from carry the loop-amplified feature rounding above - seen 40..80 such elements, per-tensor <= 1e-4 of the tensor)
-    # norm-wise update error: a first Adam step is lr * sign-like, so a 512-element LayerNorm weight of the value / dynamics nets reads 2-3 % when a
-    # single element's gradient sits near eps and the latents it came from carry the loop-amplified feature rounding (seen 0.8-2.6 %): 5 % here
-    moved = _check_post_step_tensors(sd, st.p, p0, names, 1, 256, tag="cfg4 B=256", max_update_err=5e-2)
+    # the usual caps: <= 16 elements whose first Adam step amplifies gradient rounding, norm-wise update error < 2 % per tensor (achieved: printed)
+    moved = _check_post_step_tensors(sd, st.p, p0, names, 1, 16, tag="cfg4 B=256", max_update_err=2e-2)
     assert {"latent_score_network", "latent_diffusion", "policy_network", "value_network", "latent_dynamics", "feature_decoder", "encoder"} <= moved, moved
     for n in st.p:      # power-iteration vectors of the spectral norm: two passes, as the reference
         if n.endswith(("weight_u", "weight_v")):

@@ -35,7 +35,8 @@ def test_encoder_forward_backward_golden(nat, golden_dir):
     x = dev(g["x"]).reshape(B, 9, 84, 84)
     # eval forward (no power iteration, no masks)
     f, _ = nat.encoder_forward(enc, x, train=False)
-    np.testing.assert_allclose(f.cpu().numpy(), g["feat_eval"], rtol=1e-3, atol=2e-5)
+    print(f"encoder golden: max|feat_eval - reference| = {float(np.abs(f.cpu().numpy() - g['feat_eval']).max()):.3e}")
+    np.testing.assert_allclose(f.cpu().numpy(), g["feat_eval"], rtol=1e-4, atol=1e-5)
     u0 = pd["convs.0.weight_u"].clone()
     assert torch.equal(u0, p["convs.0.weight_u"].cuda())           # eval leaves u/v untouched
     cot = NoiseStream(int(g["cotangent_key"])).randn(2, B, FD)
@@ -48,23 +49,29 @@ def test_encoder_forward_backward_golden(nat, golden_dir):
         ms = NoiseStream(int(g[f"train{pas}_key"]))
         m1, m2, mo = dev(ms.dropout_mask((B, 64), 0.025)), dev(ms.dropout_mask((B, 128), 0.05)), dev(ms.dropout_mask((B, 2 * FD), 0.1))
         f, saved = nat.encoder_forward(enc, x, sh if pas == 0 else None, sw if pas == 0 else None, 4, m1, m2, mo, train=True)
-        np.testing.assert_allclose(f.cpu().numpy(), g[f"feat_train{pas}"], rtol=1e-3, atol=2e-5, err_msg=f"pass {pas}")
+        print(f"encoder golden: max|feat_train{pas} - reference| = {float(np.abs(f.cpu().numpy() - g[f'feat_train{pas}']).max()):.3e}")
+        np.testing.assert_allclose(f.cpu().numpy(), g[f"feat_train{pas}"], rtol=1e-4, atol=1e-5, err_msg=f"pass {pas}")
         for i in range(4):
             np.testing.assert_allclose(pd[f"convs.{i}.weight_u"].cpu().numpy(), g[f"u{pas}/{i}"], rtol=1e-4, atol=1e-6)
         nat.encoder_backward(enc, genc, dev(cot[pas]), saved, m1, m2, mo, train=True)
+        gerr = 0.0
         for k in g.files:
             if k.startswith(f"grad{pas}/"):
                 name = k.split("/", 1)[1]; ref = g[k]
                 got = gd[name].cpu().numpy()
                 scale = np.abs(ref).max() + 1e-12
-                assert np.abs(got - ref).max() / scale < 3e-3, (pas, name, np.abs(got - ref).max(), scale)
+                gerr = max(gerr, np.abs(got - ref).max() / scale)
+                assert np.abs(got - ref).max() / scale < 1e-3, (pas, name, np.abs(got - ref).max(), scale)
+                assert np.linalg.norm((got - ref).ravel()) / (np.linalg.norm(ref.ravel()) + 1e-300) < 2e-4, (pas, name)
             if k.startswith(f"gradsample{pas}/"):
                 name = k.split("/", 1)[1]; ref = g[k]
                 got = gd[name].reshape(-1)[::9973].cpu().numpy()
                 scale = np.abs(ref).max() + 1e-12
-                assert np.abs(got - ref).max() / scale < 3e-3, (pas, name)
+                gerr = max(gerr, np.abs(got - ref).max() / scale)
+                assert np.abs(got - ref).max() / scale < 1e-3, (pas, name)
                 s_ref = g[f"gradsum{pas}/{name}"]
                 np.testing.assert_allclose(float(gd[name].double().abs().sum()), s_ref[1], rtol=1e-3)
+        print(f"encoder golden pass {pas}: worst gradient max|err| / max|ref| = {gerr:.3e}")
 
 
 def test_random_shift_matches_oracle(nat, golden_dir):
@@ -93,13 +100,30 @@ def test_encoder_batch16_vs_oracle(nat):
     for k in gn:
         p[k].requires_grad_(True)
     torch.set_num_threads(8)
-    fr = orc.encoder_forward(p, torch.from_numpy(x), NoiseStream(6), True)
-    np.testing.assert_allclose(f.cpu().numpy(), fr.detach().numpy(), rtol=1e-3, atol=2e-5)
+    fr = orc.encoder_forward(p, torch.from_numpy(x), NoiseStream(6), True, update_uv=False)
     gr = torch.autograd.grad((fr * torch.from_numpy(cot)).sum(), [p[k] for k in gn])
-    for k, r in zip(gn, gr):
-        scale = float(r.abs().max()) + 1e-12
-        err = float((gd[k].cpu() - r).abs().max()) / scale
-        assert err < 3e-3, (k, err, scale)
+    # the same function in float64: how far the fp32 oracle (= the reference's own arithmetic) and the HIP path each sit from the exact value - the
+    # oracle's distance is the floor no fp32 implementation can be held under when compared with it
+    p64 = {k: v.detach().double().requires_grad_(k in gn) for k, v in p.items()}
+    f64 = orc.encoder_forward(p64, torch.from_numpy(x).double(), NoiseStream(6), True, update_uv=False)
+    g64 = torch.autograd.grad((f64 * torch.from_numpy(cot).double()).sum(), [p64[k] for k in gn])
+    fh = f.cpu().double()
+    e_hip, e_orc, e_ho = float((fh - f64).abs().max()), float((fr.double() - f64).abs().max()), float((fh - fr.double()).abs().max())
+    print(f"encoder B=16 features: max|hip - fp64| = {e_hip:.3e}, max|oracle32 - fp64| = {e_orc:.3e}, max|hip - oracle32| = {e_ho:.3e}")
+    nw = lambda a, b: float((a - b).norm() / (b.norm() + 1e-300))
+    worst = sorted(((nw(gd[k].cpu().double(), r.double()), nw(gd[k].cpu().double(), r64), nw(r.double(), r64),
+                     float((gd[k].cpu() - r).abs().max()) / (float(r.abs().max()) + 1e-12), k) for k, r, r64 in zip(gn, gr, g64)), reverse=True)
+    print("encoder B=16 gradients, norm-wise (hip vs oracle32, hip vs fp64, oracle32 vs fp64, max-abs/max-ref vs oracle32):",
+          [(f"{a:.2e}", f"{b:.2e}", f"{c:.2e}", f"{d:.2e}", k) for a, b, c, d, k in worst[:6]])
+    # Features are tanh(LN(.)) in [-1, 1].  Against the exact (float64) value the HIP path and the float32 reference both sit at ~4e-6 (printed above): the
+    # distance BETWEEN two float32 evaluations cannot be held under the sum of their distances from the truth.  So: (1) the HIP path is at least as exact
+    # as the reference's own arithmetic (within 1.5x + 1e-6), (2) HIP vs the reference at rtol 1e-4 (SURVEY 8c's forward tolerance) with the absolute
+    # floor 1e-5 that (1) implies instead of 1e-6.
+    assert e_hip <= 1.5 * e_orc + 1e-6, (e_hip, e_orc)
+    np.testing.assert_allclose(f.cpu().numpy(), fr.detach().numpy(), rtol=1e-4, atol=1e-5)
+    for a, b, c, d, k in worst:     # gradients: norm-wise 1e-4 vs the reference or no further from the truth than the reference itself; max-abs 1e-3
+        assert a < 1e-4 or b <= 1.5 * c + 1e-6, (k, a, b, c)
+        assert d < 1e-3, (k, d)
 
 
 # ------------------------------------------------------------------------------------------------- pixel-mode training pieces
@@ -200,8 +224,11 @@ def test_pixel_agent_train_step_vs_oracle():
     batch["observations"] = batch["observations"].reshape(B, 9, 84, 84); batch["next_observations"] = batch["next_observations"].reshape(B, 9, 84, 84)
     torch.set_num_threads(8)
     m_ref, g_ref, aux = orc.pixel_train_step(st, batch, ns, horizon=H, return_grads=True)
-    np.testing.assert_allclose(agent._last["encoded_obs"].cpu().numpy(), aux["encoded_obs"].numpy(), rtol=1e-3, atol=2e-5)
-    np.testing.assert_allclose(agent._last["next_latents"].cpu().numpy(), aux["next_latents"].numpy(), rtol=2e-3, atol=1e-4)
+    for k_ in ("encoded_obs", "latents", "next_latents"):
+        print(f"pixel step B=8 achieved: max|{k_} - oracle| = {float((agent._last[k_].cpu() - aux[k_]).abs().max()):.3e}")
+    np.testing.assert_allclose(agent._last["encoded_obs"].cpu().numpy(), aux["encoded_obs"].numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(agent._last["latents"].cpu().numpy(), aux["latents"].numpy(), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(agent._last["next_latents"].cpu().numpy(), aux["next_latents"].numpy(), rtol=1e-3, atol=1e-5)
     for k, v in m_ref.items():
         if isinstance(v, float) and k in m:
             assert_metric(k, float(m[k]), v)
@@ -351,3 +378,31 @@ def test_pixel_epistemic_value_reference_golden(nat, golden_dir):
         np.testing.assert_allclose(joint, float(g[f"c{call}/epistemic/joint_term"]), rtol=5e-3, atol=2e-4)
         np.testing.assert_allclose(tlog, float(g[f"c{call}/epistemic/marginal_term"]), rtol=5e-3, atol=2e-4)
         np.testing.assert_allclose(rm, float(g[f"c{call}/epistemic/running_mean"]), rtol=2e-3)
+
+
+def test_pixel_score_step_waits_for_the_next_obs_belief_chain():
+    """The default pixel schedule runs the belief over next_obs (chain b) on a chain stream underneath the ELBO, InfoNCE and the encoder backward passes,
+    reading the score-network weights in place; score_optimizer.step() on the side stream rewrites them.  The reference computes next_latents before that
+    step (pixel_agent.py:307 vs :332), so the step must be ordered behind chain b.  Make chain b LONG (400 denoise steps at 160 rows: ~70 ms, longer than
+    everything the side stream does before the step) and compare with the schedule that has no concurrent chain (early_belief_chains off: the paired loop
+    finishes before the ELBO): same next_latents, same post-step tensors, bit for bit (the rows of a loop never interact, both forms run the same kernels)."""
+    L, A, D, N, H, B, cap = 32, 6, 64, 400, 1, 160, 192
+    outs = []
+    for early in (True, False):
+        torch.manual_seed(0)          # the feature decoder keeps torch's default initialisation: same seed, same weights in both agents
+        agent = _pixel_agent(L, A, D, N, H, B, cap=cap)
+        ai = agent.active_inference
+        _load_pixel_params(agent, L, A, D, N, 23)
+        bs = NoiseStream(9)
+        agent.replay_buffer.add_batch(bs.rand(cap, 9 * 84 * 84), np.tanh(bs.randn(cap, A)).astype(np.float32), bs.randn(cap), bs.rand(cap, 9 * 84 * 84), bs.rand(cap) < 0.1)
+        pn = ParityNoise(555, pixel=True); ai.noise = pn; agent.replay_buffer.index_source = pn
+        agent.early_belief_chains = early
+        agent.train_step(); torch.cuda.synchronize()
+        sd = {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}
+        outs.append(({k: v.detach().cpu().clone() for k, v in sd.items()}, {k: v.detach().cpu().clone() for k, v in agent._last.items()}))
+        del agent, ai; torch.cuda.empty_cache()
+    (sd_a, last_a), (sd_b, last_b) = outs
+    for k in ("latents", "next_latents"):
+        assert torch.equal(last_a[k], last_b[k]), (k, float((last_a[k] - last_b[k]).abs().max()))
+    diff = [k for k in sd_a if not torch.equal(sd_a[k], sd_b[k])]
+    assert not diff, diff[:8]

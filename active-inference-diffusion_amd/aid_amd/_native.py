@@ -688,6 +688,60 @@ def p_sample(z, score, coefs, step: int, eps=None):
     return out
 
 
+# ---- A5: forward-process helpers of LatentDiffusionProcess (aid/core/diffusion.py:56-104, 146-174, 239-255), one launch each
+def _steps_ptr(steps):
+    assert steps.is_cuda and steps.dtype == torch.int64 and steps.is_contiguous(), "diffusion steps: contiguous CUDA int64 [B]"
+    return C.c_void_p(steps.data_ptr())
+
+
+def log_snr(t, lmin, lmax):
+    out = torch.empty_like(t)
+    check(lib().aid_log_snr(_ptr(t), _ptr(lmin), _ptr(lmax), _ptr(out), C.c_size_t(t.numel()), _stream()), "aid_log_snr")
+    return out
+
+
+def loss_weight(t, lmin, lmax):
+    out = torch.empty_like(t)
+    check(lib().aid_loss_weight(_ptr(t), _ptr(lmin), _ptr(lmax), _ptr(out), C.c_size_t(t.numel()), _stream()), "aid_loss_weight")
+    return out
+
+
+def continuous_q_sample(z, t, eps, lmin, lmax):
+    """-> (z_noisy [B,L], log_snr [B], alpha [B], sigma [B])"""
+    B, L = z.shape
+    zn = torch.empty_like(z)
+    ls, al, sg = (torch.empty(B, device=z.device) for _ in range(3))
+    check(lib().aid_continuous_q_sample(_ptr(z), _ptr(t), _ptr(eps), _ptr(lmin), _ptr(lmax), B, L, _ptr(zn), _ptr(ls), _ptr(al), _ptr(sg), _stream()),
+          "aid_continuous_q_sample")
+    return zn, ls, al, sg
+
+
+def sample_latent_prior(prior_mean, prior_log_std, eps):
+    out = torch.empty_like(eps)
+    check(lib().aid_sample_latent_prior(_ptr(prior_mean), _ptr(prior_log_std), _ptr(eps), eps.shape[0], eps.shape[1], _ptr(out), _stream()),
+          "aid_sample_latent_prior")
+    return out
+
+
+def _step_axpby(fn, name, x0, x1, steps, c0, c1, validate):
+    B, L = x0.shape
+    out = torch.empty_like(x0)
+    flag = torch.zeros(1, dtype=torch.int32, device=x0.device) if validate else None
+    check(fn(_ptr(x0), _steps_ptr(steps) if name == "aid_q_sample" else _ptr(x1), _ptr(x1) if name == "aid_q_sample" else _steps_ptr(steps),
+             _ptr(c0), _ptr(c1), int(c0.numel()), B, L, _ptr(out), C.c_void_p(flag.data_ptr()) if validate else C.c_void_p(0), _stream()), name)
+    if validate and int(flag.item()):
+        raise IndexError(f"{name}: a diffusion step lies outside [0, {int(c0.numel())})")       # the reference's gather raises here too
+    return out
+
+
+def q_sample(z_start, steps, eps, sqrt_acp, sqrt_1m_acp, validate=True):
+    return _step_axpby(lib().aid_q_sample, "aid_q_sample", z_start, eps, steps, sqrt_acp, sqrt_1m_acp, validate)
+
+
+def posterior_mean(z_start, z_t, steps, coef1, coef2, validate=True):
+    return _step_axpby(lib().aid_posterior_mean, "aid_posterior_mean", z_start, z_t, steps, coef1, coef2, validate)
+
+
 def reward_normalize(rewards, state):
     """state: CUDA float64 [3] = (mean, var, count), updated in place; returns normalised rewards."""
     assert state.is_cuda and state.dtype == torch.float64 and state.numel() == 3

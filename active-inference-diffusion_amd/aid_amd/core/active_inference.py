@@ -123,10 +123,24 @@ class DiffusionActiveInference(nn.Module):
         self.pixel_epistemic = False
         self.param_version = 0          # bumped whenever parameters change outside an optimiser step (load_state_dict, broadcast)
 
+    # The NoiseSource is shared with the latent_diffusion sub-module (the `noise=None` forms of its continuous_q_sample / q_sample /
+    # sample_latent_prior draw from it): assigning `ai.noise = ...` (parity tests, data-parallel seeding) re-points both.
+    @property
+    def noise(self) -> NoiseSource:
+        return self.__dict__["_noise"]
+
+    @noise.setter
+    def noise(self, value):
+        self.__dict__["_noise"] = value
+        ld = self._modules.get("latent_diffusion") if "_modules" in self.__dict__ else None
+        if ld is not None:
+            ld.noise = value
+
     # ------------------------------------------------------------------------------------------ construction
     def _build_models(self):
         c, L, D = self.config, self.latent_dim, self.config.hidden_dim
         self.latent_diffusion = LatentDiffusionProcess(c.diffusion, latent_dim=L)
+        self.latent_diffusion.noise = self.noise
         self.register_buffer("reward_mean", torch.tensor(0.0))
         self.register_buffer("reward_var", torch.tensor(1.0))
         self.register_buffer("preference_temperature", torch.tensor(float(c.preference_temperature)))

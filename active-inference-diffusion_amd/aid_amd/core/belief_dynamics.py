@@ -109,3 +109,22 @@ class BeliefDynamics(nn.Module):
         lam = self._lam if self.full else self.variance
         e = 0.5 * torch.sum(torch.log(lam) + 2.8378770664093453, dim=-1)   # log(2 pi e)
         return e[0] if self.n_beliefs == 1 else e
+
+    def get_diagnostics(self):
+        """belief_dynamics.py:391-409.  Full covariance: min / max eigenvalue, condition number, determinant - read off the eigenvalues the belief is
+        carried as (the reference calls eigvals / det on the matrix); diagonal: min / max / mean variance; both: |mean| and the entropy.  One belief:
+        floats, as the reference; batched beliefs: one list entry per belief."""
+        one = (lambda x: float(x[0])) if self.n_beliefs == 1 else (lambda x: [float(v) for v in x])
+        d = {}
+        if self.full:
+            lam = self._lam
+            d["min_eigenvalue"], d["max_eigenvalue"] = one(lam.min(dim=-1).values), one(lam.max(dim=-1).values)
+            d["condition_number"] = one(lam.max(dim=-1).values / lam.min(dim=-1).values)
+            d["determinant"] = one(torch.exp(torch.log(lam).sum(dim=-1)))
+        else:
+            v = self.variance
+            d["min_variance"], d["max_variance"], d["mean_variance"] = one(v.min(dim=-1).values), one(v.max(dim=-1).values), one(v.mean(dim=-1))
+        d["mean_norm"] = one(self.mean.norm(dim=-1))
+        e = self.entropy()
+        d["entropy"] = float(e) if self.n_beliefs == 1 else [float(x) for x in e]
+        return d

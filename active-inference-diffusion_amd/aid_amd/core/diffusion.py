@@ -12,6 +12,11 @@ import torch.nn as nn
 from .. import _native as nat
 
 
+def extract(a: torch.Tensor, t: torch.Tensor, x_shape) -> torch.Tensor:
+    """Coefficients at the per-row steps t, shaped for broadcasting (diffusion.py:258-262)."""
+    return a.gather(-1, t).reshape(t.shape[0], *((1,) * (len(x_shape) - 1)))
+
+
 def make_schedule(steps: int, kind: str = "cosine", beta_start: float = 1e-4, beta_end: float = 0.02) -> Dict[str, torch.Tensor]:
     """Schedule buffers of setup_schedule (diffusion.py:106-144); float32 CPU tensors (init-time only)."""
     if kind == "cosine":
@@ -41,12 +46,80 @@ class LatentDiffusionProcess(nn.Module):
         self.latent_prior_log_std = nn.Parameter(torch.zeros(latent_dim))
         self.log_snr_min = nn.Parameter(torch.tensor(-10.0))
         self.log_snr_max = nn.Parameter(torch.tensor(10.0))
-        for k, v in make_schedule(config.num_diffusion_steps, config.beta_schedule, config.beta_start, config.beta_end).items():
-            self.register_buffer(k, v)
+        self.setup_schedule()
+        if getattr(config, "use_positional_embedding", False):        # diffusion.py:39-41 (never read by the reference either; kept for state_dict parity)
+            self.pos_embed = nn.Parameter(torch.zeros(1, latent_dim))
+            nn.init.normal_(self.pos_embed, std=0.02)
         self.register_buffer("loss_weight_cache", torch.zeros(1000))
         self.continuous_time, self.time_min, self.time_max, self.loss_weight_computed = True, 1e-5, 1.0, False
-        self._coefs = None
         self._ws = None
+        self.noise = None          # a NoiseSource (set by DiffusionActiveInference): where the draws of the `noise=None` forms come from
+
+    def setup_schedule(self):
+        """diffusion.py:106-144: (re)build the schedule buffers from self.config."""
+        c = self.config
+        dev = self.betas.device if hasattr(self, "betas") else None
+        for k, v in make_schedule(c.num_diffusion_steps, c.beta_schedule, c.beta_start, c.beta_end).items():
+            if hasattr(self, k):
+                setattr(self, k, v.to(dev))
+            else:
+                self.register_buffer(k, v)
+        self._coefs = None
+        self._post_coefs = None
+
+    # -- A5: the forward process (diffusion.py:56-104, 146-174, 239-255); each is ONE HIP launch (csrc/diffusion_ops.hip) -------------------------
+    def _f(self, x: torch.Tensor) -> torch.Tensor:
+        return x.to(self.betas.device).float().contiguous()
+
+    def _randn(self, *shape) -> torch.Tensor:
+        out = torch.empty(*shape, device=self.betas.device)
+        if self.noise is not None:
+            nat.fill_normal(out, self.noise.seed, self.noise.next_offset(out.numel()))
+        else:
+            nat.fill_normal(out, 0xA5, int(torch.randint(0, 2 ** 31, (1,))) << 20)
+        return out
+
+    def compute_log_snr(self, t: torch.Tensor) -> torch.Tensor:
+        """lambda(t) = lambda_min + (lambda_max - lambda_min)(1 - t), any shape (diffusion.py:56-60)."""
+        return nat.log_snr(self._f(t), self.log_snr_min.data, self.log_snr_max.data)
+
+    def continuous_q_sample(self, z_start: torch.Tensor, t: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """z_t = sqrt(sigmoid(lambda)) z + sqrt(sigmoid(-lambda)) eps -> (z_noisy, eps, {log_snr [B], alpha [B,1], sigma [B,1]})  (diffusion.py:62-91)."""
+        z = self._f(z_start)
+        eps = self._randn(*z.shape) if noise is None else self._f(noise)
+        zn, ls, al, sg = nat.continuous_q_sample(z, self._f(t).reshape(-1), eps, self.log_snr_min.data, self.log_snr_max.data)
+        return zn, (eps if noise is None else noise), {"log_snr": ls.reshape(t.shape), "alpha": al.view(-1, 1), "sigma": sg.view(-1, 1)}
+
+    def compute_loss_weight(self, t: torch.Tensor) -> torch.Tensor:
+        """exp(-lambda^2 / 8) (sin(pi t) + 0.1) (diffusion.py:93-104)."""
+        return nat.loss_weight(self._f(t), self.log_snr_min.data, self.log_snr_max.data)
+
+    def sample_latent_prior(self, batch_size: int, device=None, eps: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """mu_p + exp(log sigma_p) eps, eps ~ N(0, I) [batch_size, L] (diffusion.py:146-152); the module's device is used (there is no CPU path)."""
+        eps = self._randn(batch_size, self.latent_dim) if eps is None else self._f(eps)
+        return nat.sample_latent_prior(self.latent_prior_mean.data, self.latent_prior_log_std.data, eps)
+
+    def _steps(self, t: torch.Tensor) -> torch.Tensor:
+        return t.to(self.betas.device).long().reshape(-1).contiguous()
+
+    def q_sample(self, z_start: torch.Tensor, t: torch.Tensor, noise: Optional[torch.Tensor] = None):
+        """Discrete forward diffusion with per-row integer steps -> (z_noisy, noise) (diffusion.py:154-174)."""
+        z = self._f(z_start)
+        eps = self._randn(*z.shape) if noise is None else self._f(noise)
+        return nat.q_sample(z, self._steps(t), eps, self.sqrt_alphas_cumprod, self.sqrt_one_minus_alphas_cumprod), (eps if noise is None else noise)
+
+    def posterior_coefs(self):
+        """(coef1 [N], coef2 [N]) of _posterior_mean, device-resident."""
+        if getattr(self, "_post_coefs", None) is None or self._post_coefs[0].device != self.betas.device:
+            c1 = self.betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+            c2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(self.alphas) / (1.0 - self.alphas_cumprod)
+            self._post_coefs = (c1.contiguous(), c2.contiguous())
+        return self._post_coefs
+
+    def _posterior_mean(self, z_start: torch.Tensor, z_t: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """coef1[t] z_start + coef2[t] z_t with per-row integer steps (diffusion.py:239-255)."""
+        c1, c2 = self.posterior_coefs()
+        return nat.posterior_mean(self._f(z_start), self._f(z_t), self._steps(t), c1, c2)
 
     # [N,5] per-step scalars of p_sample / _posterior_mean (diffusion.py:220-255), device-resident
     def coefs(self) -> torch.Tensor:

@@ -20,7 +20,7 @@ class FreeEnergyComputation(nn.Module):
         return torch.exp(self.log_precision)
 
     def compute_loss(self, states: torch.Tensor, observations: torch.Tensor, actions: torch.Tensor, score_network: nn.Module,
-                     current_time: float = 0.0, prior_mean: Optional[torch.Tensor] = None, prior_std: float = 1.0
+                     current_time: float = 0.0, prior_mean: Optional[torch.Tensor] = None, prior_std: float = 1.0, backward: bool = False
                      ) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         states, observations = states.contiguous().float(), observations.contiguous().float()
         B = states.shape[0]
@@ -33,8 +33,19 @@ class FreeEnergyComputation(nn.Module):
         accuracy = -0.5 * self.precision.to(sq.device) * sq[1]
         score_reg = 0.01 * sq[2]
         fe = complexity - accuracy + score_reg
-        return fe, {"complexity": complexity, "accuracy": -accuracy, "observation_error": sq[1], "score_regularization": score_reg,
-                    "precision": self.precision}
+        info = {"complexity": complexity, "accuracy": -accuracy, "observation_error": sq[1], "score_regularization": score_reg,
+                "precision": self.precision}
+        if backward:
+            # The reference returns an autograd scalar (free_energy.py:30-91); here there is no graph, so the gradients the closed form gives are
+            # produced explicitly: dF/d(log_precision) = 1/2 exp(log pi) mean|o - z|^2 is ACCUMULATED into log_precision.grad, and the direct
+            # parts of dF/d(states) (complexity + accuracy terms; the path through the score network's input is not included) and dF/d(score)
+            # are returned.  Gradients of the score-network PARAMETERS are not produced by this call (the reference never calls compute_loss).
+            gp = (0.5 * self.precision.to(sq.device) * sq[1]).detach().to(self.log_precision.device).reshape(self.log_precision.shape)
+            self.log_precision.grad = gp if self.log_precision.grad is None else self.log_precision.grad + gp
+            pi = float(self.precision)
+            info["d_states_direct"] = ((states - prior_mean) / (prior_std ** 2) + pi * (states - observations)) / B
+            info["d_score"] = 0.02 * score / B
+        return fe, info
 
     def update_precision(self, complexity: torch.Tensor, accuracy: torch.Tensor):
         with torch.no_grad():

@@ -119,9 +119,9 @@ class LatentScoreNetwork(nn.Module):
 
     def forward(self, z_t: torch.Tensor, time: torch.Tensor, observation: Optional[torch.Tensor] = None, continuous: Optional[bool] = None,
                 drop_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
-        if observation is None:
-            raise NotImplementedError("unconditional (observation=None) scoring is not on the reference's hot path")
-        z_t, time, observation = (x.contiguous().float() for x in (z_t, time, observation))
+        # observation=None: the reference's zero observation embedding (score_networks.py:144-149) - the native forward takes a NULL obs pointer
+        z_t, time = z_t.contiguous().float(), time.contiguous().float()
+        observation = None if observation is None else observation.contiguous().float()
         if continuous is None:  # reference semantics (score_networks.py:121): whole-batch test, costs one host sync
             continuous = bool(time.max() <= 1.0 and time.min() >= 0.0)
         if self.training and drop_mask is None:

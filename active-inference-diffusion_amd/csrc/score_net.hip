@@ -299,7 +299,7 @@ size_t aid_score_forward_workspace(const AidScoreNet* net, int B) {
 int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const float* t, int t_mode, const float* obs,
                       const float* drop_mask, float* score, void* wsp, size_t ws_bytes, void* stream) {
     AID_TRY(score_validate(net));
-    AID_REQUIRE(z_t && t && obs && score, AID_E_NULL, "aid_score_forward: null tensor");
+    AID_REQUIRE(z_t && t && score, AID_E_NULL, "aid_score_forward: null tensor");
     AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_score_forward: B=%d", B);
     AID_REQUIRE(t_mode == AID_T_DISCRETE || t_mode == AID_T_CONTINUOUS, AID_E_SHAPE, "aid_score_forward: t_mode=%d", t_mode);
     hipStream_t s = (hipStream_t)stream;
@@ -307,8 +307,18 @@ int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const flo
     ScoreActs a;
     AID_TRY(score_acts_alloc(*net, B, false, ws, a));
     AID_TRY(score_time_embed(*net, B, t, t_mode, a, s));
-    AID_TRY(score_obs_stage0(*net, B, obs, a, s));
-    AID_TRY(score_cond(*net, B, drop_mask, a.temb, net->D, a, s));
+    if (obs) {
+        AID_TRY(score_obs_stage0(*net, B, obs, a, s));
+        AID_TRY(score_cond(*net, B, drop_mask, a.temb, net->D, a, s));
+    } else {
+        // observation = None: the reference conditions on a ZERO observation embedding (models/score_networks.py:144-149), so cond = t_emb.  The
+        // conditioning kernel computes cond = t_emb + LN(o2) gamma + beta: with o2 = 0 and gamma = beta = 0 (a zero vector in the activation store,
+        // which this call does not otherwise use) that is exactly t_emb + 0; the obs-encoder parameters are not read.
+        AID_CHECK_HIP(hipMemsetAsync(a.o2, 0, sizeof(float) * (size_t)B * net->D, s));
+        AID_CHECK_HIP(hipMemsetAsync(a.o1, 0, sizeof(float) * (size_t)net->D, s));
+        AidScoreNet z = *net; z.oe8_g = a.o1; z.oe8_b = a.o1;
+        AID_TRY(score_cond_mod(z, B, a.temb, net->D, a, s));
+    }
     AID_TRY(score_trunk(*net, B, z_t, a, false, s));
     AID_TRY(score_head(a.raw, net->output_multiplier, t, t_mode, score, B, net->L, s));
     return AID_OK;
@@ -332,7 +342,10 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     n += sizeof(float) * ((size_t)n_steps * (D + 1) + (size_t)B * (3 * L + 2 * D) + (size_t)n_steps * B * L);
     n += sizeof(float) * (C * B * (4 * D + NA * 2 * D));            // mask, two ping-pong activations, sc, modulations
     n += sizeof(float) * net->n_blocks * (D * D + D);                // fused attention weights
-    n += sizeof(float) * (16 * (size_t)B * D + (size_t)L * D) + 512;  // split-K slabs of the mid-M pipeline (<= 16 slices), transposed latent_proj weight
+    // split-K slabs of the mid-M pipeline - 4 slices above 128 rows, max(4, K slices of the 4D-deep product) at <= 128 rows: exactly what denoise_impl
+    // carves - and the transposed latent_proj weight
+    const size_t nsl = B > 128 ? 4 : (small_ks(4 * (int)D) > 4 ? small_ks(4 * (int)D) : 4);
+    n += sizeof(float) * (nsl * (size_t)B * D + (size_t)L * D) + 512;
     return n + (1 << 16);
 }
 

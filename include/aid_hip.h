@@ -182,7 +182,8 @@ typedef struct AidScoreNet {
 #define AID_T_CONTINUOUS 1
 
 /* s_theta(z_t, t, o) -> score[B,L].  t: [B] floats.  drop_mask: [B,D] scaled keep mask of the obs
- * encoder's Dropout(0.1) or NULL for eval mode. */
+ * encoder's Dropout(0.1) or NULL for eval mode.  obs == NULL: unconditional scoring, the zero observation
+ * embedding of aid/models/score_networks.py:144-149 (the obs-encoder parameters are not read). */
 size_t aid_score_forward_workspace(const AidScoreNet* net, int B);
 int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const float* t, int t_mode,
                       const float* obs, const float* drop_mask, float* score, void* ws, size_t ws_bytes,
@@ -474,6 +475,25 @@ int aid_reward_forward(const AidRewardNet* rew, int B, const float* z, float* ou
  * out3 = mean_b sum_l of (z-mu_p)^2, (o-z)^2, score^2. */
 int aid_free_energy_terms(const float* states, const float* prior_mean, const float* obs, const float* score, int B, int L,
                           float* out3, void* stream);
+/* ---- A5: LatentDiffusionProcess's forward-process helpers as stand-alone operations (aid/core/diffusion.py).  One launch each; inside a
+ * train_step the same arithmetic runs fused in aid_elbo_step.  log_snr_min / log_snr_max: device scalars (the module's Parameters).
+ *   aid_log_snr               compute_log_snr        :56-60    out[i] = min + (max - min) (1 - t[i]); n elements of any shape
+ *   aid_loss_weight           compute_loss_weight    :93-104   out[i] = exp(-lambda^2 / 8) (sin(pi t) + 0.1)
+ *   aid_continuous_q_sample   continuous_q_sample    :62-91    z_noisy [B,L] = sqrt(alpha_b) z + sqrt(sigma_b) eps; log_snr / alpha / sigma [B] optional (NULL)
+ *   aid_sample_latent_prior   sample_latent_prior    :146-152  out [B,L] = prior_mean + exp(prior_log_std) eps
+ *   aid_q_sample              q_sample               :154-174  per-row int64 steps in [0, N); tables [N] = the module's sqrt_alphas_cumprod buffers
+ *   aid_posterior_mean        _posterior_mean        :239-255  coef1 = beta sqrt(acp_prev) / (1 - acp), coef2 = (1 - acp_prev) sqrt(alpha) / (1 - acp), [N] each
+ * bad_step (optional device int, zeroed by the caller): set to 1 when a step lies outside [0, N) - the reference's gather raises there; the kernel
+ * itself clamps, it never reads outside the tables. */
+int aid_log_snr(const float* t, const float* log_snr_min, const float* log_snr_max, float* out, size_t n, void* stream);
+int aid_loss_weight(const float* t, const float* log_snr_min, const float* log_snr_max, float* out, size_t n, void* stream);
+int aid_continuous_q_sample(const float* z_start, const float* t, const float* eps, const float* log_snr_min, const float* log_snr_max, int B, int L,
+                            float* z_noisy, float* log_snr, float* alpha, float* sigma, void* stream);
+int aid_sample_latent_prior(const float* prior_mean, const float* prior_log_std, const float* eps, int B, int L, float* out, void* stream);
+int aid_q_sample(const float* z_start, const int64_t* steps, const float* eps, const float* sqrt_alphas_cumprod, const float* sqrt_one_minus_alphas_cumprod,
+                 int N, int B, int L, float* z_noisy, int* bad_step, void* stream);
+int aid_posterior_mean(const float* z_start, const float* z_t, const int64_t* steps, const float* coef1, const float* coef2, int N, int B, int L, float* out,
+                       int* bad_step, void* stream);
 /* p_sample with a caller-supplied score (aid/core/diffusion.py:208-255); eps may be NULL (deterministic / t = 0). */
 int aid_p_sample(const float* z, const float* score, const float* eps, const float* coefs, int step, int B, int L, float* out,
                  void* stream);

@@ -108,7 +108,7 @@ def score_obs_embed(p: Params, obs: Tensor, noise=None, train: bool = False) -> 
     return _ln(p, SCORE + "obs_encoder.8", _lin(p, SCORE + "obs_encoder.7", x))
 
 
-def score_forward(p: Params, z_t: Tensor, time: Tensor, obs: Tensor, noise=None,
+def score_forward(p: Params, z_t: Tensor, time: Tensor, obs: Optional[Tensor], noise=None,
                   train: bool = False, n_blocks: int = 6) -> Tensor:
     """s_theta(z_t, t, o).  Draw order (train mode): one dropout mask [B,D] (obs encoder).
 
@@ -129,7 +129,8 @@ def score_forward(p: Params, z_t: Tensor, time: Tensor, obs: Tensor, noise=None,
     else:  # :138-141
         t_emb = _time_embed(p, time)
         time_weight = None
-    obs_emb = score_obs_embed(p, obs, noise, train)
+    # observation=None: a zero embedding, no dropout draw (:144-149)
+    obs_emb = score_obs_embed(p, obs, noise, train) if obs is not None else torch.zeros(z_t.shape[0], D)
     cond = t_emb + obs_emb  # :153
     h = _lin(p, SCORE + "latent_proj", z_t)
     for i in range(n_blocks):  # DiTBlock.forward :214-235
@@ -331,6 +332,31 @@ def loss_weight(p: Params, t: Tensor) -> Tensor:
     """compute_loss_weight, aid/core/diffusion.py:93-104."""
     ls = log_snr(p, t)
     return torch.exp(-0.5 * (ls ** 2) / 4.0) * (torch.sin(t * np.pi) + 0.1)
+
+
+def continuous_q_sample(p: Params, z_start: Tensor, t: Tensor, eps: Tensor):
+    """continuous_q_sample, aid/core/diffusion.py:62-91: alpha = sigmoid(lambda(t)), sigma = sigmoid(-lambda(t)),
+    z_t = sqrt(alpha) z + sqrt(sigma) eps.  -> (z_noisy, eps, {log_snr [B], alpha [B,1], sigma [B,1]})."""
+    ls = log_snr(p, t)
+    alpha, sigma = torch.sigmoid(ls).view(-1, 1), torch.sigmoid(-ls).view(-1, 1)
+    return torch.sqrt(alpha) * z_start + torch.sqrt(sigma) * eps, eps, {"log_snr": ls, "alpha": alpha, "sigma": sigma}
+
+
+def sample_latent_prior(p: Params, eps: Tensor) -> Tensor:
+    """sample_latent_prior, aid/core/diffusion.py:146-152: mu_p + exp(log sigma_p) eps (eps [B, L] = the randn_like draw)."""
+    return p[DIFF + "latent_prior_mean"].unsqueeze(0) + torch.exp(p[DIFF + "latent_prior_log_std"]).unsqueeze(0) * eps
+
+
+def q_sample(tab: Dict[str, Tensor], z_start: Tensor, t: Tensor, eps: Tensor) -> Tensor:
+    """q_sample, aid/core/diffusion.py:154-174: discrete forward diffusion with per-row integer steps t [B]."""
+    return tab["sqrt_alphas_cumprod"][t].view(-1, 1) * z_start + tab["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1) * eps
+
+
+def posterior_mean(tab: Dict[str, Tensor], z_start: Tensor, z_t: Tensor, t: Tensor) -> Tensor:
+    """_posterior_mean, aid/core/diffusion.py:239-255, per-row integer steps t [B]."""
+    c1 = (tab["betas"] * torch.sqrt(tab["alphas_cumprod_prev"]) / (1.0 - tab["alphas_cumprod"]))[t].view(-1, 1)
+    c2 = ((1.0 - tab["alphas_cumprod_prev"]) * torch.sqrt(tab["alphas"]) / (1.0 - tab["alphas_cumprod"]))[t].view(-1, 1)
+    return c1 * z_start + c2 * z_t
 
 
 def importance_sample_time(tiw: Tensor, B: int, noise) -> Tensor:

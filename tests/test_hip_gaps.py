@@ -42,6 +42,20 @@ def test_free_energy_compute_loss_golden(golden_dir, tag):
     for k, v in rinfo.items():
         if k in info:
             np.testing.assert_allclose(float(info[k]), float(v), rtol=1e-4, atol=1e-7, err_msg=k)
+    # backward=True: dF/d(log_precision) accumulated into .grad, the direct dF/d(states) and dF/d(score) returned - against the oracle's autograd
+    lp = torch.zeros((), requires_grad=True)
+    zt = torch.from_numpy(g["z"]).clone().requires_grad_(True)
+    ref2, _ = orc.free_energy_loss(p, zt, torch.from_numpy(g["obs"]), lp, 0.5)
+    (g_lp,) = torch.autograd.grad(ref2, [lp], retain_graph=True)
+    direct = 0.5 * torch.sum(zt ** 2, dim=-1).mean() + 0.5 * torch.exp(lp.detach()) * torch.sum((torch.from_numpy(g["obs"]) - zt) ** 2, dim=-1).mean()
+    (g_z,) = torch.autograd.grad(direct, [zt])
+    loss2, info2 = fe.compute_loss(z, obs, None, net, current_time=0.5, backward=True)
+    np.testing.assert_allclose(float(fe.log_precision.grad), float(g_lp), rtol=1e-4)
+    np.testing.assert_allclose(info2["d_states_direct"].cpu().numpy(), g_z.numpy(), rtol=1e-5, atol=1e-7)
+    s_ref = orc.score_forward(p, torch.from_numpy(g["z"]), torch.full((z.shape[0],), 0.5), torch.from_numpy(g["obs"]))
+    np.testing.assert_allclose(info2["d_score"].cpu().numpy(), (0.02 * s_ref / z.shape[0]).numpy(), rtol=1e-3, atol=1e-9)
+    fe.compute_loss(z, obs, None, net, current_time=0.5, backward=True)                       # accumulates, like autograd's .grad
+    np.testing.assert_allclose(float(fe.log_precision.grad), 2 * float(g_lp), rtol=1e-4)
     # update_precision (:93-101): log-precision nudged by 0.01 * clamp(err, -1, 1), clamped to [-3, 3]
     fe.update_precision(torch.tensor(5.0), torch.tensor(1.0)); np.testing.assert_allclose(float(fe.log_precision), 0.01, rtol=1e-6)
     fe.update_precision(torch.tensor(0.25), torch.tensor(0.5)); np.testing.assert_allclose(float(fe.log_precision), 0.0075, rtol=1e-5)

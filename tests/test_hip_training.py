@@ -376,6 +376,15 @@ def test_fokker_planck_full_covariance_reference_golden(nat, golden_dir):
             np.testing.assert_allclose(float(bd.entropy()), float(g[f"{name}_entropy{t}"]), rtol=1e-9)
             np.testing.assert_allclose(float(bd._last_cond[0]), float(g[f"{name}_cond{t}"]), rtol=1e-6)
             assert m32.dtype == torch.float32 and c32.shape == (L, L)
+        # get_diagnostics (belief_dynamics.py:391-409) against the same quantities taken from the reference's covariance matrix
+        d = bd.get_diagnostics()
+        w = np.linalg.eigvalsh(cov)
+        np.testing.assert_allclose([d["min_eigenvalue"], d["max_eigenvalue"], d["condition_number"]], [w.min(), w.max(), w.max() / w.min()], rtol=1e-6)
+        np.testing.assert_allclose(np.log(d["determinant"]) if d["determinant"] > 0 and np.isfinite(d["determinant"]) else np.log(w).sum(), np.log(w).sum(), rtol=1e-8)
+        np.testing.assert_allclose(d["mean_norm"], np.linalg.norm(g[f"{name}_mean{steps - 1}"]), rtol=1e-12)
+        np.testing.assert_allclose(d["entropy"], float(g[f"{name}_entropy{steps - 1}"]), rtol=1e-9)
+    dd = aid_amd.BeliefDynamics(6, aid_amd.BeliefDynamicsConfig()).cuda().get_diagnostics()            # diagonal belief after reset: unit variance
+    assert dd["min_variance"] == dd["max_variance"] == dd["mean_variance"] == 1.0 and dd["mean_norm"] == 0.0
 
 
 def test_fokker_planck_full_covariance_batched_vs_oracle(nat):

@@ -711,6 +711,8 @@ def continuous_q_sample(z, t, eps, lmin, lmax):
     B, L = z.shape
     zn = torch.empty_like(z)
     ls, al, sg = (torch.empty(B, device=z.device) for _ in range(3))
+    if B * L == 0:          # nothing to launch (an empty tensor has no storage to point at)
+        return zn, ls, al, sg
     check(lib().aid_continuous_q_sample(_ptr(z), _ptr(t), _ptr(eps), _ptr(lmin), _ptr(lmax), B, L, _ptr(zn), _ptr(ls), _ptr(al), _ptr(sg), _stream()),
           "aid_continuous_q_sample")
     return zn, ls, al, sg
@@ -726,6 +728,8 @@ def sample_latent_prior(prior_mean, prior_log_std, eps):
 def _step_axpby(fn, name, x0, x1, steps, c0, c1, validate):
     B, L = x0.shape
     out = torch.empty_like(x0)
+    if B * L == 0:
+        return out
     flag = torch.zeros(1, dtype=torch.int32, device=x0.device) if validate else None
     check(fn(_ptr(x0), _steps_ptr(steps) if name == "aid_q_sample" else _ptr(x1), _ptr(x1) if name == "aid_q_sample" else _steps_ptr(steps),
              _ptr(c0), _ptr(c1), int(c0.numel()), B, L, _ptr(out), C.c_void_p(flag.data_ptr()) if validate else C.c_void_p(0), _stream()), name)

@@ -111,9 +111,12 @@ class LatentDiffusionProcess(nn.Module):
     def posterior_coefs(self):
         """(coef1 [N], coef2 [N]) of _posterior_mean, device-resident."""
         if getattr(self, "_post_coefs", None) is None or self._post_coefs[0].device != self.betas.device:
-            c1 = self.betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
-            c2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(self.alphas) / (1.0 - self.alphas_cumprod)
-            self._post_coefs = (c1.contiguous(), c2.contiguous())
+            # N-entry tables, built once on the HOST like the reference's own CPU buffers (IEEE sqrt / divide, so the products below are bit-for-bit
+            # the reference's), then kept on the device
+            b, ap, a, acp = (x.detach().cpu() for x in (self.betas, self.alphas_cumprod_prev, self.alphas, self.alphas_cumprod))
+            c1 = b * torch.sqrt(ap) / (1.0 - acp)
+            c2 = (1.0 - ap) * torch.sqrt(a) / (1.0 - acp)
+            self._post_coefs = (c1.contiguous().to(self.betas.device), c2.contiguous().to(self.betas.device))
         return self._post_coefs
 
     def _posterior_mean(self, z_start: torch.Tensor, z_t: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -47,14 +47,21 @@ def test_a5_forward_process_reference_golden(golden_dir, L):
     np.testing.assert_allclose(ld.compute_loss_weight(t).cpu().numpy(), want("loss_weight"), rtol=3e-6, atol=1e-9)
     prior_eps = cu(NoiseStream(key + 50).randn(B, L))
     np.testing.assert_allclose(ld.sample_latent_prior(B, "cuda", eps=prior_eps).cpu().numpy(), want("prior"), rtol=2e-6, atol=2e-7)
-    # the discrete-schedule forms are one multiply-add per element on the schedule buffers the reference builds the same way: bit-exact
+    # the discrete-schedule forms: one multiply-add per element on the schedule buffers.  The buffers are built on the host (cos / sqrt / cumprod of
+    # setup_schedule), whose vector math library may differ by an ulp between this box's CPU and the one the golden was written on: 1e-6 against the
+    # golden, and BIT-EXACT against the oracle evaluated here on the tables this process built (unfused multiply, multiply, add on both sides)
     qs, qe = ld.q_sample(z, steps, eps)
-    assert qe is eps and np.array_equal(qs.cpu().numpy(), want("q_sample"))
-    assert np.array_equal(ld._posterior_mean(z, z_t, steps).cpu().numpy(), want("posterior_mean"))
-    # and the oracle says the same about its own restatement (what pins it on the GPU box, where the reference cannot run)
+    pm = ld._posterior_mean(z, z_t, steps)
+    assert qe is eps
+    np.testing.assert_allclose(qs.cpu().numpy(), want("q_sample"), rtol=1e-6, atol=5e-7)
+    np.testing.assert_allclose(pm.cpu().numpy(), want("posterior_mean"), rtol=1e-6, atol=5e-7)
+    tab = orc.schedule_tables(N)
+    assert np.array_equal(qs.cpu().numpy(), orc.q_sample(tab, z.cpu(), steps.cpu(), eps.cpu()).numpy())
+    assert np.array_equal(pm.cpu().numpy(), orc.posterior_mean(tab, z.cpu(), z_t.cpu(), steps.cpu()).numpy())
+    # the oracle's restatement against the reference's vectors (what pins it on the GPU box, where the reference cannot run)
     p = {"latent_diffusion." + k: v.detach().cpu() for k, v in ld.state_dict().items()}
-    assert np.array_equal(orc.q_sample(orc.schedule_tables(N), z.cpu(), steps.cpu(), eps.cpu()).numpy(), want("q_sample"))
-    assert np.array_equal(orc.continuous_q_sample(p, z.cpu(), t.cpu(), eps.cpu())[0].numpy(), want("z_noisy"))
+    np.testing.assert_allclose(orc.q_sample(tab, z.cpu(), steps.cpu(), eps.cpu()).numpy(), want("q_sample"), rtol=1e-6, atol=5e-7)
+    np.testing.assert_allclose(orc.continuous_q_sample(p, z.cpu(), t.cpu(), eps.cpu())[0].numpy(), want("z_noisy"), rtol=2e-6, atol=2e-7)
 
 
 def test_a5_drawn_noise_edge_cases_and_errors():

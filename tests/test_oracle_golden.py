@@ -259,3 +259,33 @@ def test_round3_surface_goldens(golden_dir):
         np.testing.assert_allclose(out["latent"].numpy(), g[f"pix_{tag}_latent"], rtol=1e-4, atol=1e-6)
         np.testing.assert_allclose(float(out["reconstruction_error"]), float(g[f"pix_{tag}_rec"]), rtol=1e-5)
         np.testing.assert_allclose(np.stack([x.numpy() for x in out["trajectory"]]), g[f"pix_{tag}_traj"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("L", [17, 128])
+def test_a5_forward_process_oracle_vs_reference_golden(golden_dir, L):
+    """SURVEY row A5 (core/diffusion.py:56-104, 146-174, 239-255): the oracle's restatement against the reference's own outputs
+    (tests/golden/a5_surface.npz, oracle/gen_golden_a5.py; bit-identical when written - 1e-6 here because the host's vector exp / cos may differ by an ulp
+    between CPUs)."""
+    import numpy as np
+    import torch
+    from oracle import aid_oracle as orc
+    from oracle.gen_golden_a5 import B, N, inputs
+    from oracle.noise import NoiseStream
+    g = np.load(os.path.join(golden_dir, "a5_surface.npz"))
+    key = int(g[f"L{L}/key"])
+    d = inputs(L, key)
+    T = torch.from_numpy
+    p = {"latent_diffusion.latent_prior_mean": T(d["prior_mean"]), "latent_diffusion.latent_prior_log_std": T(d["prior_log_std"]),
+         "latent_diffusion.log_snr_min": torch.tensor(float(d["log_snr_min"])), "latent_diffusion.log_snr_max": torch.tensor(float(d["log_snr_max"]))}
+    tab = orc.schedule_tables(N)
+    z, z_t, eps, t, steps = T(d["z"]), T(d["z_t"]), T(d["eps"]), T(d["t"]), T(d["steps"])
+    close = lambda a, k: np.testing.assert_allclose(a.numpy(), g[f"L{L}/{k}"], rtol=2e-6, atol=5e-7, err_msg=k)
+    close(orc.log_snr(p, t), "log_snr")
+    zn, _, info = orc.continuous_q_sample(p, z, t, eps)
+    close(zn, "z_noisy"); close(info["alpha"], "alpha"); close(info["sigma"], "sigma")
+    close(orc.loss_weight(p, t), "loss_weight")
+    close(orc.sample_latent_prior(p, T(NoiseStream(key + 50).randn(B, L))), "prior")
+    close(orc.q_sample(tab, z, steps, eps), "q_sample")
+    close(orc.posterior_mean(tab, z, z_t, steps), "posterior_mean")
+    assert "out_features" in str(g["uncond_reference_raises"])       # the reference's observation=None branch raises (recorded fact)
+    assert orc.score_forward  # the oracle's zero-embedding branch is exercised on the GPU box (tests/test_hip_a5.py)

@@ -224,29 +224,45 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         nrew = self.reward_normalizer.update_and_normalize(rewards, parallel.allgather_cat(rewards) if dp else None)
         if h_a is not None:
             nz_b = ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)
-            h_b = ai.denoise_start(enc_next, 1, nz_b)
-            latents = ai.denoise_join(h_a)
+            if self.stagger_next_obs_chain:      # chain b only once chain a is done: chain a (the critical path) runs next to encode(next_obs) alone
+                latents = ai.denoise_join(h_a)
+                h_b = ai.denoise_start(enc_next, 1, nz_b)
+            else:
+                h_b = ai.denoise_start(enc_next, 1, nz_b)
+                latents = ai.denoise_join(h_a)
             next_latents = None if h_b is not None else ai.denoise_only(enc_next, noise=nz_b, ws=ai._ws)
         else:
             h_b = None
             both = ai.denoise_pair(enc_obs, enc_next, nz_a, ai.noise.belief(B, ai.latent_dim, cfg.hidden_dim, N, train)) if nz_a is not None else ai.denoise_pair(enc_obs, enc_next)
             latents, next_latents = both[:B], both[B:]
         self._mark("main: belief over obs joined")
-        # score / diffusion / encoder / feature-decoder group
+        # score / diffusion / encoder / feature-decoder group.  Schedule (results unchanged up to which GEMM variant a stream's dispatch hint selects):
+        # once the belief over obs is known, two chains of small dependent kernels are ready at the same time - the ELBO (forward, backward, gradient-penalty
+        # double backward: ~400 launches) and the EFE rollout + BPTT - and they overlap well with EACH OTHER (both leave most CUs idle), whereas either of
+        # them crawls underneath the encoder backward's chip-filling convolutions (a 7-us kernel waits for workgroup slots behind 100-us conv workgroups).
+        # So the ELBO goes to the side stream next to the EFE on the calling stream, and the two encoder backward passes + the optimiser step follow the ELBO on
+        # the side stream.  The host draws in the reference's order (ELBO, then EFE).  InfoNCE (no draws) runs first: it needs only features and latents.
         self.score_optimizer.zero_grad()
-        elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents)
-        d_next = torch.zeros_like(enc_next)
-        contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
-        self._mark("main: ELBO + InfoNCE done")
-        # The two encoder backward passes (36 ms at B=256) and the score / encoder / feature-decoder optimiser step depend only on the
-        # feature gradients produced above; the policy, value and dynamics phases read none of those parameters.  They run on a side
-        # stream underneath those phases (in data-parallel runs the gradient all-reduces ride on that stream too).
         main = torch.cuda.current_stream()
         side = self._comm_stream() if self.overlap_streams else main
+        d_next = torch.zeros_like(enc_next)
+        side_elbo = self.elbo_on_side_stream and self.overlap_streams
+        if side_elbo:
+            contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
+            self._mark("main: InfoNCE done")
+        else:
+            elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents)
+            contrastive = self.compute_representation_loss(enc_obs, enc_next, actions, latents, next_latents, d_next, cfg.contrastive_weight)
+            self._mark("main: ELBO + InfoNCE done")
         self._hint_main_stream(main, 2 if (self.overlap_streams and self.main_shares_cus) else 0)      # aid_stream_hint bit 1, as in the state agent
         if self.overlap_streams:
             side.wait_stream(main)
+            for t_ in (enc_obs, enc_next, nrew, latents, d_next):
+                t_.record_stream(side)
         with torch.cuda.stream(side):
+            if side_elbo:
+                elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents, ws=self._side_workspace())
+                self._mark("side: ELBO done", side)
             self.encoder.backward(ai._last_d_obs, ctx_a)
             self.encoder.backward(d_next, ctx_b)
             self._mark("side: encoder backward x2 done", side)
@@ -258,8 +274,10 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
             self.score_optimizer.step()
             self._mark("side: score / encoder step done", side)
         if self.overlap_streams:
-            for t_ in (ai._last_d_obs, d_next, enc_obs, enc_next):
-                t_.record_stream(side)
+            ai._last_d_obs.record_stream(side)
+            for v in elbo_info.values():
+                if torch.is_tensor(v):
+                    v.record_stream(main)
         # policy
         self.policy_optimizer.zero_grad()
         efe, efe_info = ai.compute_expected_free_energy_diffusion(latents, horizon=cfg.efe_horizon, backward=True)
@@ -298,6 +316,13 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
         if self.timeline is not None:
             import time as _t
             ev = torch.cuda.Event(enable_timing=True); ev.record(stream or torch.cuda.current_stream()); self.timeline.append((label, ev, _t.perf_counter()))
+    stagger_next_obs_chain = False      # chain b only after chain a (measured slower: 63.8 vs 60.5 ms, tools/perf/README.md round 5)
+    elbo_on_side_stream = True          # the ELBO on the side stream next to the EFE on the calling stream (see train_step); False: ELBO on the calling stream, EFE behind it
+
+    def _side_workspace(self):
+        if getattr(self, "_ws_side", None) is None:
+            self._ws_side = nat.Workspace(self.device)
+        return self._ws_side
     early_belief_chains = True   # the two belief updates as separately started chains (see train_step); False: one merged / paired loop after both encoder passes
 
     def _comm_stream(self):

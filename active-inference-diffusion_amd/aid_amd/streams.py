@@ -37,5 +37,7 @@ def chain_streams(device=None) -> List[torch.cuda.Stream]:
     """The process's two extra chain streams on `device`."""
     i = _index(device)
     if i not in _chains:
-        _chains[i] = [torch.cuda.Stream(device=torch.device("cuda", i), priority=-1) for _ in range(2)]
+        import os
+        pr = [int(x) for x in os.environ.get("AID_CHAIN_PRIO", "-1,-1").split(",")]          # A/B experiments only
+        _chains[i] = [torch.cuda.Stream(device=torch.device("cuda", i), priority=pr[k]) for k in range(2)]
     return _chains[i]

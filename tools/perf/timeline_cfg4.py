@@ -11,6 +11,8 @@ rng = np.random.default_rng(0); n = 512
 frames = rng.integers(0, 256, (n, 3, 3, 84, 84), dtype=np.uint8)
 agent.replay_buffer.add_batch(frames, rng.uniform(-1, 1, (n, 6)).astype(np.float32), rng.standard_normal(n).astype(np.float32), np.roll(frames, -1, axis=0), rng.random(n) < 0.01)
 agent.early_belief_chains = os.environ.get("EARLY", "1") == "1"
+agent.elbo_on_side_stream = os.environ.get("SIDE_ELBO", "1") == "1"
+agent.stagger_next_obs_chain = os.environ.get("STAGGER", "0") == "1"
 for _ in range(4): agent.train_step()
 n = 8; steps = []
 for _ in range(n + 1):

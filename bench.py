@@ -470,7 +470,45 @@ def other_configs(device):
         res["cfg4_pixel_b256"]["roofline_phases"] = {"error": repr(e)}
     res["pixel_epistemic_f1"] = pixel_epistemic_probe(agent)
     del agent; torch.cuda.empty_cache()
+    try:
+        res["cfg4_pixel_b8_estimator_on"] = pixel_step_with_estimator(device)
+    except Exception as e:      # diagnostics must not cost the bench line
+        res["cfg4_pixel_b8_estimator_on"] = {"error": repr(e)}
     return res
+
+
+def pixel_step_with_estimator(device, B=8):
+    """The pixel train_step as the REFERENCE executes it by default: its ConvDecoder-based estimator evaluated inside every EFE call
+    (core/active_inference.py:362-366 -> 865-883, 977-983) at the default K = 10, S = 10, H = 5 - here opt-in (`ai.pixel_epistemic = True`).  Per step that is
+    H K S B sample rows x 5 decodes of a 3 x 168 x 168 image (~8 GFLOP each): 20 000 images at B = 8, 640 000 at B = 256.  Timed at B = 8 (one warm step, one
+    timed); FLOPs = the library's count of its GEMM / implicit-GEMM launches in that step."""
+    import aid_amd
+    from aid_amd import _native as nat
+    l4, a4 = 128, 6
+    cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=B, efe_horizon=HORIZON, latent_dim=l4, hidden_dim=D, pixel_observation=True)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=NSTEPS)
+
+    class Env4:
+        observation_space, action_space = _Box((3, 3, 84, 84)), _Box((a4,))
+    agent = aid_amd.DiffusionPixelAgent(Env4(), cfg, aid_amd.TrainingConfig(buffer_size=64), aid_amd.PixelObservationConfig())
+    rng = np.random.default_rng(0); n = 64
+    frames = rng.integers(0, 256, (n, 3, 3, 84, 84), dtype=np.uint8)
+    agent.replay_buffer.add_batch(frames, rng.uniform(-1, 1, (n, a4)).astype(np.float32), rng.standard_normal(n).astype(np.float32), np.roll(frames, -1, axis=0), rng.random(n) < 0.01)
+    agent.active_inference.pixel_epistemic = True
+    agent.train_step(); torch.cuda.synchronize()
+    nat.prof_enable(True); nat.prof_reset()
+    t0 = time.perf_counter(); m = agent.train_step(); torch.cuda.synchronize(); dt_prof = time.perf_counter() - t0
+    fl = nat.prof_read(nat.PROF_GEMM)["flops"] + nat.prof_read(nat.PROF_GEMM_TILE)["flops"]
+    nat.prof_enable(False); nat.prof_reset()
+    t0 = time.perf_counter(); m = agent.train_step(); torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    print(f"[bench] pixel train_step with the estimator on, B = {B}: {1e3 * dt:.0f} ms", file=sys.stderr, flush=True)
+    out = {"workload": f"DiffusionPixelAgent.train_step, pixel_epistemic = True (the reference's default behaviour), B = {B}, K = 10, S = 10, H = {HORIZON}, L = 128, D = {D}, "
+                       f"N = {NSTEPS}", "ms_per_step": 1e3 * dt, "images_decoded": 5 * HORIZON * 100 * B, "gemm_flop": fl, "achieved": fl / dt / 1e12,
+           "peak": PEAK_F32_MFMA / 1e12, "unit": "TFLOP/s", "frac": fl / dt / PEAK_F32_MFMA, "epistemic_mean": m.get("epistemic_mean"),
+           "finite": bool(all(np.isfinite(v) for v in m.values())),
+           "note": "B = 256 would decode 640 000 images per step (32x this time): the estimator changes no parameter update, which is why it is opt-in"}
+    del agent; torch.cuda.empty_cache()
+    return out
 
 
 def pixel_epistemic_probe(agent, rows=64, S=2):

@@ -406,3 +406,59 @@ def test_pixel_score_step_waits_for_the_next_obs_belief_chain():
         assert torch.equal(last_a[k], last_b[k]), (k, float((last_a[k] - last_b[k]).abs().max()))
     diff = [k for k in sd_a if not torch.equal(sd_a[k], sd_b[k])]
     assert not diff, diff[:8]
+
+
+def test_pixel_train_step_with_the_estimator_at_default_K_S_vs_oracle():
+    """The pixel train_step the reference actually executes: its ConvDecoder-based estimator evaluated inside every EFE call
+    (core/active_inference.py:362-366 -> 398-415 -> 865-883, 977-983) at the DEFAULT K = 10 trajectories and S = 10 ambiguity samples.  The oracle's CPU cost is
+    ~27 ms per decoded 3 x 168 x 168 image and a step decodes 5 K S H B of them, so the batch and the horizon are what is reduced here (B = 2, H = 2: 2 000
+    images, ~60 s of oracle time on 16 cores); `ai.pixel_epistemic = True` is the switch a user of the reference's default behaviour sets.  Checked: every metric
+    incl. policy_loss, epistemic_mean and epistemic/*, the MINE running mean, and every post-step tensor."""
+    import functools
+    from oracle.encoder_weights import conv_decoder_specs, draw_conv_decoder_params, draw_pixel_estimator_params, pixel_estimator_specs
+    from oracle.weights import draw_feature_decoder
+    L, A, D, N, H, B, K, S, CAP = 16, 4, 64, 3, 2, 2, 10, 10, 4
+    agent = _pixel_agent(L, A, D, N, H, B, cap=CAP)
+    ai = agent.active_inference
+    p = draw_params(param_specs(L, A, L, D, N), 611, orc.schedule_tables(N))
+    p = {k: v for k, v in p.items() if not k.startswith(("observation_decoder.", "epistemic_estimator."))}
+    p.update(draw_feature_decoder(L, D, 612))
+    pdec = draw_conv_decoder_params(conv_decoder_specs(L, hidden=D), 613)
+    p.update({"observation_decoder." + k: v for k, v in pdec.items()}); p.update({"epistemic_estimator.decoder." + k: v for k, v in pdec.items()})
+    p.update({"epistemic_estimator." + k: v for k, v in draw_pixel_estimator_params(pixel_estimator_specs(L), 614).items()})
+    assert set(p) == set(ai.state_dict())
+    ai.load_state_dict(p, strict=True)
+    pe = draw_encoder_params(encoder_specs(L), 615)
+    agent.encoder.load_state_dict(pe, strict=True)
+    full = {k: v.clone() for k, v in p.items()}; full.update({"encoder." + k: v.clone() for k, v in pe.items()})
+    bs = NoiseStream(616)
+    store = {"observations": bs.rand(CAP, 3, 3, 84, 84), "actions": np.tanh(bs.randn(CAP, A)).astype(np.float32), "rewards": bs.randn(CAP),
+             "next_observations": bs.rand(CAP, 3, 3, 84, 84), "dones": np.zeros(CAP, bool)}
+    for i in range(CAP):
+        agent.replay_buffer.add(store["observations"][i], store["actions"][i], float(store["rewards"][i]), store["next_observations"][i], False)
+    pn = ParityNoise(617, pixel=True); pn.live_epistemic_samples = S
+    ai.noise = pn; agent.replay_buffer.index_source = pn
+    ai.pixel_epistemic = True
+    ai.compute_expected_free_energy_diffusion = functools.partial(ai.compute_expected_free_energy_diffusion, num_trajectories=K, num_ambiguity_samples=S)
+    m = agent.train_step()
+    torch.cuda.synchronize()
+    got = {k: v.detach().cpu() for k, v in {**ai.state_dict(), **{"encoder." + k: v for k, v in agent.encoder.state_dict().items()}}.items()}
+    st = orc.OraclePixelState(full, N)
+    ns = NoiseStream(617)
+    batch = orc.replay_sample(dict(store), CAP, B, ns)
+    batch["observations"] = batch["observations"].reshape(B, 9, 84, 84); batch["next_observations"] = batch["next_observations"].reshape(B, 9, 84, 84)
+    torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
+    m_ref = orc.pixel_train_step(st, batch, ns, horizon=H, num_trajectories=K, pixel_epistemic_samples=S)
+    for k, v in m_ref.items():
+        if isinstance(v, float):
+            assert k in m, k
+            np.testing.assert_allclose(m[k], v, rtol=2e-3, atol=5e-4 if k.startswith("epistemic") else 5e-5, err_msg=k)
+    for k in ("epistemic_mean", "epistemic/mi_estimate", "epistemic/running_mean", "policy_loss"):
+        assert k in m
+    np.testing.assert_allclose(float(got["epistemic_estimator.running_mean"]), st.running_mean, rtol=5e-3)
+    # every post-step tensor, with the allowance for elements whose first Adam step amplifies gradient rounding (|g| near eps: the update is lr * sign-like;
+    # at B = 2 the 14 M-element head gradient has a few dozen such elements) that the headline tests use
+    from test_hip_headline import _check_post_step_tensors
+    names = [n for n in st.p if st.p[n].dtype.is_floating_point and not n.endswith(("weight_u", "weight_v", "epistemic_estimator.running_mean"))]
+    moved = _check_post_step_tensors(got, st.p, full, names, 1, 128, tag="pixel step with the estimator, K = S = 10")
+    assert {"latent_score_network", "policy_network", "value_network", "latent_dynamics", "feature_decoder", "encoder"} <= moved, moved

@@ -893,13 +893,14 @@ def encoder_forward(enc: AidEncoderNet, x, shift_h=None, shift_w=None, pad=4, dr
 
 
 def encoder_backward(enc: AidEncoderNet, grads: AidEncoderNet, d_features, saved, drop2d_1=None, drop2d_2=None, drop_out=None, train=False,
-                     ws: Workspace = None):
+                     ws: Workspace = None, phase: int = 0):
+    """phase 0: the whole backward; 1: head only (gradients of ln.* / output_layers.*); 2: attention + conv stack, continuing from phase 1 in the SAME `ws`."""
     B = d_features.shape[0]
     ws = ws or Workspace(d_features.device)
     buf = ws.get(lib().aid_encoder_workspace(C.byref(enc), B))
-    check(lib().aid_encoder_backward(C.byref(enc), C.byref(grads), B, _ptr(d_features.contiguous()), _ptr(drop2d_1), _ptr(drop2d_2), _ptr(drop_out),
-                                     int(bool(train)), C.c_void_p(saved.data_ptr()), C.c_size_t(saved.numel()), C.c_void_p(buf.data_ptr()),
-                                     C.c_size_t(buf.numel()), _stream()), "aid_encoder_backward")
+    check(lib().aid_encoder_backward_phase(C.byref(enc), C.byref(grads), B, _ptr(d_features.contiguous()), _ptr(drop2d_1), _ptr(drop2d_2), _ptr(drop_out),
+                                           int(bool(train)), C.c_void_p(saved.data_ptr()), C.c_size_t(saved.numel()), C.c_void_p(buf.data_ptr()),
+                                           C.c_size_t(buf.numel()), int(phase), _stream()), "aid_encoder_backward")
 
 
 def feature_decoder_step(fd: AidFeatureDecoder, fgrads: AidFeatureDecoder, latents, target, drop_mask, d_target, ws: Workspace = None):

@@ -40,6 +40,15 @@ class _PixelScoreOptimizer:
     def allreduce_grads(self, async_op: bool = False):
         self._pending = [parallel.allreduce_mean_(a.grad, async_op=async_op) for a in (self.score, self.encoder, self.fdec)]
 
+    HEAD = "encoder.output_layers.0.weight"       # Linear(451 584 -> 2L): 462 MB of the 468 MB encoder arena at L = 128
+
+    def allreduce_encoder_head(self):
+        """Data parallel: start the mean of the Linear(451 584 -> 2L) gradient - the first thing the encoder backward produces (its head phase) - now, so that it
+        travels underneath the conv stack's backward; step() then reduces only what is left of the encoder arena.  Issued on the calling (side) stream."""
+        o, shape = self.encoder.offsets[self.HEAD]
+        n = int(torch.Size(shape).numel())
+        self._head = (o, n, parallel.allreduce_mean_(self.encoder.grad[o:o + n], async_op=True))
+
     def step(self):
         if self._pending is not None:
             for h in self._pending:
@@ -47,8 +56,19 @@ class _PixelScoreOptimizer:
                     h.wait()
             self._pending = None
         else:
-            for a in (self.score, self.encoder, self.fdec):
-                parallel.allreduce_mean_(a.grad)
+            head, self._head = getattr(self, "_head", None), None
+            parallel.allreduce_mean_(self.score.grad)
+            if head is None:
+                parallel.allreduce_mean_(self.encoder.grad)
+            else:       # the head slice is already on its way: the rest of the arena in (at most) two pieces around it, then wait for the head
+                o, n, h = head
+                if o > 0:
+                    parallel.allreduce_mean_(self.encoder.grad[:o])
+                if o + n < self.encoder.grad.numel():
+                    parallel.allreduce_mean_(self.encoder.grad[o + n:])
+                if h is not None:
+                    h.wait()
+            parallel.allreduce_mean_(self.fdec.grad)
         g = self.param_groups[0]
         ss, se = self.score.grad_sumsq().clone(), self.encoder.grad_sumsq().clone()
         self.score.step(g["lr"], g["weight_decay"], self.clip, 0.9999, ext_sumsq=se)
@@ -263,8 +283,18 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
             if side_elbo:
                 elbo_loss, elbo_info = ai.compute_diffusion_elbo(enc_obs, nrew, latents, ws=self._side_workspace())
                 self._mark("side: ELBO done", side)
-            self.encoder.backward(ai._last_d_obs, ctx_a)
-            self.encoder.backward(d_next, ctx_b)
+            if dp and self.dp_overlap_encoder_allreduce:
+                # data parallel: the head phase of BOTH passes first (they accumulate into the same Linear(451 584 -> 2L) gradient), then that gradient's
+                # all-reduce is started and the attention / conv-stack phases run underneath it (each pass keeps its hand-over buffer in its own workspace)
+                ws_b = self._encoder_ws_b()
+                self.encoder.backward(ai._last_d_obs, ctx_a, phase=1)
+                self.encoder.backward(d_next, ctx_b, phase=1, ws=ws_b)
+                self.score_optimizer.allreduce_encoder_head()
+                self.encoder.backward(ai._last_d_obs, ctx_a, phase=2)
+                self.encoder.backward(d_next, ctx_b, phase=2, ws=ws_b)
+            else:
+                self.encoder.backward(ai._last_d_obs, ctx_a)
+                self.encoder.backward(d_next, ctx_b)
             self._mark("side: encoder backward x2 done", side)
             # chain b (the belief over next_obs) reads the score-network weights in place on its chain stream: the AdamW / EMA step must not
             # rewrite them before that loop has finished (the reference computes next_latents before score_optimizer.step(), pixel_agent.py:307 vs
@@ -318,6 +348,13 @@ class DiffusionPixelAgent(BaseActiveInferenceAgent):
             ev = torch.cuda.Event(enable_timing=True); ev.record(stream or torch.cuda.current_stream()); self.timeline.append((label, ev, _t.perf_counter()))
     stagger_next_obs_chain = False      # chain b only after chain a (measured slower: 63.8 vs 60.5 ms, tools/perf/README.md round 5)
     elbo_on_side_stream = True          # the ELBO on the side stream next to the EFE on the calling stream (see train_step); False: ELBO on the calling stream, EFE behind it
+
+    dp_overlap_encoder_allreduce = True   # data parallel: all-reduce the encoder head's gradient underneath the conv stack's backward (see train_step)
+
+    def _encoder_ws_b(self):
+        if getattr(self, "_enc_ws_b", None) is None:
+            self._enc_ws_b = nat.Workspace(self.device)
+        return self._enc_ws_b
 
     def _side_workspace(self):
         if getattr(self, "_ws_side", None) is None:

@@ -120,11 +120,12 @@ class DrQV2Encoder(nn.Module):
             return feat, self._saved
         return feat
 
-    def backward(self, d_features: torch.Tensor, ctx=None):
-        """Accumulate parameter gradients for the forward whose context is `ctx` (default: the last keep_for_backward call)."""
+    def backward(self, d_features: torch.Tensor, ctx=None, phase: int = 0, ws=None):
+        """Accumulate parameter gradients for the forward whose context is `ctx` (default: the last keep_for_backward call).  phase 1 / 2: the head
+        (ln.*, output_layers.*) and the rest as two calls that share `ws` (data parallel: the head gradient's all-reduce starts in between)."""
         saved, noise, train = ctx or self._saved
         nat.encoder_backward(self.table(), self.grad_table(), d_features, saved, noise.get("drop2d_1"), noise.get("drop2d_2"), noise.get("drop_out"),
-                             train=train, ws=self._ws)
+                             train=train, ws=ws or self._ws, phase=phase)
 
 
 class _SNConvBias(nn.Module):

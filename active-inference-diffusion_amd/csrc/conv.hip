@@ -887,10 +887,15 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
 }
 
 // backward: d_features [B, L] -> parameter gradients ACCUMULATED into `grads` (same table type; conv_u/conv_v/unused members ignored)
-int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
-                         const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* wsp,
-                         size_t ws_bytes, void* stream) {
-    AID_REQUIRE(enc && grads && d_features && saved, AID_E_NULL, "aid_encoder_backward: null argument");
+// phase: 0 = the whole backward; 1 = the head only (output layers, Linear(F -> 2L), LayerNorm(F): everything that writes the gradients of ln.* and
+// output_layers.*, ending with d(loss)/d(flattened attention output) in the workspace); 2 = the rest (spatial attention, conv stack), reading what phase 1
+// left.  A data-parallel caller runs phase 1 of every pass, starts the all-reduce of the 462 MB Linear(F -> 2L) gradient, and runs phase 2 underneath it.
+// Phases 1 and 2 of one pass must get the SAME workspace, untouched in between (its carve is deterministic: the hand-over buffer has the same address).
+static int encoder_backward_impl(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                                 const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* wsp,
+                                 size_t ws_bytes, int phase, void* stream) {
+    AID_REQUIRE(enc && grads && (d_features || phase == 2) && saved, AID_E_NULL, "aid_encoder_backward: null argument");
+    AID_REQUIRE(phase >= 0 && phase <= 2, AID_E_SHAPE, "aid_encoder_backward: phase %d", phase);
     hipStream_t s = (hipStream_t)stream;
     const AidEncoderNet& e = *enc; const AidEncoderNet& gr = *grads;
     const EncGeom g = enc_geom(e);
@@ -902,6 +907,7 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
     float* d_o0 = ws.f32((size_t)B * L2);
     float* dxln = ws.f32((size_t)B * g.F); float* dxf = ws.f32((size_t)B * g.F);
     AID_WS_OK(ws);
+    if (phase != 2) {
     // ---- output head: tanh(LN(Linear)) <- Dropout(Mish(LN(Linear(F))))
     AID_TRY(ln_bwd_rows(d_features, L, sv.o4, L, sv.st5, e.out5.g, e.out5.b, ACT_TANH, nullptr, d_o4, L, dyeff, B, L, s));
     AID_TRY(ln_param_grad(dyeff, sv.o4, L, sv.st5, gr.out5.g, gr.out5.b, B, L, s, &ws));
@@ -921,6 +927,8 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.xf, e.ln_g, sv.ln_stats, dxf, g.F, vec);
     }
     AID_LAUNCH_CHECK();
+    }
+    if (phase == 1) return AID_OK;
     // ---- spatial attention
     const size_t nact3 = (size_t)256 * B * HW;
     float* dact = ws.f32(nact3); float* da = ws.f32((size_t)B * HW); float* tpart = ws.f32((size_t)B * HW);
@@ -973,6 +981,17 @@ int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, i
         ws.release(mark);
     }
     return AID_OK;
+}
+
+int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                         const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* wsp,
+                         size_t ws_bytes, void* stream) {
+    return encoder_backward_impl(enc, grads, B, d_features, drop2d_1, drop2d_2, drop_out, train, saved, saved_bytes, wsp, ws_bytes, 0, stream);
+}
+int aid_encoder_backward_phase(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                               const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* wsp,
+                               size_t ws_bytes, int phase, void* stream) {
+    return encoder_backward_impl(enc, grads, B, d_features, drop2d_1, drop2d_2, drop_out, train, saved, saved_bytes, wsp, ws_bytes, phase, stream);
 }
 
 }  // extern "C"

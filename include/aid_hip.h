@@ -530,6 +530,13 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
 int aid_encoder_backward(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
                          const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* ws,
                          size_t ws_bytes, void* stream);
+/* The same backward in two parts, for a data-parallel caller that wants the all-reduce of the Linear(451 584 -> 2L) gradient (462 MB at L = 128: the first thing the
+ * backward produces) under way while the conv stack is still being differentiated.  phase 1: output layers, that Linear and LayerNorm(F) - writes the
+ * gradients of ln.* / output_layers.* and leaves d(loss)/d(attention output) in `ws`; phase 2: spatial attention + conv stack, reading it (d_features may be
+ * NULL).  Both phases of one pass take the SAME `ws`, untouched in between; phase 0 = aid_encoder_backward. */
+int aid_encoder_backward_phase(const AidEncoderNet* enc, const AidEncoderNet* grads, int B, const float* d_features, const float* drop2d_1,
+                               const float* drop2d_2, const float* drop_out, int train, const void* saved, size_t saved_bytes, void* ws,
+                               size_t ws_bytes, int phase, void* stream);
 
 /* ---- A0: ReplayBuffer.sample gather (aid/utils/buffers.py:83-111), device-resident ring arrays.
  * idx: [B] int64 row indices.  One coalesced pass over the 2*O + A + 2 floats of each transition. */

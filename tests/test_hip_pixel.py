@@ -462,3 +462,36 @@ def test_pixel_train_step_with_the_estimator_at_default_K_S_vs_oracle():
     names = [n for n in st.p if st.p[n].dtype.is_floating_point and not n.endswith(("weight_u", "weight_v", "epistemic_estimator.running_mean"))]
     moved = _check_post_step_tensors(got, st.p, full, names, 1, 128, tag="pixel step with the estimator, K = S = 10")
     assert {"latent_score_network", "policy_network", "value_network", "latent_dynamics", "feature_decoder", "encoder"} <= moved, moved
+
+
+def test_encoder_backward_in_two_phases_equals_the_whole(nat):
+    """aid_encoder_backward_phase: head phase (1) + attention / conv-stack phase (2) with a shared workspace accumulate exactly the gradients of the one-call
+    backward (phase 0) - what the data-parallel pixel agent relies on to start the all-reduce of the Linear(451 584 -> 2L) gradient between the two."""
+    FD, B = 32, 8
+    p = draw_encoder_params(encoder_specs(FD), 51)
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    enc = nat.encoder_table(pd, FD)
+    ns = NoiseStream(52)
+    x, cot = dev(ns.rand(B, 9, 84, 84)), dev(ns.randn(B, FD))
+    ms = NoiseStream(53)
+    m1, m2, mo = dev(ms.dropout_mask((B, 64), 0.025)), dev(ms.dropout_mask((B, 128), 0.05)), dev(ms.dropout_mask((B, 2 * FD), 0.1))
+    out = []
+    for phases in ((0,), (1, 2)):
+        for k in ("convs.0.weight_u", "convs.0.weight_v"):      # same power-iteration start for both runs
+            pd[k].copy_(p[k].cuda())
+        gd = {k: torch.zeros_like(v) for k, v in pd.items()}
+        genc = nat.encoder_table(gd, FD)
+        f, saved = nat.encoder_forward(enc, x, None, None, 4, m1, m2, mo, train=False)
+        ws = nat.Workspace("cuda")
+        for ph in phases:
+            nat.encoder_backward(enc, genc, cot, saved, m1, m2, mo, train=False, ws=ws, phase=ph)
+        torch.cuda.synchronize()
+        out.append({k: v.cpu() for k, v in gd.items()})
+    head = [k for k in out[0] if k.startswith(("ln.", "output_layers."))]
+    assert head and all(float(out[0][k].abs().max()) > 0 for k in head)
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+    # after phase 1 alone only the head's gradients are non-zero
+    gd = {k: torch.zeros_like(v) for k, v in pd.items()}
+    nat.encoder_backward(enc, nat.encoder_table(gd, FD), cot, saved, m1, m2, mo, train=False, ws=nat.Workspace("cuda"), phase=1)
+    assert all(float(gd[k].abs().max()) == 0 for k in gd if k.startswith(("convs.", "norms.", "attention.")))

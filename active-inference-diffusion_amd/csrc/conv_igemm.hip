@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(256) conv3_igemm_kernel(ConvIgArgs g) {
 
 static int g_ig_dbg = 0;
 static int g_dw_tm = 1;          // aid_conv_debug(12 / 13): tap-major weight-gradient kernel off / on (A/B timing)
+static int g_dw_big = 1;         // aid_conv_debug(14 / 15 / 16): its 128 x 128-tile form off / on where 9 Cin % 128 == 0 / on wherever Cin % 64 == 0 (A/B timing, tests)
 static int g_ig_vec4 = 1;        // aid_conv_debug(10 / 11): four-pixel vector gathers of the tap-major kernels off / on (A/B timing)
 // tap-major kernels need whole BK-channel blocks per tap: BK = 32 for the <= 32-output-channel tile, 16 otherwise
 bool conv3_tapmajor_ok(int Cin, int Cout) { return Cin % (Cout <= 32 ? 32 : 16) == 0; }
@@ -521,6 +522,150 @@ __global__ void __launch_bounds__(256) conv3_igemm_dw_tm_kernel(ConvDwArgs g) {
         if (row < g.Cout && col < g.ldw) out[(size_t)row * g.ldw + col] = col < g.K ? acc[r] : 0.f;
     }
 }
+// (round 5) The tap-major weight gradient on 128 x 128 output tiles: 128 output channels x 128 positions k' = tap Cin + ci (Cin % 64 == 0: each 64-row half of
+// the tile lies in ONE tap), n in stages of 32 with PREFETCH DISTANCE 2 (stage st + 2's global loads are issued before stage st is contracted and land in the
+// register set stage st + 1 does not use) and 4 accumulators of 32 x 32 per wave - per workgroup barrier 64 MFMAs per wave against 16 on the 64 x 64 tile, whose
+// barrier convoy left the matrix pipe idle a quarter of the time (81 TFLOP/s on the encoder's 128 -> 256 layer, 3.26 ms per pass).  Operand traffic per FLOP
+// halves (a 128 x 128 tile reads 2 x 128 rows per 32 n for 4x the products of a 64 x 64 tile).  74 KB of LDS, 2 workgroups per CU; the slab count is chosen
+// so that the grid is one or two full rounds of 512 workgroups.  Same slabs, same fold (conv3_dw_fold_tm_kernel), same summation order within a slab as the
+// 64 x 64 kernel: n ascending, two k-values per MFMA.
+__global__ void __launch_bounds__(256) conv3_igemm_dw_big_kernel(ConvDwArgs g) {
+    constexpr int BT = 128, BK = 32, LD = BK + 4, FL = BT * LD, P = 4;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;              // [2][128 co][36]   (n contiguous)
+    float* Bs = smem + 2 * FL;     // [2][128 k'][36]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wm = (wave >> 1) * 64, wk = (wave & 1) * 64;
+    const int tco = blockIdx.x / g.tiles_k, tk = blockIdx.x % g.tiles_k;
+    const int co0 = tco * BT, k0 = tk * BT;
+    const long nb0 = (long)blockIdx.y * g.chunk, nb1 = min(g.N, nb0 + g.chunk);
+    const int nst = (int)((nb1 - nb0 + BK - 1) / BK);
+    const long plane = (long)g.B * g.Hi * g.Wi, total4 = (long)g.Cin * plane - 4;
+    const int q = tid & 7, krow = tid >> 3;                     // this thread's pixel quad within a stage; its rows krow + 32 i of either operand
+    // per piece i: rows k0 + krow + 32 i -> (tap, ci); pieces 0, 1 share the tile's first tap, pieces 2, 3 the tap of its second half
+    long toff[P]; int dh_[2], dw_[2]; bool kok[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = k0 + krow + 32 * i;
+        kok[i] = k < g.K;
+        const int kc = kok[i] ? k : 0, tap = kc / g.Cin, ci = kc - tap * g.Cin, dh = tap / 3, dw = tap - 3 * dh;
+        toff[i] = (long)(dh - 1) * g.Wi + (dw - 1) + (long)ci * plane;
+        if ((i & 1) == 0) { dh_[i >> 1] = dh; dw_[i >> 1] = dw; }
+    }
+    const bool one_tap = dh_[0] == dh_[1] && dw_[0] == dw_[1];
+    ig_f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    struct Stage { ig_f32x4 a[P], b[P]; int d[P]; unsigned am, bm0, bm1; };
+    int cwo, cho;
+    { const long nn = min(nb0 + 4 * q, g.N - 1); cwo = (int)(nn % g.Wo); cho = (int)((nn / g.Wo) % g.Ho); }
+    auto border = [&](int wo, int ho, int dh, int dw, bool inr) {
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int hh = ho + dh - 1, ww = wo + dw - 1;
+            if (inr && hh >= 0 && hh < g.Hi && ww >= 0 && ww < g.Wi) m |= 1u << e;
+            if (++wo == g.Wo) { wo = 0; if (++ho == g.Ho) ho = 0; }
+        }
+        return m;
+    };
+    // the loads of stage st (stages are requested in order, so one (wo, ho) tracker serves them all); unconditional, from clamped addresses
+    auto load_stage = [&](Stage& t, int st) {
+        const long nb = nb0 + (long)st * BK, n4 = nb + 4 * q;
+        const bool inr = n4 < nb1;                              // N and the slab bounds are multiples of 4: a quad is inside or outside as a whole
+        t.am = 0;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int row = krow + 32 * i;
+            const bool ok = co0 + row < g.Cout && inr;
+            t.am |= (ok ? 1u : 0u) << i;
+            t.a[i] = *reinterpret_cast<const ig_f32x4*>(g.dy + (long)min(co0 + row, g.Cout - 1) * g.N + (ok ? n4 : 0));
+        }
+        t.bm0 = border(cwo, cho, dh_[0], dw_[0], inr);
+        t.bm1 = one_tap ? t.bm0 : border(cwo, cho, dh_[1], dw_[1], inr);
+        cwo += BK;
+        while (cwo >= g.Wo) { cwo -= g.Wo; if (++cho == g.Ho) cho = 0; }
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const long idx = toff[i] + n4;
+            const long idc = idx < 0 ? 0 : (idx > total4 ? total4 : idx);
+            t.d[i] = (int)(idc - idx);
+            t.b[i] = *reinterpret_cast<const ig_f32x4u*>(g.x + idc);
+        }
+    };
+    auto store_stage = [&](const Stage& t, int buf) {
+#pragma unroll
+        for (int i = 0; i < P; ++i)
+            *reinterpret_cast<ig_f32x4*>(As + buf * FL + (krow + 32 * i) * LD + 4 * q) = ((t.am >> i) & 1u) ? t.a[i] : (ig_f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            ig_f32x4 v = t.b[i];
+            const int d = t.d[i];
+            if (d != 0) {                                        // a load clamped at an end of the tensor: element e wants loaded[e - d]
+                ig_f32x4 w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int j = e - d; w[e] = j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : (j == 3 ? v[3] : 0.f))); }
+                v = w;
+            }
+            const unsigned m = kok[i] ? (i < 2 ? t.bm0 : t.bm1) : 0u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ((m >> e) & 1u) ? v[e] : 0.f;
+            *reinterpret_cast<ig_f32x4*>(Bs + buf * FL + (krow + 32 * i) * LD + 4 * q) = v;
+        }
+    };
+    auto contract = [&](int cur) {
+        const float* a_s = As + cur * FL;
+        const float* b_s = Bs + cur * FL;
+#pragma unroll
+        for (int g8 = 0; g8 < BK / 8; ++g8) {
+            ig_f32x4 av[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) av[i] = *reinterpret_cast<const ig_f32x4*>(a_s + (wm + 32 * i + li) * LD + 8 * g8 + 4 * h);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bv[j] = *reinterpret_cast<const ig_f32x4*>(b_s + (wk + 32 * j + li) * LD + 8 * g8 + 4 * h);
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][qq], bv[j][qq], acc[i][j], 0, 0, 0);
+        }
+    };
+    Stage s0, s1;
+    load_stage(s0, 0);
+    load_stage(s1, 1);                                          // stages beyond the slab come back as zeros (their quads are outside [nb0, nb1))
+    store_stage(s0, 0);
+    __syncthreads();
+    // an odd stage count runs one extra all-zero stage instead of leaving the loop half way (the accumulators would otherwise shuttle between register banks)
+    const int nst2 = (nst + 1) & ~1;
+    for (int st = 0; st < nst2; st += 2) {
+        load_stage(s0, st + 2);
+        __builtin_amdgcn_sched_barrier(0);                      // keep the prefetch ahead of the MFMA block
+        contract(0);
+        store_stage(s1, 1);
+        __syncthreads();
+        load_stage(s1, st + 3);
+        __builtin_amdgcn_sched_barrier(0);
+        contract(1);
+        store_stage(s0, 0);
+        __syncthreads();
+    }
+    float* out = g.slab + (size_t)blockIdx.y * g.Cout * g.ldw;
+#pragma clang loop unroll(full)
+    for (int i = 0; i < 2; ++i)
+#pragma clang loop unroll(full)
+        for (int j = 0; j < 2; ++j)
+#pragma clang loop unroll(full)
+            for (int r = 0; r < 16; ++r) {
+                const int row = co0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h, col = k0 + wk + 32 * j + li;
+                if (row < g.Cout && col < g.ldw) out[(size_t)row * g.ldw + col] = col < g.K ? acc[i][j][r] : 0.f;
+            }
+}
 // dW[co][k] = sum of the S slabs (slab order); tm_cin > 0: the slabs are tap-major (position tap tm_cin + ci), dW gets the weight's own order k = ci 9 + tap
 __global__ void conv3_dw_fold_tm_kernel(const float* __restrict__ slab, int S, int Cout, int ldw, int tm_cin, float* __restrict__ dW) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, n = (size_t)Cout * ldw;
@@ -554,6 +699,28 @@ int conv3_igemm_dw(const float* dy, const float* x, float* dW, int ldw, int Cin,
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * Cout * g.K * (double)N, 4.0 * ((double)Cout * N + (double)Cin * B * Hi * Hi));
     prof.m = Cout; prof.n = g.K; prof.k = (int)(N > 2000000000L ? 2000000000L : N); prof.layout = 4 + stride; prof.variant = 32;
     const size_t n = (size_t)Cout * ldw;
+    // 128 x 128 tap-major tiles, prefetch distance 2: measured on the encoder's layers (tools/perf/conv_dw_ab.py, isolated) 128 -> 256: 2.63 ms (101 TFLOP/s)
+    // against 2.83 (94) with the 64 x 64 tiles; 64 -> 128 (4.5 tiles of k': the fifth is half empty): 0.81 against 0.79 - so only where 9 Cin is a
+    // multiple of 128.  (The kernel itself handles Cin % 64 == 0: tests/test_hip_kernels.py runs it there through aid_conv_debug(16).)
+    if (stride == 1 && Hi == Ho && Cin % 64 == 0 && Cout % 128 == 0 && g_dw_tm && g_dw_big && (Cin % 128 == 0 || g_dw_big == 2)) {
+        prof.layout = 4 + stride + 16;
+        const int tiles = (Cout / 128) * ((ldw + 127) / 128);
+        // slabs so that tiles x slabs is two full rounds of the chip's 512 resident workgroups (2 per CU), or - with fewer slabs on offer - nearly two
+        // (> 1.5) or exactly one: a round that is a small fraction full costs as much as a full one
+        const int r2 = 1024 / tiles, r1 = 512 / tiles;
+        int S_use = S_eff >= r2 ? r2 : (S_eff >= r1 ? (S_eff * tiles > 768 ? S_eff : r1) : S_eff);
+        if (S_use < 1) S_use = 1;
+        g.tiles_k = (ldw + 127) / 128;
+        g.chunk = ((N + S_use - 1) / S_use + 31) / 32 * 32;
+        const int S_big = (int)((N + g.chunk - 1) / g.chunk);
+        const size_t lds = sizeof(float) * 4 * 128 * (32 + 4);
+        static bool attr_done = false;
+        if (!attr_done) { AID_CHECK_HIP(hipFuncSetAttribute((const void*)conv3_igemm_dw_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_done = true; }
+        hipLaunchKernelGGL(conv3_igemm_dw_big_kernel, dim3(tiles, S_big), dim3(256), lds, s, g);
+        hipLaunchKernelGGL(conv3_dw_fold_tm_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, slab, S_big, Cout, ldw, Cin, dW);
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
     if (stride == 1 && Hi == Ho && Cin % 64 == 0 && g_dw_tm) {      // tap-major tiles + four-pixel vector gathers
         prof.layout = 4 + stride + 8;
         hipLaunchKernelGGL(conv3_igemm_dw_tm_kernel, dim3(((Cout + 63) / 64) * g.tiles_k, S_eff), dim3(256), sizeof(float) * 4 * 64 * (32 + 4), s, g);
@@ -573,7 +740,7 @@ using namespace aid;
 extern "C" {
 // Unit-test entries for the implicit-GEMM convolution (W: [Cout][ldw] with ldw >= 9 Cin a multiple of 4, x: CNHW [Cin][B][Hi][Hi], out / dy: [Cout][B Ho Ho]).
 int aid_conv_debug(int mode) {
-    if (mode == 10) aid::g_ig_vec4 = 0; else if (mode == 11) aid::g_ig_vec4 = 1; else if (mode == 12) aid::g_dw_tm = 0; else if (mode == 13) aid::g_dw_tm = 1; else aid::g_ig_dbg = mode;
+    if (mode == 10) aid::g_ig_vec4 = 0; else if (mode == 11) aid::g_ig_vec4 = 1; else if (mode == 12) aid::g_dw_tm = 0; else if (mode == 13) aid::g_dw_tm = 1; else if (mode == 14) aid::g_dw_big = 0; else if (mode == 15) aid::g_dw_big = 1; else if (mode == 16) aid::g_dw_big = 2; else aid::g_ig_dbg = mode;
     return AID_OK;
 }
 int aid_conv3_igemm_tm(const float* Wtm, int ldw, const float* x, float* out, int Cin, int Cout, int B, int Hi, int Ho, int stride, void* stream) {

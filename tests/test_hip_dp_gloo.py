@@ -191,4 +191,4 @@ def test_bench_strong_scaling_rehearsal_four_ranks_on_one_gpu():
     dp = out["data_parallel"]
     assert dp["rccl_ranks_seen"] == 4 and dp["backend"] == "gloo" and len(dp["per_rank_ms_per_step"]) == 4 and len(dp["per_rank_ms_per_step_dead_belief_elided"]) == 4
     assert out["value"] > 0 and out["value_dead_belief_elided"] > 0 and "REHEARSAL" in out["data"]
-    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]          # strong: ONE global batch-256 step per step time
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-5 * out["value"]          # strong: ONE global batch-256 step per step time (the line carries 6 significant digits)

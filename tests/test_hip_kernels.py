@@ -685,7 +685,8 @@ def test_gemm_split_k_folded_in_kernel(nat, tmp_path, M, N, K, lay, act, acc):
 
 @pytest.mark.parametrize("Cin,Cout,B,Hi,stride", [(9, 32, 4, 84, 2), (32, 64, 4, 42, 1), (64, 128, 2, 42, 1), (128, 256, 2, 20, 1), (5, 70, 3, 14, 1), (3, 3, 2, 12, 2),
                                                    (32, 32, 3, 21, 1), (64, 32, 2, 30, 1), (32, 3, 2, 17, 1), (16, 80, 3, 13, 2),
-                                                   (32, 128, 40, 42, 1), (16, 160, 38, 42, 1)])        # >= 65 536 pixels x >= 128 channels: the 128 x 128 tile
+                                                   (32, 128, 40, 42, 1), (16, 160, 38, 42, 1),         # >= 65 536 pixels x >= 128 channels: the 128 x 128 tile
+                                                   (128, 128, 3, 21, 1), (192, 256, 1, 16, 1)])        # weight gradient on 128 x 128 tap-major tiles: odd stage counts, a tile across two taps
 def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     """csrc/conv_igemm.hip against torch's conv2d on the CPU (fp64): forward (border taps, stride 2, ragged channel counts), the data
     gradient through the flipped weights, the weight gradient (slab-split contraction over B Ho Wo) - and, where the channel counts allow it, the
@@ -705,9 +706,12 @@ def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     ref.backward(torch.from_numpy(dy).double())
     dy_cnhw = dev(np.ascontiguousarray(dy.transpose(1, 0, 2, 3)))
     if (B * ref.shape[2] * ref.shape[3]) % 4 == 0:
-        dW = nat.conv3_igemm_dw(dy_cnhw, x_cnhw, ldw, stride, slabs=5)
-        np.testing.assert_allclose(dW.cpu().numpy()[:, :K].reshape(w.shape), wt.grad.numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(B * ref.shape[2] * ref.shape[3]))
-        assert float(dW[:, K:].abs().max()) == 0.0 if ldw > K else True
+        for mode in (15, 16, 14):      # 128 x 128 weight-gradient tiles where the product takes them / wherever the kernel can run (Cin % 64 == 0, Cout % 128 == 0) / never
+            nat.lib().aid_conv_debug(mode)
+            dW = nat.conv3_igemm_dw(dy_cnhw, x_cnhw, ldw, stride, slabs=5)
+            np.testing.assert_allclose(dW.cpu().numpy()[:, :K].reshape(w.shape), wt.grad.numpy(), rtol=2e-5, atol=2e-5 * np.sqrt(B * ref.shape[2] * ref.shape[3]))
+            assert float(dW[:, K:].abs().max()) == 0.0 if ldw > K else True
+        nat.lib().aid_conv_debug(15)
     if stride == 1:
         Wt = nat.conv3_flip_weights(dev(W), Cin)
         dx = nat.conv3_igemm(Wt, dy_cnhw, 1)

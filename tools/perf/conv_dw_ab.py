@@ -8,11 +8,11 @@ for Cin, Cout, B, H, name in ((128, 256, 256, 42, "encoder layer 3"), (64, 128, 
     K = 9 * Cin
     x = torch.randn(Cin, B, H, H, device="cuda"); dy = torch.randn(Cout, B, H, H, device="cuda")
     fl = 2.0 * Cout * K * B * H * H
-    for mode, what in ((12, "element gathers, k = ci 9 + tap"), (13, "tap-major tiles, 4-pixel vector gathers")):
-        L.aid_conv_debug(mode)
+    for mode, what in ((12, "element gathers, k = ci 9 + tap"), (14, "tap-major 64 x 64 tiles, 4-pixel vector gathers"), (15, "tap-major 128 x 128 tiles, prefetch distance 2")):
+        L.aid_conv_debug(13); L.aid_conv_debug(15); L.aid_conv_debug(15); L.aid_conv_debug(mode)
         for _ in range(3): nat.conv3_igemm_dw(dy, x, K, 1, slabs=96)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(10): nat.conv3_igemm_dw(dy, x, K, 1, slabs=96)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
         print(f"{name:18s} {what:42s} {dt*1e3:7.3f} ms  {fl/dt/1e12:6.1f} TFLOP/s", flush=True)
-    L.aid_conv_debug(13)
+    L.aid_conv_debug(13); L.aid_conv_debug(15)

@@ -322,13 +322,7 @@ __global__ void attn_conv_kernel(const float* __restrict__ pool, const float* __
         }
     apre[i] = s; att[i] = 1.f / (1.f + expf(-s / temp[0]));
 }
-// out (NCHW-flattened [B][C*HW]) = x * (1 + att)
-__global__ void attn_apply_kernel(const float* __restrict__ x, const float* __restrict__ att, float* __restrict__ out, int C, int B, int HW) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)C * B * HW) return;
-    const int p = i % HW, b = (i / HW) % B, c = i / ((size_t)HW * B);
-    out[((size_t)b * C + c) * HW + p] = x[i] * (1.f + att[(size_t)b * HW + p]);
-}
+// (the attended activation x (1 + att) is never materialised: the LayerNorm(F) kernels below form it on the fly - AttRow)
 // backward A: per (b,p): datt = sum_c dout*x ; da = datt*att(1-att)/T ; tpart[i] = -datt*att(1-att)*a/T^2 ; dxa (CNHW) = dout*(1+att)
 __global__ void attn_bwd_a_kernel(const float* __restrict__ dout /*[B][C][HW]*/, const float* __restrict__ x /*CNHW*/, const float* __restrict__ att,
                                   const float* __restrict__ apre, const float* __restrict__ temp, float* __restrict__ dx /*CNHW*/,
@@ -424,24 +418,44 @@ __device__ __forceinline__ double wg_sum_d(double v, double* sh) {      // <= 10
     for (int i = 0; i < nw; ++i) t += sh[i];
     return t;
 }
-__global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ y,
-                                                     float* __restrict__ stats, size_t F, int vec) {
+// The row a LayerNorm(F) kernel normalises is the spatial attention's output x (1 + att) flattened in NCHW order - element j = c HW + p of row b is
+// act[(c B + b) HW + p] (1 + att[b HW + p]) with act the last conv block's CNHW activation.  (round 5) It is formed ON THE FLY from act and att in every
+// kernel that needs it (forward, both backward kernels): the attn_apply kernel that used to materialise it (462 MB read + 462 MB written per pass, 0.37 ms)
+// and its [B, F] buffer in the saved-activation store are gone.  Same float32 product, so the same bits as before.  HW % 4 == 0 for the float4 loops
+// (a quad never straddles two channels); else the element loops.
+struct AttRow {
+    const float* act; const float* att; int Bn, HW;       // act + b HW: this row's first channel plane; consecutive channels are Bn HW apart
+    __device__ __forceinline__ float at(size_t j) const { const size_t c = j / HW, p = j - c * HW; return act[c * (size_t)Bn * HW + p] * (1.f + att[p]); }
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __device__ __forceinline__ f4 at4(size_t j4) const {     // quad j4 of the row (HW % 4 == 0)
+        const size_t q = (size_t)(HW >> 2), c = j4 / q, pq = j4 - c * q;
+        const f4 a = *reinterpret_cast<const f4*>(act + c * (size_t)Bn * HW + 4 * pq), t = *reinterpret_cast<const f4*>(att + 4 * pq);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = a[e] * (1.f + t[e]);
+        return o;
+    }
+};
+__device__ __forceinline__ AttRow att_row(const float* act, const float* att, int b, int Bn, int HW) { return AttRow{act + (size_t)b * HW, att + (size_t)b * HW, Bn, HW}; }
+
+__global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ act, const float* __restrict__ att, int Bn, int HW, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ y, float* __restrict__ stats, size_t F, int vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ double shd[16];
-    const float* xr = x + (size_t)blockIdx.x * F; float* yr = y + (size_t)blockIdx.x * F;
+    const AttRow xr = att_row(act, att, blockIdx.x, Bn, HW);
+    float* yr = y + (size_t)blockIdx.x * F;
     const size_t F4 = F / 4;
-    const f4* x4 = reinterpret_cast<const f4*>(xr);
     double s = 0.0, q = 0.0;
     if (!vec) {
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const double v = (double)xr[i]; s += v; q += v * v; }
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const double v = (double)xr.at(i); s += v; q += v * v; }
     } else {
         for (size_t i = threadIdx.x; i < F4; i += 4 * (size_t)blockDim.x) {
             f4 v[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const size_t j = i + u * (size_t)blockDim.x; v[u] = j < F4 ? x4[j] : (f4){0.f, 0.f, 0.f, 0.f}; }
+            for (int u = 0; u < 4; ++u) { const size_t j = i + u * (size_t)blockDim.x; v[u] = j < F4 ? xr.at4(j) : (f4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                // four elements folded in float32 products would round: each term goes to float64 on its own (exact squares: 24-bit x 24-bit fits 53)
+                // every term goes to float64 on its own (exact squares: 24-bit x 24-bit fits 53)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { const double d = (double)v[u][e]; s += d; q += d * d; }
             }
@@ -452,14 +466,14 @@ __global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x
     const float mean = (float)md, rstd = (float)(1.0 / sqrt(vard + 1e-5));
     if (threadIdx.x == 0) { stats[2 * blockIdx.x] = mean; stats[2 * blockIdx.x + 1] = rstd; }
     if (!vec) {
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) yr[i] = (xr.at(i) - mean) * rstd * gamma[i] + beta[i];
         return;
     }
     const f4* g4 = reinterpret_cast<const f4*>(gamma); const f4* b4 = reinterpret_cast<const f4*>(beta); f4* y4 = reinterpret_cast<f4*>(yr);
     for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
         const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
-        const f4 a0 = x4[i], c0 = g4[i], d0 = b4[i];
-        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, d1 = two ? b4[j1] : d0;
+        const f4 a0 = xr.at4(i), c0 = g4[i], d0 = b4[i];
+        const f4 a1 = two ? xr.at4(j1) : a0, c1 = two ? g4[j1] : c0, d1 = two ? b4[j1] : d0;
         f4 o0, o1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { o0[e] = (a0[e] - mean) * rstd * c0[e] + d0[e]; o1[e] = (a1[e] - mean) * rstd * c1[e] + d1[e]; }
@@ -467,26 +481,27 @@ __global__ void __launch_bounds__(1024) bigln_kernel(const float* __restrict__ x
         if (two) y4[j1] = o1;
     }
 }
-__global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-                                                         const float* __restrict__ stats, float* __restrict__ dx, size_t F, int vec) {
+__global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ act, const float* __restrict__ att, int Bn, int HW,
+                                                         const float* __restrict__ gamma, const float* __restrict__ stats, float* __restrict__ dx, size_t F, int vec) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ double shd[16];
-    const float* xr = x + (size_t)blockIdx.x * F; const float* dyr = dy + (size_t)blockIdx.x * F; float* dxr = dx + (size_t)blockIdx.x * F;
+    const AttRow xr = att_row(act, att, blockIdx.x, Bn, HW);
+    const float* dyr = dy + (size_t)blockIdx.x * F; float* dxr = dx + (size_t)blockIdx.x * F;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     double sg = 0.0, sgx = 0.0;
     if (!vec) {
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += (double)g; sgx += (double)(g * ((xr[i] - mean) * rstd)); }
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) { const float g = dyr[i] * gamma[i]; sg += (double)g; sgx += (double)(g * ((xr.at(i) - mean) * rstd)); }
         const float mg = (float)(wg_sum_d(sg, shd) / (double)F), mgx = (float)(wg_sum_d(sgx, shd) / (double)F);
-        for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr[i] - mean) * rstd * mgx);
+        for (size_t i = threadIdx.x; i < F; i += blockDim.x) dxr[i] = rstd * (dyr[i] * gamma[i] - mg - (xr.at(i) - mean) * rstd * mgx);
         return;
     }
     const size_t F4 = F / 4;
-    const f4* x4 = reinterpret_cast<const f4*>(xr); const f4* d4 = reinterpret_cast<const f4*>(dyr); const f4* g4 = reinterpret_cast<const f4*>(gamma);
+    const f4* d4 = reinterpret_cast<const f4*>(dyr); const f4* g4 = reinterpret_cast<const f4*>(gamma);
     f4* o4 = reinterpret_cast<f4*>(dxr);
     for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
         const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
-        const f4 a0 = x4[i], c0 = g4[i], e0 = d4[i];
-        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
+        const f4 a0 = xr.at4(i), c0 = g4[i], e0 = d4[i];
+        const f4 a1 = two ? xr.at4(j1) : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const float g0 = e0[e] * c0[e]; sg += (double)g0; sgx += (double)(g0 * ((a0[e] - mean) * rstd));
@@ -496,8 +511,8 @@ __global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict
     const float mg = (float)(wg_sum_d(sg, shd) / (double)F), mgx = (float)(wg_sum_d(sgx, shd) / (double)F);
     for (size_t i = threadIdx.x; i < F4; i += 2 * (size_t)blockDim.x) {
         const size_t j1 = i + blockDim.x; const bool two = j1 < F4;
-        const f4 a0 = x4[i], c0 = g4[i], e0 = d4[i];
-        const f4 a1 = two ? x4[j1] : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
+        const f4 a0 = xr.at4(i), c0 = g4[i], e0 = d4[i];
+        const f4 a1 = two ? xr.at4(j1) : a0, c1 = two ? g4[j1] : c0, e1 = two ? d4[j1] : e0;
         f4 r0, r1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -508,12 +523,17 @@ __global__ void __launch_bounds__(1024) bigln_bwd_kernel(const float* __restrict
         if (two) o4[j1] = r1;
     }
 }
-__global__ void bigln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ stats,
-                                        float* __restrict__ dgamma, float* __restrict__ dbeta, int B, size_t F) {
+__global__ void bigln_param_grad_kernel(const float* __restrict__ dy, const float* __restrict__ act, const float* __restrict__ att, int HW,
+                                        const float* __restrict__ stats, float* __restrict__ dgamma, float* __restrict__ dbeta, int B, size_t F) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= F) return;
+    const size_t c = i / HW, p = i - c * HW;
+    const float* xc = act + c * (size_t)B * HW + p;
     float s0 = 0.f, s1 = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = dy[(size_t)b * F + i]; s0 += d * (x[(size_t)b * F + i] - stats[2 * b]) * stats[2 * b + 1]; s1 += d; }
+    for (int b = 0; b < B; ++b) {
+        const float d = dy[(size_t)b * F + i], x = xc[(size_t)b * HW] * (1.f + att[(size_t)b * HW + p]);
+        s0 += d * (x - stats[2 * b]) * stats[2 * b + 1]; s1 += d;
+    }
     dgamma[i] += s0; dbeta[i] += s1;
 }
 
@@ -541,7 +561,7 @@ struct EncSaved {
     float* x0;                                   // augmented input, CNHW
     float* conv_out[ENC_LAYERS]; float* act[ENC_LAYERS]; float* gn_stats[ENC_LAYERS]; float* w_eff[ENC_LAYERS]; float* sn[ENC_LAYERS];
     float *pool, *apre, *att; int32_t* amax;
-    float *xf, *ln_stats, *xln;
+    float *ln_stats, *xln;
     LlaSave s0; float* o4; float* st5; float* feat;
 };
 static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSaved& sv) {
@@ -554,7 +574,7 @@ static void enc_saved_layout(const AidEncoderNet& e, int B, Workspace& ws, EncSa
     }
     sv.pool = ws.f32((size_t)B * 2 * g.HW); sv.apre = ws.f32((size_t)B * g.HW); sv.att = ws.f32((size_t)B * g.HW);
     sv.amax = (int32_t*)ws.raw(sizeof(int32_t) * (size_t)B * g.HW);
-    sv.xf = ws.f32((size_t)B * g.F); sv.ln_stats = ws.f32((size_t)B * 2); sv.xln = ws.f32((size_t)B * g.F);
+    sv.ln_stats = ws.f32((size_t)B * 2); sv.xln = ws.f32((size_t)B * g.F);
     lla_alloc(B, e.out0.out, ws, sv.s0);
     sv.o4 = ws.f32((size_t)B * e.out4.out); sv.st5 = ws.f32((size_t)B * 2); sv.feat = ws.f32((size_t)B * e.out4.out);
 }
@@ -865,10 +885,9 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
     const int HW = g.HW, Hh = g.ho[3];
     L1D(attn_pool_kernel, B * HW, s, cur, sv.pool, sv.amax, 256, B, HW);
     L1D(attn_conv_kernel, B * HW, s, sv.pool, e.att_conv_w, e.att_conv_b, e.att_temperature, sv.apre, sv.att, B, Hh, Hh);
-    L1D(attn_apply_kernel, (size_t)256 * B * HW, s, cur, sv.att, sv.xf, 256, B, HW);
-    {
-        const int vec = g.F % 4 == 0 && ((((uintptr_t)sv.xf | (uintptr_t)e.ln_g | (uintptr_t)e.ln_b | (uintptr_t)sv.xln) & 15) == 0);
-        hipLaunchKernelGGL(bigln_kernel, dim3(B), dim3(1024), 0, s, sv.xf, e.ln_g, e.ln_b, sv.xln, sv.ln_stats, g.F, vec);
+    {   // LayerNorm(F) over x (1 + att), formed on the fly from the CNHW activation (no attn_apply pass, no [B, F] copy)
+        const int vec = HW % 4 == 0 && ((((uintptr_t)cur | (uintptr_t)sv.att | (uintptr_t)e.ln_g | (uintptr_t)e.ln_b | (uintptr_t)sv.xln) & 15) == 0);
+        hipLaunchKernelGGL(bigln_kernel, dim3(B), dim3(1024), 0, s, cur, sv.att, B, HW, e.ln_g, e.ln_b, sv.xln, sv.ln_stats, g.F, vec);
     }
     AID_LAUNCH_CHECK();
     {   // Linear(F -> 2L): deterministic split-K
@@ -921,10 +940,10 @@ static int encoder_backward_impl(const AidEncoderNet* enc, const AidEncoderNet* 
     AID_TRY(colsum(d_o0, L2, gr.out0.b, B, L2, 1, s, &ws));
     AID_TRY(linear_bwd_data(d_o0, L2, e.out0.w, (int)g.F, dxln, (int)g.F, B, L2, s));
     // ---- LayerNorm(F)
-    hipLaunchKernelGGL(bigln_param_grad_kernel, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, s, dxln, sv.xf, sv.ln_stats, gr.ln_g, gr.ln_b, B, g.F);
+    hipLaunchKernelGGL(bigln_param_grad_kernel, dim3((unsigned)((g.F + 255) / 256)), dim3(256), 0, s, dxln, sv.act[3], sv.att, HW, sv.ln_stats, gr.ln_g, gr.ln_b, B, g.F);
     {
-        const int vec = g.F % 4 == 0 && ((((uintptr_t)dxln | (uintptr_t)sv.xf | (uintptr_t)e.ln_g | (uintptr_t)dxf) & 15) == 0);
-        hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.xf, e.ln_g, sv.ln_stats, dxf, g.F, vec);
+        const int vec = HW % 4 == 0 && ((((uintptr_t)dxln | (uintptr_t)sv.act[3] | (uintptr_t)sv.att | (uintptr_t)e.ln_g | (uintptr_t)dxf) & 15) == 0);
+        hipLaunchKernelGGL(bigln_bwd_kernel, dim3(B), dim3(1024), 0, s, dxln, sv.act[3], sv.att, B, HW, e.ln_g, sv.ln_stats, dxf, g.F, vec);
     }
     AID_LAUNCH_CHECK();
     }

@@ -410,6 +410,112 @@ __global__ void __launch_bounds__(64 * NW) gemm_w4_kernel(MidArgs g, int tiles_m
         }
     }
 }
+// (round 5) The same kernel with the adaLN that produces its A operand as a PROLOGUE, for <= 32 rows (act(), the collector's smallest batches):
+//   x_new = res + bias_in + sum_y slab_in[y] (slab order);  A = LN(x_new) (1 + scale) + shift     (exactly adaln_sum_kernel's arithmetic and order)
+// Every workgroup rebuilds the (at most 32 x 512) A tile into LDS - a wave per row, all loads of a row in flight at once - while its weight fragments are
+// already on their way; the workgroup of column tile 0 / K slice 0 also writes x_new, the residual stream.  At these row counts a denoise step is a chain of
+// 32 dependent launches of ~3.3 us each whatever they compute; folding the 12 adaLN launches into their consumers leaves 20.  (At 32+ rows per tile the
+// redundant prologue costs more than the launch it saves - round 3 measured that with the skinny kernel - so the caller uses this form up to W4LN_MAX_ROWS.)
+// The input slabs and the output slabs must be different buffers (other workgroups may still be reading the former when this one writes the latter).
+struct W4Ln {
+    const float* res; int ldres;                 // [M][D]
+    const float* slab; size_t slab_stride;       // nslab raw K-slice slabs [M][D], or unused with NSLAB == 0
+    const float* bias;                           // [D] or null
+    const float* mod; int ldmod;                 // row m: [scale (D) | shift (D)]
+    float* xout; int ldxo;                       // x_new, written once (may be null)
+};
+constexpr int W4LN_D = 512, W4LN_LD = W4LN_D + 4, W4LN_MAX_ROWS = 16;
+template <int KW, int NW, int ACT, int NSLAB>
+__global__ void __launch_bounds__(64 * NW) gemm_w4ln_kernel(MidArgs g, W4Ln ln) {
+    constexpr int NG = KW / 16, D = W4LN_D, NV = D / 256;
+    extern __shared__ __attribute__((aligned(16))) float w4smem[];
+    float* ys = w4smem;                                               // [32][W4LN_LD]: the normalised A tile (rows >= M are never read: row indices are clamped)
+    float (*red)[2][64][4] = reinterpret_cast<float (*)[2][64][4]>(w4smem + 32 * W4LN_LD);      // [NW][2][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, r16 = lane & 15, kq = lane >> 4;
+    const int b = blockIdx.x;
+    const int ky = b % g.ksplit, tn = b / g.ksplit;                   // one row tile (M <= 32)
+    const int n0 = tn * 16;
+    const int kloc = ky * (g.K / g.ksplit) + wave * KW + 4 * kq;      // this lane's first k
+    // the weight fragments do not depend on the prologue: request them first
+    const float* w0 = g.W + (size_t)min(n0 + r16, g.N - 1) * g.ldw + kloc;
+    f32x4 bv[NG];
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) bv[gk] = *reinterpret_cast<const f32x4*>(w0 + 16 * gk);
+    // ---- prologue: rows wave, wave + NW, ... (adaln_sum_kernel's row body)
+    const bool writer = ln.xout != nullptr && tn == 0 && ky == 0;
+    for (int row = wave; row < g.M; row += NW) {
+        const f32x4* sc = reinterpret_cast<const f32x4*>(ln.mod + (size_t)row * ln.ldmod);
+        const f32x4* sh = reinterpret_cast<const f32x4*>(ln.mod + (size_t)row * ln.ldmod + D);
+        f32x4 v[NV], a[NV], bsh[NV], bi[NV], sl[NSLAB > 0 ? NSLAB : 1][NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = reinterpret_cast<const f32x4*>(ln.res + (size_t)row * ln.ldres)[lane + 64 * i];
+            a[i] = sc[lane + 64 * i]; bsh[i] = sh[lane + 64 * i];
+            bi[i] = ln.bias ? reinterpret_cast<const f32x4*>(ln.bias)[lane + 64 * i] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int y0 = 0; y0 < NSLAB; ++y0)
+#pragma unroll
+            for (int i = 0; i < NV; ++i) sl[y0][i] = reinterpret_cast<const f32x4*>(ln.slab + (size_t)y0 * ln.slab_stride + (size_t)row * D)[lane + 64 * i];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] += bi[i];
+#pragma unroll
+            for (int y0 = 0; y0 < NSLAB; ++y0) v[i] += sl[y0][i];
+        }
+        if (writer) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) reinterpret_cast<f32x4*>(ln.xout + (size_t)row * ln.ldxo)[lane + 64 * i] = v[i];
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) sm += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        const float mean = wave_sum(sm) / (float)D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = (v[i][j] - mean) * rstd * (1.0f + a[i][j]) + bsh[i][j];
+            *reinterpret_cast<f32x4*>(ys + row * W4LN_LD + 4 * (lane + 64 * i)) = o;
+        }
+    }
+    __syncthreads();
+    // ---- the product, A fragments from LDS (row pitch D + 4: the 16 rows of a fragment read hit distinct banks)
+    const float* a0 = ys + min(r16, g.M - 1) * W4LN_LD + kloc;
+    const float* a1 = ys + min(16 + r16, g.M - 1) * W4LN_LD + kloc;
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int gk = 0; gk < NG; ++gk) {
+        const f32x4 av0 = *reinterpret_cast<const f32x4*>(a0 + 16 * gk), av1 = *reinterpret_cast<const f32x4*>(a1 + 16 * gk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av0[q], bv[gk][q], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av1[q], bv[gk][q], acc1, 0, 0, 0);
+        }
+    }
+    *reinterpret_cast<f32x4*>(&red[wave][0][lane][0]) = acc0;
+    *reinterpret_cast<f32x4*>(&red[wave][1][lane][0]) = acc1;
+    __syncthreads();
+    if (tid >= 256) return;
+    const int i = tid >> 7, l = (tid >> 1) & 63, e0 = 2 * (tid & 1);
+#pragma unroll
+    for (int e = e0; e < e0 + 2; ++e) {
+        float v = red[0][i][l][e];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) v += red[w][i][l][e];                          // fixed order: wave 0, 1, 2, ... (as gemm_w4_kernel)
+        const int row = 16 * i + 4 * (l >> 4) + e, col = n0 + (l & 15);
+        if (row < g.M && col < g.N) {
+            if (g.ksplit > 1) g.slab[((size_t)ky * g.M + row) * g.N + col] = v;
+            else g.C[(size_t)row * g.ldc + col] = mid_act<ACT>(v + (g.bias ? g.bias[col] : 0.f));
+        }
+    }
+}
 // waves per workgroup x K per wave for a K slice of `kper`: 64 per wave (12 loads in flight per lane) wherever four or eight waves cover the slice, else 128
 static inline bool w4_shape(int kper, int& nw, int& kw) {
     if (kper == 512) { nw = 8; kw = 64; return true; }
@@ -440,6 +546,47 @@ int gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias,
     if (kw == 64 && nw == 8) AID_W4A(64, 8) else if (kw == 64) AID_W4A(64, 4) else AID_W4A(128, 8)
 #undef AID_W4A
 #undef AID_W4
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+
+bool gemm_w4ln_ok(int M, int N, int K, int ksplit, int act, const float* W, int ldw, int nslab_in) {
+    int nw, kw;
+    return M >= 1 && M <= W4LN_MAX_ROWS && K == W4LN_D && N >= 16 && ksplit >= 1 && K % ksplit == 0 && w4_shape(K / ksplit, nw, kw) && kw == 64 &&
+           ((((uintptr_t)W) & 15) == 0) && ldw % 4 == 0 && (ksplit == 1 || act == ACT_NONE) && (act == ACT_NONE || act == ACT_GELU || act == ACT_SILU) &&
+           (nslab_in == 0 || nslab_in == 2 || nslab_in == 4);
+}
+// C = act(adaLN(res + bias_in + sum slab_in) W^T + bias) or raw K-slice slabs of it; see gemm_w4ln_kernel.  K = 512, M <= W4LN_MAX_ROWS.
+int gemm_w4ln(const float* res, int ldres, const float* slab_in, int nslab_in, const float* bias_in, const float* mod, int ldmod, float* xout, int ldxo,
+              const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit, hipStream_t s) {
+    AID_REQUIRE(gemm_w4ln_ok(M, N, K, ksplit, act, W, ldw, nslab_in) && res && mod && (ksplit == 1 ? C != nullptr : slab != nullptr) && (nslab_in == 0 || slab_in) &&
+                slab_in != slab, AID_E_SHAPE, "gemm_w4ln: unsupported M=%d N=%d K=%d ksplit=%d act=%d slabs=%d", M, N, K, ksplit, act, nslab_in);
+    MidArgs g; memset(&g, 0, sizeof(g));
+    g.W = W; g.ldw = ldw; g.bias = bias; g.C = C; g.ldc = ldc; g.slab = slab; g.M = M; g.N = N; g.K = K; g.ksplit = ksplit; g.act = act;
+    W4Ln ln{res, ldres, slab_in, (size_t)M * W4LN_D, bias_in, mod, ldmod, xout, ldxo};
+    ProfScope prof(PROF_GEMM, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)ksplit * M * N));
+    prof.m = M; prof.n = N; prof.k = K; prof.layout = act; prof.variant = 27;
+    int nw = 0, kw = 0; w4_shape(K / ksplit, nw, kw);
+    const dim3 grid(((N + 15) / 16) * ksplit);
+    const size_t lds = sizeof(float) * ((size_t)32 * W4LN_LD + (size_t)nw * 2 * 64 * 4);
+    auto go = [&](auto kern) {
+        // 66 KB + the fold buffer: above the 64 KB a kernel gets without asking
+        static thread_local const void* done[24]; static thread_local int ndone = 0;
+        const void* fp = (const void*)kern;
+        bool have = false;
+        for (int i = 0; i < ndone; ++i) have = have || done[i] == fp;
+        if (!have) { if (hipFuncSetAttribute(fp, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AID_E_HIP; if (ndone < 24) done[ndone++] = fp; }
+        hipLaunchKernelGGL(kern, grid, dim3(64 * nw), lds, s, g, ln);
+        return (int)AID_OK;
+    };
+    int rc;
+#define AID_W4LN_S(NW_, ACT_, NS_) rc = go(gemm_w4ln_kernel<64, NW_, ACT_, NS_>)
+#define AID_W4LN(NW_, ACT_) { if (nslab_in == 0) AID_W4LN_S(NW_, ACT_, 0); else if (nslab_in == 2) AID_W4LN_S(NW_, ACT_, 2); else AID_W4LN_S(NW_, ACT_, 4); }
+    if (nw == 8) { if (act == ACT_GELU) AID_W4LN(8, ACT_GELU) else if (act == ACT_SILU) AID_W4LN(8, ACT_SILU) else AID_W4LN(8, ACT_NONE) }
+    else { if (act == ACT_GELU) AID_W4LN(4, ACT_GELU) else if (act == ACT_SILU) AID_W4LN(4, ACT_SILU) else AID_W4LN(4, ACT_NONE) }
+#undef AID_W4LN
+#undef AID_W4LN_S
+    if (rc != AID_OK) { ::aid::set_error("gemm_w4ln: hipFuncSetAttribute failed"); return rc; }
     AID_LAUNCH_CHECK();
     return AID_OK;
 }

@@ -125,6 +125,10 @@ bool gemm_w4_ok(int M, int N, int K, int ksplit, int act, const float* A, int ld
 int gemm_w4(const float* A, int lda, const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit,
             hipStream_t s);
 // x_new = res + bias + sum of `nslab` slabs [M,D] (fixed order) -> xout (optional);  y = LN(x_new) (1 + scale) + shift (adaLN, mod row = [scale | shift])
+// <= 16 rows: gemm_w4 with the adaLN that produces its A operand as a prologue (res + bias_in + slab_in[0..nslab_in) -> LN -> modulation; x_new -> xout once)
+bool gemm_w4ln_ok(int M, int N, int K, int ksplit, int act, const float* W, int ldw, int nslab_in);
+int gemm_w4ln(const float* res, int ldres, const float* slab_in, int nslab_in, const float* bias_in, const float* mod, int ldmod, float* xout, int ldxo,
+              const float* W, int ldw, const float* bias, int act, float* C, int ldc, float* slab, int M, int N, int K, int ksplit, hipStream_t s);
 bool adaln_sum_ok(int D, const float* res, int ldres, const float* slab, const float* bias, const float* mod, int ldmod, const float* xout, int ldxo,
                   const float* y, int ldy);
 int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,

@@ -51,7 +51,7 @@ int score_cond(const AidScoreNet& n, int B, const float* drop_mask, const float*
 // slab: [4][rows][D] scratch for the split-K partial products of the mid-M pipeline (null: not used)
 // wlp_t: latent_proj weight transposed to [L][D] (folded into block 0's adaLN); p0_slabs: set by the trunk when it left the head's first
 // layer as 4 raw slabs in `slab` ([4][rows][D/2]) for head2_slab_p_sample instead of writing p0
-struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; float* slab = nullptr; float* wlp_t = nullptr; bool p0_slabs = false;
+struct ScoreFused { float* wov[AID_MAX_BLOCKS]; float* bov[AID_MAX_BLOCKS]; float* slab = nullptr; float* slab2 = nullptr; float* wlp_t = nullptr; bool p0_slabs = false;
                     bool lp_done = false; };   // lp_done: block 0's adaLN (+ latent projection) of this step was produced by the previous step's reverse-step kernel (NextLp)
 int score_fuse_attention(const AidScoreNet& n, Workspace& ws, ScoreFused& f, hipStream_t s);
 // latent_proj, DiT blocks, final adaLN, output_proj -> a.raw [B,L]

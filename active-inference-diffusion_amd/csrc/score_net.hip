@@ -141,6 +141,7 @@ static int g_fuse_next_lp = 1;    // aid_denoise_debug(-5 / -6): the next step's
 // the <= 128-row loop: 1 = gemm_w4 pipeline (score_trunk_small); 0 = weight-streaming skinny / panel kernels (score_trunk).  aid_denoise_debug(-1 / -2):
 // A/B timing (tools/perf/small_batch_ab.py)
 static int g_mid_small = 1;
+static int g_mid_ks_ov = 0;      // aid_denoise_debug(-7 / -8 / -9): K slices of the 512-deep x Wov^T product at 129..1024 rows: 2 / 1 / default (= mid_ksplit: 4) - A/B timing
 static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const ScoreFused* f) {
     const int D = n.D;
     if (!f || !f->slab || n.n_blocks < 1) return false;
@@ -151,7 +152,7 @@ static bool trunk_mid_ok(const AidScoreNet& n, int B, const ScoreActs& a, const 
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
 static int score_trunk_mid(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
-    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS = mid_ksplit(B), KS4 = KS, KSH = 4;
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KS4 = mid_ksplit(B), KS = (g_mid_ks_ov > 0 && B <= 1024) ? g_mid_ks_ov : KS4, KSH = 4;
     // the raw product of a 512-wide layer: `ks` slabs (ks == 1: the one "slab" is the kernel's ordinary output, no bias / activation)
     auto product = [&](const float* x, int ldx, const float* W, int K, int ks) {
         return gemm_mid(x, ldx, W, K, nullptr, ACT_NONE, nullptr, 0, ks == 1 ? f.slab : nullptr, D, ks == 1 ? nullptr : f.slab, B, D, K, ks, s);
@@ -204,7 +205,46 @@ static bool trunk_small_ok(const AidScoreNet& n, int B, const ScoreActs& a, cons
            gemm_w4_ok(B, D / 2, D, 1, ACT_SILU, a.nxf, D, n.op0_w, D) &&
            adaln_sum_ok(D, b.h_in, D, f->slab, f->bov[0], a.mod, n_ada(n) * 2 * D, b.h_mid, D, b.nx2, D);
 }
+// <= 16 rows (round 5): the adaLN launches folded into the GEMMs that consume them (gemm_w4ln: 20 launches per denoise step instead of 32).  Same arithmetic
+// in the same order as score_trunk_small, so the same bits.  The two slab buffers alternate: a fused GEMM reads its input slabs while it writes its own.
+static int g_w4ln = 1;          // aid_denoise_debug(-10 / -11): on / off (A/B timing)
+static bool trunk_small_fused_ok(const AidScoreNet& n, int B, const ScoreFused* f) {
+    const int D = n.D;
+    return g_w4ln == 1 && f && f->slab && f->slab2 && D == 512 && gemm_w4ln_ok(B, D, D, 2, ACT_NONE, f->wov[0], D, 4) &&
+           gemm_w4ln_ok(B, 4 * D, D, 1, ACT_GELU, n.blk[0].mlp0_w, D, 2) && gemm_w4ln_ok(B, D / 2, D, 1, ACT_SILU, n.op0_w, D, 4) && small_ks(4 * D) == 4;
+}
+static int score_trunk_small_fused(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
+    const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D, KSO = 2, KS4 = 4;
+    float* slabA = f.slab; float* slabB = f.slab2;          // A: x Wov^T slices; B: u W2^T slices
+    const bool lp_fused = f.wlp_t != nullptr && L <= 32;
+    if (!lp_fused) AID_TRY(linear_fwd(z, L, n.lp_w, n.lp_b, a.h0, D, B, D, L, ACT_NONE, s));
+    const float* pend_res = nullptr; const float* pend_bias = nullptr;
+    for (int i = 0; i < n.n_blocks; ++i) {
+        const AidDiTBlock& w = n.blk[i];
+        ScoreBlockActs& b = a.blk[i];
+        const float* mod1 = a.mod + (size_t)(2 * i) * 2 * D; const float* mod2 = a.mod + (size_t)(2 * i + 1) * 2 * D;
+        if (pend_res) {     // h_in = pend_res + u W2^T + b2 (previous block); x Wov^T of adaLN1(h_in), in KSO raw slices
+            AID_TRY(gemm_w4ln(pend_res, D, slabB, KS4, pend_bias, mod1, ldmod, b.h_in, D, f.wov[i], D, nullptr, ACT_NONE, nullptr, 0, slabA, B, D, D, KSO, s));
+        } else {
+            if (lp_fused && f.lp_done) {}
+            else if (lp_fused) AID_TRY(adaln_lp(z, L, f.wlp_t, n.lp_b, mod1, ldmod, b.h_in, D, b.nx1, D, B, D, s));
+            else AID_TRY(adaln(b.h_in, D, mod1, ldmod, b.nx1, D, nullptr, B, D, s));
+            AID_TRY(gemm_w4(b.nx1, D, f.wov[i], D, nullptr, ACT_NONE, nullptr, D, slabA, B, D, D, KSO, s));
+        }
+        // h_mid = h_in + x Wov^T + bov;  u = GELU(adaLN2(h_mid) W1^T + b1)
+        AID_TRY(gemm_w4ln(b.h_in, D, slabA, KSO, f.bov[i], mod2, ldmod, b.h_mid, D, w.mlp0_w, D, w.mlp0_b, ACT_GELU, b.u, 4 * D, nullptr, B, 4 * D, D, 1, s));
+        AID_TRY(gemm_w4(b.u, 4 * D, w.mlp2_w, 4 * D, nullptr, ACT_NONE, nullptr, D, slabB, B, D, 4 * D, KS4, s));
+        pend_res = b.h_mid; pend_bias = w.mlp2_b;
+    }
+    f.p0_slabs = false;
+    // h_last = pend_res + u W2^T + b2;  p0 = SiLU(adaLN_f(h_last) op0^T + b)
+    AID_TRY(gemm_w4ln(pend_res, D, slabB, KS4, pend_bias, a.mod + (size_t)(2 * n.n_blocks) * 2 * D, ldmod, a.h_last, D, n.op0_w, D, n.op0_b, ACT_SILU, a.p0, D / 2,
+                      nullptr, B, D / 2, D, 1, s));
+    if (!skip_last) AID_TRY(linear_fwd(a.p0, D / 2, n.op2_w, nullptr, a.raw, L, B, L, D / 2, ACT_NONE, s));
+    return AID_OK;
+}
 static int score_trunk_small(const AidScoreNet& n, int B, const float* z, ScoreActs& a, hipStream_t s, ScoreFused& f, bool skip_last) {
+    if (trunk_small_fused_ok(n, B, &f)) return score_trunk_small_fused(n, B, z, a, s, f, skip_last);
     const int D = n.D, L = n.L, NA = n_ada(n), ldmod = NA * 2 * D;
     const int KSO = D == 512 ? 2 : 1, KS4 = small_ks(4 * D);
     auto product = [&](const float* x, int ldx, const float* W, int K, int ks) {      // ks == 1: the one "slab" is the complete product (no bias)
@@ -345,7 +385,7 @@ size_t aid_denoise_loop_workspace(const AidScoreNet* net, int B, int n_steps) {
     // split-K slabs of the mid-M pipeline - 4 slices above 128 rows, max(4, K slices of the 4D-deep product) at <= 128 rows: exactly what denoise_impl
     // carves - and the transposed latent_proj weight
     const size_t nsl = B > 128 ? 4 : (small_ks(4 * (int)D) > 4 ? small_ks(4 * (int)D) : 4);
-    n += sizeof(float) * (nsl * (size_t)B * D + (size_t)L * D) + 512;
+    n += sizeof(float) * (nsl * (size_t)B * D * (B <= 16 ? 2 : 1) + (size_t)L * D) + 1024;
     return n + (1 << 16);
 }
 
@@ -415,7 +455,9 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
     AID_TRY(score_fuse_attention(n, ws, fused, s));
     if (B <= MID_MAX_M && (B > 128 || g_mid_small)) {      // split-K pipelines: score_trunk_mid (one workgroup per CU at 129..1024 rows), score_trunk_small (<= 128 rows)
         const int nsl = B > 128 ? 4 : (small_ks(4 * D) > 4 ? small_ks(4 * D) : 4);
-        fused.slab = ws.f32((size_t)nsl * B * D); fused.wlp_t = ws.f32((size_t)L * D); AID_WS_OK(ws);
+        fused.slab = ws.f32((size_t)nsl * B * D); fused.wlp_t = ws.f32((size_t)L * D);
+        fused.slab2 = B <= 16 ? ws.f32((size_t)nsl * B * D) : nullptr;      // second slab buffer of the fused small-batch trunk (gemm_w4ln)
+        AID_WS_OK(ws);
         AID_TRY(transpose_small(n.lp_w, fused.wlp_t, D, L, s));
     }
     ScoreActs a;
@@ -514,6 +556,8 @@ static int denoise_impl(const AidScoreNet* net, int B, int N, const float* coefs
 
 int aid_denoise_debug(int chunk_cap) {
     if (chunk_cap == -1) g_mid_small = 1; else if (chunk_cap == -2) g_mid_small = 0;
+    else if (chunk_cap == -10) g_w4ln = 1; else if (chunk_cap == -11) g_w4ln = 0;
+    else if (chunk_cap == -7) g_mid_ks_ov = 2; else if (chunk_cap == -8) g_mid_ks_ov = 1; else if (chunk_cap == -9) g_mid_ks_ov = 0;
     else if (chunk_cap == -5) g_fuse_next_lp = 1; else if (chunk_cap == -6) g_fuse_next_lp = 0;
     else g_chunk_cap = chunk_cap;
     return AID_OK;

@@ -200,7 +200,9 @@ def small_batch_loops(agent):
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
             out[name] = {"rows": b, "loop_us": 1e6 * dt, "us_per_denoise_step": 1e6 * dt / NSTEPS, "denoise_steps_per_s": NSTEPS / dt,
                          "weight_bytes_per_step": live_bytes, "achieved_GBps": live_bytes * NSTEPS / dt / 1e9, "peak_GBps": 8000.0,
-                         "frac": live_bytes * NSTEPS / dt / 8e12, "bound": "hbm", "note": "hipGraph replay of the whole loop; launch-chain bound (32 dependent kernels per step)"}
+                         "frac": live_bytes * NSTEPS / dt / 8e12, "bound": "hbm",
+                         "note": "hipGraph replay of the whole loop; launch-chain bound: " + ("20 dependent kernels per step (adaLN folded into its consumer GEMMs, gemm_w4ln)"
+                                                                                              if b <= 16 else "32 dependent kernels per step")}
     finally:
         ai.train(was_training)
         ai.__dict__.get("_denoise_graphs", {}).clear()      # the captured loops (and their private memory pools) are not needed any more

@@ -723,3 +723,44 @@ def test_conv3_implicit_gemm(nat, Cin, Cout, B, Hi, stride):
     if stride == 1 and tm_ok(Cout, Cin):
         dx_tm = nat.conv3_igemm_tm(dev(W), dy_cnhw, 1, flip_transpose=True)
         np.testing.assert_allclose(dx_tm.cpu().numpy().transpose(1, 0, 2, 3), xt.grad.numpy(), rtol=2e-5, atol=5e-5)
+
+
+@pytest.mark.parametrize("B", [1, 3, 8, 16])
+def test_small_batch_loop_with_adaln_folded_into_its_gemms(nat, B):
+    """<= 16 rows (act(), the collector's smallest batches): the reverse loop with the adaLN launches folded into the GEMMs that consume them
+    (csrc/gemm_mid.hip, gemm_w4ln_kernel: 20 launches per denoise step instead of 32) against the same loop with separate adaLN kernels - the SAME arithmetic
+    in the same order, so bit-identical latents and trajectory - and, through that loop, against everything the unfused loop is tested against (loop goldens,
+    oracle).  Reference: models/score_networks.py:214-235, core/diffusion.py:176-206."""
+    from oracle import aid_oracle as orc
+    from oracle.weights import draw_params, param_specs
+    O, D, N = 17, 512, 6
+    p = draw_params(param_specs(O, 6, O, D, N), 77, orc.schedule_tables(N))
+    pd = {k: v.cuda().contiguous() for k, v in p.items()}
+    tab = nat.score_net_table(pd, "latent_score_network.", O, O, D)
+    coefs = orc.p_sample_coefs(orc.schedule_tables(N)).cuda().contiguous()
+    rng = np.random.default_rng(B)
+    obs, z0, eps = dev(rng.standard_normal((B, O))), dev(rng.standard_normal((B, O))), dev(rng.standard_normal((N, B, O)))
+    outs = []
+    for mode in (-10, -11):
+        nat.lib().aid_denoise_debug(mode)
+        z, traj = nat.denoise_loop(tab, coefs, obs, N, z0, eps, None, train=False, keep_traj=True)
+        torch.cuda.synchronize()
+        outs.append((z.clone(), traj.clone()))
+    nat.lib().aid_denoise_debug(-10)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = orc.generate_latent_trajectory({k: v for k, v in p.items()}, orc.schedule_tables(N), obs.cpu(), _FixedNoise(z0.cpu(), eps.cpu()), False)
+    np.testing.assert_allclose(outs[0][0].cpu().numpy(), ref.numpy(), rtol=1e-3, atol=1e-5)
+
+
+class _FixedNoise:
+    """The draws generate_latent_trajectory makes, served from given tensors: randn(B, L) first, then one randn per step t = N-1 .. 1."""
+    def __init__(self, z0, eps):
+        self.z0, self.eps, self.t = z0, eps, eps.shape[0] - 1
+        self.first = True
+
+    def randn(self, *shape):
+        if self.first:
+            self.first = False
+            return self.z0.numpy()
+        out = self.eps[self.t].numpy(); self.t -= 1
+        return out

@@ -731,7 +731,7 @@ def main():
     obs = torch.randn(BATCH, O, device=device)
     for _ in range(0 if "denoise" in SKIP else 2):
         ai.denoise_only(obs)
-    torch.cuda.synchronize(); t1 = time.perf_counter(); reps = 5
+    torch.cuda.synchronize(); t1 = time.perf_counter(); reps = 1 if "denoise" in SKIP else 5
     for _ in range(reps):
         ai.denoise_only(obs)
     torch.cuda.synchronize(); dn = (time.perf_counter() - t1) / reps

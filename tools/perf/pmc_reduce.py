@@ -33,6 +33,10 @@ for k, e in top:
         # MFMA busy cycles are summed over SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE over the 8 XCDs
         s["mfma_util"] = (e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024) / (e["GRBM_GUI_ACTIVE_per_launch"] / 8)
         s["eff_clock_GHz"] = e["GRBM_GUI_ACTIVE_per_launch"] / 8 / (e["avg_us_mfma"] * 1e3)
+        # GRBM_GUI_ACTIVE spans more than the kernel on dispatches of a few us (eff_clock > the 2.4 GHz maximum: the guide says the quotient reads high below
+        # ~0.3 ms), which dilutes mfma_util above by the same factor.  Second figure: busy cycles per SIMD over the kernel's OWN duration at the clock the
+        # chip can at most run (2.4 GHz) - a lower bound on the utilisation inside the kernel; for the long kernels (eff_clock 2.0-2.3) the two agree.
+        s["mfma_util_kernel_window_lower_bound"] = (e["SQ_VALU_MFMA_BUSY_CYCLES_per_launch"] / 1024) / (e["avg_us_mfma"] * 1e-6 * 2.4e9)
     summary[k] = s
 json.dump(summary, open(os.path.join(out, "pmc_summary.json"), "w"), indent=1)
 for k, s in summary.items():

@@ -278,7 +278,12 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
 // workgroup is 48 KB of LDS, so three fit a CU - but at the 184 VGPRs the compiler takes by itself only two waves fit a SIMD and the third
 // chain's workgroup waits for a slot (three chains overlapped 1.63x, exactly what two resident workgroups give).
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
-__global__ void __launch_bounds__(256, 3) gemm_mid_kernel_o3(MidArgs g, int tiles_m, int tiles_n) { gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n); }
+__global__ void __launch_bounds__(256, 3) gemm_mid_kernel_o3(MidArgs g, int tiles_m, int tiles_n) {
+#ifdef AID_CHAIN_SETPRIO
+    __builtin_amdgcn_s_setprio(3);       // experiment (tools/perf/README.md, round 5): the chain's short waves ahead of a co-resident tall kernel's in issue arbitration
+#endif
+    gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n);
+}
 
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 static int launch_mid(const MidArgs& g, hipStream_t s) {
@@ -601,6 +606,9 @@ __global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const
                                  float* __restrict__ y, int ldy, int M) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int D = 256 * NV;
+#ifdef AID_CHAIN_SETPRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);

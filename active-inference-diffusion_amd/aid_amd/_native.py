@@ -231,7 +231,7 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("AID_HIP_LIB", LIB_PATH)     # another build of the same library (A/B measurements of kernel variants)
+    path = os.environ.get("AID_HIP_LIB") or LIB_PATH     # another build of the same library (A/B measurements of kernel variants)
     if not os.path.exists(path):
         raise RuntimeError(
             f"aid_amd: native library not found at {path}. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -50,6 +50,11 @@ struct MidArgs {
     int M, N, K, ksplit, act;
 };
 
+// issue priority of the reverse loop's kernels (see gemm_mid_kernel_o3); -DAID_CHAIN_PRIO_LEVEL=0 builds them without it (A/B)
+#ifndef AID_CHAIN_PRIO_LEVEL
+#define AID_CHAIN_PRIO_LEVEL 3
+#endif
+#define AID_CHAIN_PRIO() do { if (AID_CHAIN_PRIO_LEVEL > 0) __builtin_amdgcn_s_setprio(AID_CHAIN_PRIO_LEVEL); } while (0)
 constexpr int MID_BK = 64, MID_BN = 64;
 __device__ __forceinline__ int mid_off(int row, int chunk) { return row * MID_BK + ((chunk ^ (row & 15)) << 2); }
 
@@ -279,9 +284,12 @@ __global__ void __launch_bounds__(256) gemm_mid_kernel(MidArgs g, int tiles_m, i
 // chain's workgroup waits for a slot (three chains overlapped 1.63x, exactly what two resident workgroups give).
 template <int BMF, int WM, int WN, int NJ, int ACT, bool BKM>
 __global__ void __launch_bounds__(256, 3) gemm_mid_kernel_o3(MidArgs g, int tiles_m, int tiles_n) {
-#ifdef AID_CHAIN_SETPRIO
-    __builtin_amdgcn_s_setprio(3);       // experiment (tools/perf/README.md, round 5): the chain's short waves ahead of a co-resident tall kernel's in issue arbitration
-#endif
+    // (round 5) The reverse loop's kernels raise their waves' issue priority: a belief chain runs on a side stream UNDERNEATH the estimator's tall full-row
+    // kernels, and where a chain workgroup is co-resident with one (the 512-wide stages) its few short waves were losing the SIMD's issue arbitration to the
+    // tall kernel's two older, MFMA-dense waves (age decides at equal priority; priority outranks age: MI355X_MICROARCH.md, "Two waves per SIMD").  The chain is
+    // latency-bound - every cycle its wave waits for an issue slot is a cycle of the step - while the tall kernel barely notices a 7-us kernel's instructions.
+    // cfg-2 step with the dead belief elided 44.27 -> 43.22 ms, as executed 48.99 -> 48.50 (two alternating pairs, tools/perf/ab_bench.sh).  No arithmetic changes.
+    AID_CHAIN_PRIO();
     gemm_mid_body<BMF, WM, WN, NJ, ACT, BKM>(g, tiles_m, tiles_n);
 }
 
@@ -606,9 +614,7 @@ __global__ void adaln_sum_kernel(const float* __restrict__ res, int ldres, const
                                  float* __restrict__ y, int ldy, int M) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     constexpr int D = 256 * NV;
-#ifdef AID_CHAIN_SETPRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    AID_CHAIN_PRIO();
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     const f4* sc = reinterpret_cast<const f4*>(mod + (size_t)row * ldmod);
@@ -696,6 +702,7 @@ __global__ void __launch_bounds__(256) head2_slab_p_sample_kernel(const float* _
                                                                   NextLp nx) {
     typedef float f4 __attribute__((ext_vector_type(4)));
     __shared__ float zs[4][128];                            // the new z rows of this block's four waves, for the optional next-step tail
+    AID_CHAIN_PRIO();
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, row = blockIdx.x * 4 + wv;
     const bool live = row < M;
     if (live) {

@@ -242,7 +242,7 @@ def lib() -> C.CDLL:
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
                  "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
-                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes"):
+                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes", "aid_module_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != ABI_VERSION:
@@ -686,6 +686,34 @@ def p_sample(z, score, coefs, step: int, eps=None):
     out = torch.empty_like(z)
     check(lib().aid_p_sample(_ptr(z), _ptr(score), _ptr(eps), _ptr(coefs), int(step), z.shape[0], z.shape[1], _ptr(out), _stream()), "aid_p_sample")
     return out
+
+
+# ---- sub-module forwards of LatentScoreNetwork (inference): SinusoidalPositionEmbeddings, AdaptiveLayerNorm, DiTBlock (models/score_networks.py:214-291)
+def sinusoid_embed(t, freq_scale, dim: int):
+    out = torch.empty(t.shape[0], dim, device=t.device)
+    if t.shape[0]:
+        check(lib().aid_sinusoid_embed(_ptr(t), _ptr(freq_scale), t.shape[0], int(dim), _ptr(out), _stream()), "aid_sinusoid_embed")
+    return out
+
+
+def adaptive_layer_norm(x, cond, mod_w, mod_b, ws: Workspace = None):
+    M, D = x.shape
+    y = torch.empty_like(x)
+    ws = ws or Workspace(x.device)
+    buf = ws.get(lib().aid_module_workspace(M, D))
+    check(lib().aid_adaptive_layer_norm(_ptr(x), _ptr(cond), _ptr(mod_w), _ptr(mod_b), M, D, _ptr(y), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()),
+                                        _stream()), "aid_adaptive_layer_norm")
+    return y
+
+
+def dit_block_forward(blk: "AidDiTBlock", x, cond, ws: Workspace = None):
+    M, D = x.shape
+    y = torch.empty_like(x)
+    ws = ws or Workspace(x.device)
+    buf = ws.get(lib().aid_module_workspace(M, D))
+    check(lib().aid_dit_block_forward(C.byref(blk), M, D, _ptr(x), _ptr(cond), _ptr(y), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_dit_block_forward")
+    return y
 
 
 # ---- A5: forward-process helpers of LatentDiffusionProcess (aid/core/diffusion.py:56-104, 146-174, 239-255), one launch each

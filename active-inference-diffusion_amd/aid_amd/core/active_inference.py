@@ -70,7 +70,15 @@ class FunctionSpaceEpistemicEstimator(nn.Module):
         self.mine_network = nn.Sequential(nn.Linear(spatial_aggregator_output_dim + 128, 512), nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 512),
                                           nn.ReLU(), nn.Dropout(0.1), nn.Linear(512, 1))
 
-    forward = native_only("FunctionSpaceEpistemicEstimator")
+    def forward(self, next_latent_mean: torch.Tensor, next_latent_logvar: torch.Tensor, num_samples: int = 5):
+        """active_inference.py:995-1063 as the reference's module call: `estimator(mean, logvar, num_samples)` -> (clamp(mi, 0) expanded to [B], metrics), the
+        running mean advanced.  Gradient-free here (the trainable form is `DiffusionActiveInference.train_epistemic_estimator` -> aid_mine_train_step): the
+        owning module's `compute_epistemic_value` runs it (aid_epistemic_value / aid_pixel_epistemic_value)."""
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError("FunctionSpaceEpistemicEstimator.forward needs the DiffusionActiveInference that owns it (its decoder / noise source / workspace)")
+        return owner.compute_epistemic_value(next_latent_mean, next_latent_logvar, num_samples)
 
 
 class EMAModel:
@@ -115,6 +123,9 @@ class DiffusionActiveInference(nn.Module):
         self.noise = noise or PhiloxNoise(seed=0xA1D)
         self.store_trajectory = False
         self._build_models()
+        if hasattr(self, "epistemic_estimator"):      # the estimator module is callable like the reference's: it evaluates through its owner (weak reference: no module cycle)
+            import weakref
+            self.epistemic_estimator.__dict__["_owner"] = weakref.ref(self)
         self._to_device_and_flatten(self.device)
         self.current_latent, self.latent_trajectory = None, []
         self._ws = nat.Workspace(self.device)

@@ -24,7 +24,9 @@ class SinusoidalPositionEmbeddings(nn.Module):
         self.dim = dim
         self.freq_scale = nn.Parameter(torch.ones(1))
 
-    forward = native_only("SinusoidalPositionEmbeddings")
+    def forward(self, time: torch.Tensor) -> torch.Tensor:
+        """[sin(t f_i) | cos(t f_i)], f_i = freq_scale 10000^(-i / (dim/2 - 1))  (score_networks.py:282-291); one HIP launch."""
+        return nat.sinusoid_embed(time.to(self.freq_scale.device).float().reshape(-1).contiguous(), self.freq_scale.data, self.dim)
 
 
 class AdaptiveLayerNorm(nn.Module):
@@ -37,7 +39,10 @@ class AdaptiveLayerNorm(nn.Module):
         nn.init.zeros_(self.adaLN_modulation[1].weight)
         nn.init.zeros_(self.adaLN_modulation[1].bias)
 
-    forward = native_only("AdaptiveLayerNorm")
+    def forward(self, x: torch.Tensor, conditioning: torch.Tensor) -> torch.Tensor:
+        """score_networks.py:257-270 as a stand-alone call (inference; inside the network the 13 modulations are one hoisted GEMM)."""
+        lin = self.adaLN_modulation[1]
+        return nat.adaptive_layer_norm(x.contiguous().float(), conditioning.contiguous().float(), lin.weight.data, lin.bias.data)
 
 
 class _SingleTokenAttention(nn.Module):
@@ -67,7 +72,15 @@ class DiTBlock(nn.Module):
             nn.init.xavier_uniform_(lin.weight)
             nn.init.zeros_(lin.bias)
 
-    forward = native_only("DiTBlock")
+    def forward(self, x: torch.Tensor, conditioning: torch.Tensor) -> torch.Tensor:
+        """score_networks.py:214-235 as a stand-alone call (inference): x + attn(adaLN1(x)) then + MLP(adaLN2(.)); single-token attention = out_proj(V_proj(.))."""
+        t = nat.AidDiTBlock()
+        for key, field in nat.BLOCK_KEYMAP.items():
+            mod = self
+            for part in key.split("."):
+                mod = getattr(mod, part) if not part.isdigit() else mod[int(part)]
+            setattr(t, field, nat._ptr(mod.data).value)
+        return nat.dit_block_forward(t, x.contiguous().float(), conditioning.contiguous().float())
 
 
 class LatentScoreNetwork(nn.Module):

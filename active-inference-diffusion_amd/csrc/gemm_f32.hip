@@ -1168,6 +1168,7 @@ static int dispatch(const GemmArgs& g, bool vec, hipStream_t s) {
         case 10: if (!AKM && !BKM && vec && g.K >= 4 && g.K <= 4096) return launch_skinny(g, s); break;
         case 9: if (vec) return launch_big<64, 64, 32, AKM, BKM, 2>(g, s); break;
         case 11: if (vec) return launch_big<64, 64, 32, AKM, BKM, 1>(g, s); break;
+        case 12: if (vec) return launch_big<128, 128, 32, AKM, BKM, 2>(g, s); break;
         case 14: if (p32_ok) return launch_panel128<AKM, BKM>(g, s); break;
         case 15: if (p32_ok) return launch_panel128<AKM, BKM, 64>(g, s); break;
         default: break;

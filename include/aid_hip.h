@@ -189,6 +189,17 @@ int aid_score_forward(const AidScoreNet* net, int B, const float* z_t, const flo
                       const float* obs, const float* drop_mask, float* score, void* ws, size_t ws_bytes,
                       void* stream);
 
+/* ---- Sub-module forwards of LatentScoreNetwork as stand-alone operations (inference; the training / sampling paths use the fused entry points above).
+ *   aid_sinusoid_embed        SinusoidalPositionEmbeddings.forward  aid/models/score_networks.py:282-291   out [M, dim] = [sin(t f_i) | cos(t f_i)]
+ *   aid_adaptive_layer_norm   AdaptiveLayerNorm.forward             :257-270   y = LN(x) (1 + scale) + shift, [scale | shift] = SiLU(cond) mod_w^T + mod_b
+ *   aid_dit_block_forward     DiTBlock.forward                      :214-235   (single-token attention = out_proj(V_proj(.)): rows 2D.. of in_proj)
+ * Workspace of the last two: aid_module_workspace(M, D). */
+int aid_sinusoid_embed(const float* t, const float* freq_scale, int M, int dim, float* out, void* stream);
+size_t aid_module_workspace(int M, int D);
+int aid_adaptive_layer_norm(const float* x, const float* cond, const float* mod_w, const float* mod_b, int M, int D, float* y, void* ws, size_t ws_bytes,
+                            void* stream);
+int aid_dit_block_forward(const AidDiTBlock* blk, int M, int D, const float* x, const float* cond, float* y, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- A2/A3/A4: reverse-diffusion loop (aid/core/diffusion.py:176-255) ------------------------
  * coefs: device [N,5] table (sqrt(1-acp), 1/sqrt(alpha), coef1, coef2, sqrt(post_var)).
  * z_init: [B,L] N(0,1) draw; step_noise: [N,B,L] (row t used at step t>0); drop_masks: [N,B,D]

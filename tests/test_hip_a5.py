@@ -129,3 +129,46 @@ def test_unconditional_score_forward_vs_oracle(golden_dir):
             np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-4, atol=1e-6)
     # conditioning matters: with an observation the score differs
     assert not torch.allclose(ai.latent_score_network(z, t, torch.zeros(BS, O, device="cuda")), ai.latent_score_network(z, t, None))
+
+
+def test_score_network_submodules_are_callable():
+    """SinusoidalPositionEmbeddings / AdaptiveLayerNorm / DiTBlock forwards (models/score_networks.py:214-291) and the estimator module call
+    (core/active_inference.py:995-1063) as stand-alone calls, against the oracle's restatements of the same lines."""
+    from oracle.weights import draw_params, param_specs
+    from test_hip_agent import _agent
+    O, A, D, N, B = 17, 6, 64, 4, 12
+    agent = _agent(O, A, D, N, 1, B)
+    ai = agent.active_inference
+    p = draw_params(param_specs(O, A, O, D, N), 31, orc.schedule_tables(N))
+    ai.load_state_dict({**ai.state_dict(), **p}, strict=True)
+    net = ai.latent_score_network
+    ns = NoiseStream(32)
+    x, cond, t = ns.randn(B, D), ns.randn(B, D), (ns.rand(B) * 40).astype(np.float32)
+    cu = lambda a: torch.from_numpy(a).cuda()
+    S = "latent_score_network."
+    # time embedding
+    emb = net.time_embed[0](cu(t))
+    ref = orc.sinusoidal(torch.from_numpy(t), p[S + "time_embed.0.freq_scale"], 128)
+    np.testing.assert_allclose(emb.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=2e-6)
+    # adaptive layer norm (block 2, norm1) and a whole DiT block
+    y = net.transformer_blocks[2].norm1(cu(x), cu(cond))
+    ref = orc._adaln(p, S + "transformer_blocks.2.norm1", torch.from_numpy(x), torch.from_numpy(cond))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-5)
+    yb = net.transformer_blocks[2](cu(x), cu(cond))
+    import torch.nn.functional as F
+    b = S + "transformer_blocks.2."
+    h, c = torch.from_numpy(x), torch.from_numpy(cond)
+    nx = orc._adaln(p, b + "norm1", h, c)
+    v = F.linear(nx, p[b + "attention.in_proj_weight"][2 * D:], p[b + "attention.in_proj_bias"][2 * D:])
+    h = h + orc._lin(p, b + "attention.out_proj", v)
+    nx = orc._adaln(p, b + "norm2", h, c)
+    h = h + orc._lin(p, b + "mlp.2", F.gelu(orc._lin(p, b + "mlp.0", nx)))
+    np.testing.assert_allclose(yb.cpu().numpy(), h.numpy(), rtol=1e-4, atol=2e-5)
+    # the estimator module called like the reference's: same value, metrics and running-mean update as compute_epistemic_value on the same draws
+    from aid_amd.noise import PhiloxNoise
+    mean, lv = torch.randn(B, O, device="cuda"), torch.full((B, O), float(np.log(0.1)), device="cuda")
+    ai.noise = PhiloxNoise(seed=3); ai._running_mean.zero_()
+    v1, m1 = ai.compute_epistemic_value(mean, lv, 5)
+    ai.noise = PhiloxNoise(seed=3); ai._running_mean.zero_()
+    v2, m2 = ai.epistemic_estimator(mean, lv, 5)
+    assert torch.equal(v1, v2) and m1 == m2 and v2.shape == (B,)

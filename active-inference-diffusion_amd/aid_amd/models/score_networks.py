@@ -18,6 +18,12 @@ from .. import _native as nat
 from ._holders import TableCache, native_only, params_dict
 
 
+def _need_gpu(name: str, *tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError(f"{name}.forward runs on the HIP library (module and inputs on the GPU); there is no CPU path")
+
+
 class SinusoidalPositionEmbeddings(nn.Module):
     def __init__(self, dim: int):
         super().__init__()
@@ -26,6 +32,7 @@ class SinusoidalPositionEmbeddings(nn.Module):
 
     def forward(self, time: torch.Tensor) -> torch.Tensor:
         """[sin(t f_i) | cos(t f_i)], f_i = freq_scale 10000^(-i / (dim/2 - 1))  (score_networks.py:282-291); one HIP launch."""
+        _need_gpu("SinusoidalPositionEmbeddings", self.freq_scale)
         return nat.sinusoid_embed(time.to(self.freq_scale.device).float().reshape(-1).contiguous(), self.freq_scale.data, self.dim)
 
 
@@ -42,6 +49,7 @@ class AdaptiveLayerNorm(nn.Module):
     def forward(self, x: torch.Tensor, conditioning: torch.Tensor) -> torch.Tensor:
         """score_networks.py:257-270 as a stand-alone call (inference; inside the network the 13 modulations are one hoisted GEMM)."""
         lin = self.adaLN_modulation[1]
+        _need_gpu("AdaptiveLayerNorm", lin.weight, x, conditioning)
         return nat.adaptive_layer_norm(x.contiguous().float(), conditioning.contiguous().float(), lin.weight.data, lin.bias.data)
 
 
@@ -74,6 +82,7 @@ class DiTBlock(nn.Module):
 
     def forward(self, x: torch.Tensor, conditioning: torch.Tensor) -> torch.Tensor:
         """score_networks.py:214-235 as a stand-alone call (inference): x + attn(adaLN1(x)) then + MLP(adaLN2(.)); single-token attention = out_proj(V_proj(.))."""
+        _need_gpu("DiTBlock", self.mlp[0].weight, x, conditioning)
         t = nat.AidDiTBlock()
         for key, field in nat.BLOCK_KEYMAP.items():
             mod = self

@@ -153,8 +153,12 @@ def kernel_name(variant, layout):
         return "gemm_group_tn_kernel"
     if variant == 31:
         return "conv3_igemm_kernel"
-    if variant == 32:
-        return "conv3_igemm_dw_kernel"
+    if variant == 32:      # layout = 4 + stride (+ 8: tap-major 64 x 64 tiles, + 16: tap-major 128 x 128 tiles)
+        return "conv3_igemm_dw_big_kernel" if layout & 16 else ("conv3_igemm_dw_tm_kernel" if layout & 8 else "conv3_igemm_dw_kernel")
+    if variant == 26:
+        return "gemm_w4_kernel"
+    if variant == 27:
+        return "gemm_w4ln_kernel"
 
     a, k = b((layout & 3) >> 1), b(layout & 1)
     return {1: f"gemm_panel_kernel<{a}, {k}>", 2: f"gemm_ring_kernel<64, 64, 128, {a}, {k}>", 3: "gemm_smallk_kernel",

@@ -47,8 +47,10 @@ def test_module_trees_reproduce_reference_state_dict_names():
     assert float(sn.output_proj[2].weight.abs().max()) == 0.0                       # zero-initialised head (score_networks.py:99)
     assert float(sn.norm_final.adaLN_modulation[1].weight.abs().max()) == 0.0        # identity modulation (:254-255)
     assert float(sn.output_multiplier) == pytest.approx(1e-3)
-    with pytest.raises(RuntimeError, match="parameter holder"):
+    with pytest.raises(RuntimeError, match="no CPU path"):          # callable since round 5 (aid_dit_block_forward) - on the GPU; a CPU module says so
         sn.transformer_blocks[0](torch.zeros(1, 64), torch.zeros(1, 64))
+    with pytest.raises(RuntimeError, match="parameter holder"):     # the attention holder inside it is still not a stand-alone module
+        sn.transformer_blocks[0].attention(torch.zeros(1, 1, 64))
 
 
 def test_param_arena_flattens_in_place_and_keeps_adaLN_contiguous():

@@ -716,6 +716,17 @@ def dit_block_forward(blk: "AidDiTBlock", x, cond, ws: Workspace = None):
     return y
 
 
+def spatial_attention_forward(x, conv_w, conv_b, temperature, ws: Workspace = None):
+    """SpatialAttention.forward on an NCHW tensor (visual_encoders.py:210-225)."""
+    B, Cc, H, W = x.shape
+    out = torch.empty_like(x)
+    ws = ws or Workspace(x.device)
+    buf = ws.get(4 * 3 * B * H * W + 4096)
+    check(lib().aid_spatial_attention_forward(_ptr(x), _ptr(conv_w), _ptr(conv_b), _ptr(temperature), B, Cc, H, W, _ptr(out), C.c_void_p(buf.data_ptr()),
+                                              C.c_size_t(buf.numel()), _stream()), "aid_spatial_attention_forward")
+    return out
+
+
 # ---- A5: forward-process helpers of LatentDiffusionProcess (aid/core/diffusion.py:56-104, 146-174, 239-255), one launch each
 def _steps_ptr(steps):
     assert steps.is_cuda and steps.dtype == torch.int64 and steps.is_contiguous(), "diffusion steps: contiguous CUDA int64 [B]"

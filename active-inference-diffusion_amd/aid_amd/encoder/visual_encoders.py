@@ -36,7 +36,13 @@ class SpatialAttention(nn.Module):
         for m in (self.channel_reduce, self.spatial_conv):
             nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
-    forward = native_only("SpatialAttention")
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x + x * sigmoid(conv7x7([mean_c x, max_c x]) / temperature) on an NCHW tensor (visual_encoders.py:210-225) as a stand-alone call; inside the encoder
+        the same arithmetic runs on the CNHW activation with its last step folded into LayerNorm(F)."""
+        if not (x.is_cuda and self.temperature.is_cuda):
+            raise RuntimeError("SpatialAttention.forward runs on the HIP library (module and input on the GPU); there is no CPU path")
+        return nat.spatial_attention_forward(x.contiguous().float(), self.spatial_conv.weight.data.reshape(-1).contiguous(), self.spatial_conv.bias.data,
+                                             self.temperature.data)
 
 
 class DrQV2Encoder(nn.Module):

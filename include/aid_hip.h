@@ -199,6 +199,10 @@ size_t aid_module_workspace(int M, int D);
 int aid_adaptive_layer_norm(const float* x, const float* cond, const float* mod_w, const float* mod_b, int M, int D, float* y, void* ws, size_t ws_bytes,
                             void* stream);
 int aid_dit_block_forward(const AidDiTBlock* blk, int M, int D, const float* x, const float* cond, float* y, void* ws, size_t ws_bytes, void* stream);
+/* SpatialAttention.forward (aid/encoder/visual_encoders.py:210-225) on an NCHW tensor: out = x + x sigmoid(conv7x7([mean_c x, max_c x]) / temperature).
+ * conv_w [2*7*7], conv_b [1], temperature [1] device pointers.  Workspace: 3 B H W floats (+ alignment). */
+int aid_spatial_attention_forward(const float* x, const float* conv_w, const float* conv_b, const float* temperature, int B, int C, int H, int W, float* out,
+                                  void* ws, size_t ws_bytes, void* stream);
 
 /* ---- A2/A3/A4: reverse-diffusion loop (aid/core/diffusion.py:176-255) ------------------------
  * coefs: device [N,5] table (sqrt(1-acp), 1/sqrt(alpha), coef1, coef2, sqrt(post_var)).

@@ -172,3 +172,18 @@ def test_score_network_submodules_are_callable():
     ai.noise = PhiloxNoise(seed=3); ai._running_mean.zero_()
     v2, m2 = ai.epistemic_estimator(mean, lv, 5)
     assert torch.equal(v1, v2) and m1 == m2 and v2.shape == (B,)
+
+
+def test_spatial_attention_module_is_callable():
+    """SpatialAttention.forward (encoder/visual_encoders.py:210-225) as a stand-alone call on an NCHW tensor against the oracle's restatement."""
+    from aid_amd.encoder.visual_encoders import SpatialAttention
+    from oracle.encoder_weights import draw_encoder_params, encoder_specs
+    p = draw_encoder_params(encoder_specs(32), 7)
+    sa = SpatialAttention(256).cuda()
+    sa.load_state_dict({k[len("attention."):]: v for k, v in p.items() if k.startswith("attention.")}, strict=True)
+    x = NoiseStream(8).randn(3, 256, 21, 21)
+    got = sa(torch.from_numpy(x).cuda())
+    ref = orc.spatial_attention(p, "attention.", torch.from_numpy(x))
+    np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        sa(torch.from_numpy(x))

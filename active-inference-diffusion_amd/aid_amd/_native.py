@@ -408,6 +408,20 @@ def gradient_penalty(table: AidScoreNet, z, t, obs, continuous: bool, drop_mask=
     return pen, g
 
 
+def score_backward(table: AidScoreNet, gtable: AidScoreNet, z, t, obs, d_score, continuous: bool, drop_mask=None, d_obs=None, ws: Workspace = None):
+    """Forward + reverse pass of the score network for the cotangent d_score: parameter gradients accumulated into `gtable`'s tensors.
+    -> (score [B,L], dz [B,L]); d_obs (optional [B,O]) accumulates dLoss/dobs."""
+    B = z.shape[0]
+    score = torch.empty(B, table.L, device=z.device, dtype=torch.float32)
+    dz = torch.empty_like(score)
+    ws = ws or Workspace(z.device)
+    buf = ws.get(lib().aid_elbo_step_workspace(C.byref(table), None, B))
+    check(lib().aid_score_backward(C.byref(table), C.byref(gtable), B, _ptr(z), _ptr(t), T_CONTINUOUS if continuous else T_DISCRETE, _ptr(obs), _ptr(drop_mask),
+                                   _ptr(d_score), _ptr(score), _ptr(dz), _ptr(d_obs), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_score_backward")
+    return score, dz
+
+
 def mse(a, b):
     """F.mse_loss over two [M,N] tensors -> device scalar"""
     a2, b2 = a.reshape(a.shape[0], -1), b.reshape(b.shape[0], -1)

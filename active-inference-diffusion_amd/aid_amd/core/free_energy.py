@@ -27,7 +27,12 @@ class FreeEnergyComputation(nn.Module):
         if prior_mean is None:
             prior_mean = torch.zeros_like(states)
         t = torch.full((B,), float(current_time), device=states.device)
-        score = score_network(states, t, observations, continuous=(0.0 <= current_time <= 1.0))
+        mask = None
+        if score_network.training:      # one dropout mask for the forward and (backward=True) the reverse pass
+            mask = torch.empty(B, score_network.hidden_dim, device=states.device)
+            nat.fill_dropout_mask(mask, 0.1, score_network.rng_seed, score_network.rng_offset)
+            score_network.rng_offset += (mask.numel() + 3) // 4
+        score = score_network(states, t, observations, continuous=(0.0 <= current_time <= 1.0), drop_mask=mask)
         sq = nat.rowwise_sqdist_means(states, prior_mean.contiguous().float(), observations, score)   # [3]: mean_b sum_l (.)^2
         complexity = 0.5 * sq[0] / (prior_std ** 2)
         accuracy = -0.5 * self.precision.to(sq.device) * sq[1]
@@ -36,15 +41,20 @@ class FreeEnergyComputation(nn.Module):
         info = {"complexity": complexity, "accuracy": -accuracy, "observation_error": sq[1], "score_regularization": score_reg,
                 "precision": self.precision}
         if backward:
-            # The reference returns an autograd scalar (free_energy.py:30-91); here there is no graph, so the gradients the closed form gives are
-            # produced explicitly: dF/d(log_precision) = 1/2 exp(log pi) mean|o - z|^2 is ACCUMULATED into log_precision.grad, and the direct
-            # parts of dF/d(states) (complexity + accuracy terms; the path through the score network's input is not included) and dF/d(score)
-            # are returned.  Gradients of the score-network PARAMETERS are not produced by this call (the reference never calls compute_loss).
+            # The reference returns an autograd scalar (free_energy.py:30-91); there is no graph here, so `backward=True` produces what F.backward() would:
+            # dF/d(log_precision) = 1/2 exp(log pi) mean|o - z|^2 accumulated into log_precision.grad; dF/d(score-network parameters) accumulated into the
+            # score network's .grad by its reverse pass (aid_score_backward, cotangent dF/dscore = 0.02 score / B); and dF/d(states), dF/d(observations)
+            # returned in `info` (direct terms + the paths through the score network's inputs).
             gp = (0.5 * self.precision.to(sq.device) * sq[1]).detach().to(self.log_precision.device).reshape(self.log_precision.shape)
             self.log_precision.grad = gp if self.log_precision.grad is None else self.log_precision.grad + gp
             pi = float(self.precision)
+            d_score = 0.02 * score / B
+            d_obs = (-pi * (states - observations) / B).contiguous()
+            _, dz = score_network.backward(states, t, observations, d_score, continuous=(0.0 <= current_time <= 1.0), drop_mask=mask, d_observation=d_obs)
             info["d_states_direct"] = ((states - prior_mean) / (prior_std ** 2) + pi * (states - observations)) / B
-            info["d_score"] = 0.02 * score / B
+            info["d_states"] = info["d_states_direct"] + dz
+            info["d_observations"] = d_obs
+            info["d_score"] = d_score
         return fe, info
 
     def update_precision(self, complexity: torch.Tensor, accuracy: torch.Tensor):

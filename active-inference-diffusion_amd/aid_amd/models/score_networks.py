@@ -151,3 +151,18 @@ class LatentScoreNetwork(nn.Module):
             nat.fill_dropout_mask(drop_mask, 0.1, self.rng_seed, self.rng_offset)
             self.rng_offset += (drop_mask.numel() + 3) // 4
         return nat.score_forward(self.table(), z_t, time, observation, continuous, drop_mask if self.training else None, self.workspace())
+
+    def backward(self, z_t: torch.Tensor, time: torch.Tensor, observation: torch.Tensor, d_score: torch.Tensor, continuous: Optional[bool] = None,
+                 drop_mask: Optional[torch.Tensor] = None, d_observation: Optional[torch.Tensor] = None):
+        """The network as a differentiable op (there is no autograd graph on this path): forward + reverse pass for the cotangent `d_score` = dLoss/dscore.
+        ACCUMULATES the parameter gradients into `.grad` of this module's Parameters (zero them first for a fresh gradient, as with autograd) and, when given,
+        dLoss/dobservation into `d_observation`.  -> (score, dLoss/dz_t).  Train mode draws / takes the obs encoder's dropout mask like forward()."""
+        z_t, time, observation, d_score = (x.contiguous().float() for x in (z_t, time, observation, d_score))
+        if continuous is None:
+            continuous = bool(time.max() <= 1.0 and time.min() >= 0.0)
+        if self.training and drop_mask is None:
+            drop_mask = torch.empty(z_t.shape[0], self.hidden_dim, device=z_t.device)
+            nat.fill_dropout_mask(drop_mask, 0.1, self.rng_seed, self.rng_offset)
+            self.rng_offset += (drop_mask.numel() + 3) // 4
+        return nat.score_backward(self.table(), self.grad_table(), z_t, time, observation, d_score, continuous, drop_mask if self.training else None,
+                                  d_observation, self.workspace())

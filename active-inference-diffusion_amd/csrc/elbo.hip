@@ -427,6 +427,39 @@ int aid_gradient_penalty(const AidScoreNet* net, int B, const float* z, const fl
     return gp_weights(gvec, wvec, penalty_out, B, L, s);
 }
 
+// LatentScoreNetwork as a differentiable op: forward (activations kept) + reverse pass for a caller-supplied cotangent d_score = dLoss/dscore.
+// Parameter gradients are ACCUMULATED into `grads` (every weight / bias gradient of the pass in one grouped launch, as in aid_elbo_step, whose main pass this is
+// without the loss in between); dz_out (optional) receives dLoss/dz, d_obs_out (optional) ACCUMULATES dLoss/dobs.  What `loss.backward()` does for a loss built
+// on `score_network(z, t, obs)` in the reference (models/score_networks.py:101-171 under autograd).  Workspace: aid_elbo_step_workspace(net, NULL, B).
+int aid_score_backward(const AidScoreNet* net, const AidScoreNet* grads, int B, const float* z, const float* t, int t_mode, const float* obs, const float* drop_mask,
+                       const float* d_score, float* score_out, float* dz_out, float* d_obs_out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_TRY(score_validate(net)); AID_TRY(score_validate(grads));
+    AID_REQUIRE(z && t && obs && d_score, AID_E_NULL, "aid_score_backward: null argument");
+    AID_REQUIRE(B > 0, AID_E_SHAPE, "aid_score_backward: B=%d", B);
+    AID_REQUIRE(t_mode == AID_T_CONTINUOUS || t_mode == AID_T_DISCRETE, AID_E_SHAPE, "aid_score_backward: t_mode=%d", t_mode);
+    hipStream_t s = (hipStream_t)stream;
+    const AidScoreNet& n = *net;
+    const int D = n.D, L = n.L, NA = 2 * n.n_blocks + 1, ldmod = NA * 2 * D;
+    Workspace ws(wsp, ws_bytes);
+    SplitScope split(ws, s);
+    float* score = score_out ? score_out : ws.f32((size_t)B * L);
+    float* dz = dz_out ? dz_out : ws.f32((size_t)B * L);
+    float* dmod = ws.f32((size_t)B * ldmod);
+    AID_WS_OK(ws);
+    ScoreActs am;
+    AID_TRY(score_acts_alloc(n, B, true, ws, am));
+    AID_TRY(score_time_embed(n, B, t, t_mode, am, s));
+    AID_TRY(score_obs_stage0(n, B, obs, am, s));
+    AID_TRY(score_cond(n, B, drop_mask, am.temb, D, am, s));
+    AID_TRY(score_trunk(n, B, z, am, true, s));
+    AID_TRY(score_head(am.raw, n.output_multiplier, t, t_mode, score, B, L, s));
+    GradQueue gq(s);
+    AID_TRY(score_reverse(n, grads, B, am, nullptr, z, nullptr, d_score, t, t_mode, 0.f, dz, dmod, ws, s, &gq));
+    AID_TRY(score_cond_backward(n, *grads, B, am, dmod, obs, drop_mask, t, t_mode, ws, s, d_obs_out, &gq));
+    AID_TRY(gq.flush());
+    return AID_OK;
+}
+
 int aid_sample_time(const float* time_importance, int first_call, int B, uint64_t seed, uint64_t offset, float* t_out, void* wsp,
                     size_t ws_bytes, void* stream) {
     AID_REQUIRE(time_importance && t_out, AID_E_NULL, "aid_sample_time: null argument");

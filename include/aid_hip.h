@@ -339,6 +339,14 @@ size_t aid_elbo_step_workspace(const AidScoreNet* net, const AidDecoderNet* dec,
 int aid_gradient_penalty(const AidScoreNet* net, int B, const float* z, const float* t, int t_mode, const float* obs, const float* drop_mask,
                          float* penalty_out, float* grad_out, void* ws, size_t ws_bytes, void* stream);
 
+/* LatentScoreNetwork as a differentiable op (what `loss.backward()` does for a loss built on score_network(z, t, obs): aid/models/score_networks.py:101-171 under
+ * autograd): forward with the activations kept, then the reverse pass for the cotangent d_score [B,L] = dLoss/dscore.  Parameter gradients are ACCUMULATED into
+ * `grads` (same table type; zero it first for a fresh gradient); score_out (optional) [B,L] = the forward value; dz_out (optional) [B,L] = dLoss/dz;
+ * d_obs_out (optional) [B,O] ACCUMULATES dLoss/dobs.  drop_mask: [B,D] scaled keep mask of the obs encoder's Dropout(0.1) or NULL (eval).
+ * Workspace: aid_elbo_step_workspace(net, NULL, B). */
+int aid_score_backward(const AidScoreNet* net, const AidScoreNet* grads, int B, const float* z, const float* t, int t_mode, const float* obs, const float* drop_mask,
+                       const float* d_score, float* score_out, float* dz_out, float* d_obs_out, void* ws, size_t ws_bytes, void* stream);
+
 /* F.mse_loss(a, b) over [M,N] row-major operands with leading dimensions lda / ldb -> out (device scalar): the reconstruction
  * diagnostic of update_belief_via_diffusion's pixel branch (aid/core/active_inference.py:292-299). */
 int aid_mse(const float* a, int lda, const float* b, int ldb, int M, int N, float* out, void* stream);

@@ -187,3 +187,42 @@ def test_spatial_attention_module_is_callable():
     np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=1e-5, atol=1e-6)
     with pytest.raises(RuntimeError, match="no CPU path"):
         sa(torch.from_numpy(x))
+
+
+@pytest.mark.parametrize("cont,train", [(True, False), (False, False), (True, True)])
+def test_score_network_backward_vs_oracle_autograd(cont, train):
+    """LatentScoreNetwork.backward (aid_score_backward): the network as a differentiable op - parameter gradients, dLoss/dz and dLoss/dobs for a random
+    cotangent on the score - against the oracle's autograd through its restatement of models/score_networks.py:101-171 (continuous and discrete time, eval and
+    train mode with an explicit dropout mask)."""
+    from oracle.weights import draw_params, param_specs
+    from aid_amd.models import LatentScoreNetwork
+    O, A, D, N, B = 17, 6, 64, 4, 24
+    p = draw_params(param_specs(O, A, O, D, N), 91, orc.schedule_tables(N))
+    pre = "latent_score_network."
+    net = LatentScoreNetwork(latent_dim=O, observation_dim=O, hidden_dim=D).cuda()
+    net.load_state_dict({k[len(pre):]: v for k, v in p.items() if k.startswith(pre)}, strict=True)
+    net.train(train)
+    ns = NoiseStream(92)
+    z, obs, cot = ns.randn(B, O), ns.randn(B, O), ns.randn(B, O)
+    t = ns.rand(B) if cont else np.full(B, 3.0, np.float32)
+    mask = NoiseStream(93).dropout_mask((B, D), 0.1) if train else None
+    cu = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_obs = torch.zeros(B, O, device="cuda")
+    score, dz = net.backward(cu(z), cu(t), cu(obs), cu(cot), drop_mask=cu(mask) if train else None, d_observation=d_obs)
+    pg = {k: v.clone().requires_grad_(k.startswith(pre) and orc.is_param(k) and v.dtype.is_floating_point) for k, v in p.items()}
+    zt, ot = torch.from_numpy(z).requires_grad_(True), torch.from_numpy(obs).requires_grad_(True)
+    ref = orc.score_forward(pg, zt, torch.from_numpy(t), ot, NoiseStream(93), train)
+    names = [k for k in pg if pg[k].requires_grad]
+    grads = torch.autograd.grad((ref * torch.from_numpy(cot)).sum(), [zt, ot] + [pg[k] for k in names], allow_unused=True)
+    np.testing.assert_allclose(score.cpu().numpy(), ref.detach().numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(dz.cpu().numpy(), grads[0].numpy(), rtol=1e-3, atol=1e-6)
+    np.testing.assert_allclose(d_obs.cpu().numpy(), grads[1].numpy(), rtol=1e-3, atol=1e-6)
+    got = {pre + n_: q.grad for n_, q in net.named_parameters()}
+    checked = 0
+    for k, r in zip(names, grads[2:]):
+        if r is None or float(r.abs().max()) == 0.0:
+            assert got[k] is None or float(got[k].abs().max()) == 0.0, k          # Q / K projections: exactly-zero gradients, as in the reference
+            continue
+        assert float((got[k].cpu() - r).norm() / r.norm()) < 1e-3, k
+        checked += 1
+    assert checked > 40, checked

@@ -54,7 +54,27 @@ def test_free_energy_compute_loss_golden(golden_dir, tag):
     np.testing.assert_allclose(info2["d_states_direct"].cpu().numpy(), g_z.numpy(), rtol=1e-5, atol=1e-7)
     s_ref = orc.score_forward(p, torch.from_numpy(g["z"]), torch.full((z.shape[0],), 0.5), torch.from_numpy(g["obs"]))
     np.testing.assert_allclose(info2["d_score"].cpu().numpy(), (0.02 * s_ref / z.shape[0]).numpy(), rtol=1e-3, atol=1e-9)
-    fe.compute_loss(z, obs, None, net, current_time=0.5, backward=True)                       # accumulates, like autograd's .grad
+    # ... and, through the score network's reverse pass, the FULL gradient: dF/d(states), dF/d(observations) and every score-network parameter
+    pg = {k: v.clone().requires_grad_(k.startswith(pre) and orc.is_param(k) and v.dtype.is_floating_point) for k, v in p.items()}
+    zt2 = torch.from_numpy(g["z"]).clone().requires_grad_(True); ot2 = torch.from_numpy(g["obs"]).clone().requires_grad_(True)
+    ref3, _ = orc.free_energy_loss(pg, zt2, ot2, torch.zeros(()), 0.5)
+    names = [k for k in pg if pg[k].requires_grad]
+    grads = torch.autograd.grad(ref3, [zt2, ot2] + [pg[k] for k in names], allow_unused=True)
+    np.testing.assert_allclose(info2["d_states"].cpu().numpy(), grads[0].numpy(), rtol=1e-3, atol=1e-7)
+    np.testing.assert_allclose(info2["d_observations"].cpu().numpy(), grads[1].numpy(), rtol=1e-3, atol=1e-7)
+    got = {pre + n_: q.grad for n_, q in net.named_parameters()}
+    checked = 0
+    for k, r in zip(names, grads[2:]):
+        if r is None or float(r.abs().max()) == 0.0:
+            continue
+        err = float((got[k].cpu() - r).norm() / r.norm())
+        assert err < 1e-3, (k, err)
+        checked += 1
+    assert checked > 40, checked
+    for q in net.parameters():
+        q.grad = None
+    fe.log_precision.grad = None
+    fe.compute_loss(z, obs, None, net, current_time=0.5, backward=True); fe.compute_loss(z, obs, None, net, current_time=0.5, backward=True)      # accumulates, like autograd's .grad
     np.testing.assert_allclose(float(fe.log_precision.grad), 2 * float(g_lp), rtol=1e-4)
     # update_precision (:93-101): log-precision nudged by 0.01 * clamp(err, -1, 1), clamped to [-3, 3]
     fe.update_precision(torch.tensor(5.0), torch.tensor(1.0)); np.testing.assert_allclose(float(fe.log_precision), 0.01, rtol=1e-6)

@@ -242,7 +242,8 @@ def lib() -> C.CDLL:
     for name in ("aid_score_forward_workspace", "aid_denoise_loop_workspace", "aid_decode_workspace", "aid_belief_update_workspace",
                  "aid_elbo_step_workspace", "aid_efe_step_workspace", "aid_value_step_workspace", "aid_dynamics_step_workspace",
                  "aid_small_net_workspace", "aid_encoder_saved_bytes", "aid_encoder_workspace", "aid_mine_train_workspace",
-                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes", "aid_module_workspace"):
+                 "aid_conv_decoder_workspace", "aid_pixel_epistemic_workspace", "aid_epistemic_value_workspace", "aid_gemm_scratch_bytes", "aid_module_workspace", "aid_jacobian_features_workspace", "aid_decoder_block_workspace",
+                 "aid_pixel_jacobian_features_workspace"):
         getattr(L, name).restype = C.c_size_t
     _lib = L
     if L.aid_version() != ABI_VERSION:
@@ -1018,6 +1019,26 @@ def mine_train_step(dyn: AidDynamicsNet, dec: AidDecoderNet, epi: AidEpistemicNe
     return out
 
 
+def jacobian_features(dec, epi, z, delta=None, proj_mask=None, train=False, seed=0, offset=0, attn_mask=None, ws: Workspace = None):
+    """compute_jacobian_features (active_inference.py:940-993): z [R, L] -> [R, jp4.out].  `dec` / `epi` are the state-mode tables (AidDecoderNet,
+    AidEpistemicNet) or the pixel-mode ones (AidConvDecoder, AidPixelEpistemicNet); delta [4, R, L] standard-normal directions (None => device Philox)."""
+    z = z.contiguous().float(); R = z.shape[0]
+    out = torch.empty(R, epi.jp4.out, device=z.device, dtype=torch.float32)
+    if R == 0:
+        return out
+    ws = ws or Workspace(z.device)
+    if isinstance(epi, AidPixelEpistemicNet):
+        buf = ws.get(lib().aid_pixel_jacobian_features_workspace(C.byref(dec), R))
+        check(lib().aid_pixel_jacobian_features(C.byref(dec), C.byref(epi), R, _ptr(z), _ptr(delta), _ptr(proj_mask), _ptr(attn_mask), int(bool(train)),
+                                                C.c_uint64(seed), C.c_uint64(offset), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+              "aid_pixel_jacobian_features")
+    else:
+        buf = ws.get(lib().aid_jacobian_features_workspace(C.byref(dec), R))
+        check(lib().aid_jacobian_features(C.byref(dec), C.byref(epi), R, _ptr(z), _ptr(delta), _ptr(proj_mask), int(bool(train)), C.c_uint64(seed),
+                                          C.c_uint64(offset), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()), "aid_jacobian_features")
+    return out
+
+
 def epistemic_value(dec: AidDecoderNet, epi: AidEpistemicNet, next_mean, next_logvar, running_mean, num_samples=5, noise=None, train=True,
                     seed=0, offset=0, alpha=0.01, ws: Workspace = None):
     """compute_epistemic_value: one gradient-free estimator forward. -> out [4] = mi, joint, marginal term, -clamp(mi, 0)"""
@@ -1068,6 +1089,30 @@ def conv_decoder_table(params, prefix: str = "observation_decoder.") -> AidConvD
     for i in (0, 3, 6):
         setattr(t, f"out{i}_w", g(f"output_proj.{i}.weight")); setattr(t, f"out{i}_b", g(f"output_proj.{i}.bias"))
     return t
+
+
+def decoder_block_forward(block, x, ws: Workspace = None):
+    """DecoderBlock.forward (eval): x [R, cin, h, h] -> [R, cout, ho, ho].  `block`: the aid_amd.encoder DecoderBlock holder (main_path / residual_path convs)."""
+    R, cin, h, w = x.shape
+    assert h == w and cin == block.in_channels, (x.shape, block.in_channels)
+    up, cout = bool(block.upsample), block.out_channels
+
+    def sn(m):
+        c = AidSNConv(); c.w, c.u, c.v, c.bias = (_ptr(t.data).value for t in (m.weight_orig, m.weight_u, m.weight_v, m.bias))
+        return c
+    b = AidDecoderBlock()
+    b.main0 = sn(block.main_path[0]); b.main1 = sn(block.main_path[5 if up else 4])
+    if not isinstance(block.residual_path, torch.nn.Identity):
+        b.res = sn(block.residual_path[0])
+    ho = 2 * h if up else h
+    out = torch.empty(R, cout, ho, ho, device=x.device, dtype=torch.float32)
+    if R == 0:
+        return out
+    ws = ws or Workspace(x.device)
+    buf = ws.get(lib().aid_decoder_block_workspace(cin, cout, int(up), R, h))
+    check(lib().aid_decoder_block_forward(C.byref(b), cin, cout, int(up), R, h, _ptr(x), _ptr(out), C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel()), _stream()),
+          "aid_decoder_block_forward")
+    return out
 
 
 def conv_decoder_forward(dec: AidConvDecoder, z, chunk: int = 16, ws: Workspace = None):

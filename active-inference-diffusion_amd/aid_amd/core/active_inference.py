@@ -80,6 +80,24 @@ class FunctionSpaceEpistemicEstimator(nn.Module):
             raise RuntimeError("FunctionSpaceEpistemicEstimator.forward needs the DiffusionActiveInference that owns it (its decoder / noise source / workspace)")
         return owner.compute_epistemic_value(next_latent_mean, next_latent_logvar, num_samples)
 
+    def compute_jacobian_features(self, z: torch.Tensor, delta: Optional[torch.Tensor] = None, proj_mask: Optional[torch.Tensor] = None,
+                                  attn_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """active_inference.py:940-993: finite-difference function-space features of the decoder at z [R, L] along `ntk_samples` = 4 random unit directions,
+        through the feature extractor (state) or pixel processor + spatial aggregator (pixels) and the jacobian projector -> [R, 256]
+        (aid_jacobian_features / aid_pixel_jacobian_features).  `delta` [4, R, L]: the standard-normal draws behind the directions (None: device Philox);
+        `proj_mask` / `attn_mask`: explicit dropout masks in train mode (None: drawn)."""
+        owner = self.__dict__.get("_owner")
+        owner = owner() if owner is not None else None
+        if owner is None:
+            raise RuntimeError("FunctionSpaceEpistemicEstimator.compute_jacobian_features needs the DiffusionActiveInference that owns it")
+        z = z.to(owner.device).contiguous().float()
+        if self.is_pixel:
+            dec, epi = owner.observation_decoder._tab.get(owner.observation_decoder), owner._pepi_tab.get(self)
+        else:
+            dec, epi = owner.decoder_table(), owner.epistemic_table()
+        return nat.jacobian_features(dec, epi, z, delta=delta, proj_mask=proj_mask, attn_mask=attn_mask, train=self.training, seed=owner.noise.seed,
+                                     offset=owner.noise.next_offset(), ws=owner._ws)
+
 
 class EMAModel:
     """Exponential moving average of the score-network weights (active_inference.py:779-813).  The average itself is

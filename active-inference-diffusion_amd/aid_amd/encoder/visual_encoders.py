@@ -163,8 +163,17 @@ class DecoderBlock(nn.Module):
             self.residual_path = nn.Sequential(_SNConvBias(in_channels, out_channels * 4 if upsample else out_channels, 1), noop(), noop())
         else:
             self.residual_path = nn.Identity()
+        self.in_channels, self.out_channels = in_channels, out_channels
 
-    forward = native_only("DecoderBlock")
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """visual_encoders.py:455-459 in eval mode as a stand-alone call (aid_decoder_block_forward): x [R, cin, h, h] -> [R, cout, h or 2h, ...].  Inside
+        ConvDecoder.forward the same kernels run on the CNHW activations without the layout changes.  Train mode (Dropout2d, spectral-norm power iteration)
+        is not built: the reference never trains this decoder and the estimator runs it in eval mode."""
+        if self.training:
+            raise NotImplementedError("DecoderBlock.forward is built for eval mode (the only mode the reference runs the ConvDecoder in)")
+        if not (x.is_cuda and self.main_path[0].bias.is_cuda):
+            raise RuntimeError("DecoderBlock.forward runs on the HIP library (module and input on the GPU); there is no CPU path")
+        return nat.decoder_block_forward(self, x.contiguous().float())
 
 
 class ConvDecoder(nn.Module):

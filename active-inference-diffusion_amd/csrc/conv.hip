@@ -1172,6 +1172,61 @@ int aid_conv_decoder_forward(const AidConvDecoder* dec, int R, const float* z, f
 }  // extern "C"
 
 namespace aid {
+// a[r][c][p] <-> b[c][r][p]  (NCHW <-> the conv stack's CNHW); to_cnhw: out = CNHW image of an NCHW input, else the reverse
+__global__ void nchw_cnhw_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int R, int HW, int to_cnhw) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)C * R * HW) return;
+    const int p = i % HW, r = (i / HW) % R, c = i / ((size_t)HW * R);          // i indexes the CNHW image
+    const size_t j = ((size_t)r * C + c) * HW + p;
+    if (to_cnhw) out[i] = in[j]; else out[j] = in[i];
+}
+}  // namespace aid
+
+extern "C" {
+// DecoderBlock.forward, eval mode (encoder/visual_encoders.py:370-459): main = IN(conv3x3_sn(Mish(IN(PixelShuffle?(conv3x3_sn(x)))))) (Dropout2d: identity in
+// eval), residual = identity | IN(conv1x1_sn(x)) | IN(PixelShuffle(conv1x1_sn(x))), out = Mish(main + residual).  x [R][cin][h][h] -> out [R][cout][ho][ho],
+// ho = 2 h when upsampling.  The spectral-norm weights are W / (u . W v) of the stored u, v (no power iteration in eval mode).
+size_t aid_decoder_block_workspace(int cin, int cout, int upsample, int R, int h) {
+    if (cin <= 0 || cout <= 0 || R <= 0 || h <= 0) return 0;
+    const size_t ho = upsample ? 2 * (size_t)h : h, c0 = upsample ? 4 * (size_t)cout : cout;
+    auto img = [](size_t ci, size_t co, size_t k) { return co * ((ci * k * k + 31) / 32 * 32) + co + 128; };
+    size_t n = img(cin, c0, 3) + img(cout, cout, 3) + img(cin, c0, 1);
+    n += (size_t)R * ((size_t)cin * h * h + 5 * (size_t)cout * ho * ho + 2 * c0 * h * h);
+    return sizeof(float) * n + (1 << 20);
+}
+int aid_decoder_block_forward(const AidDecoderBlock* blk, int cin, int cout, int upsample, int R, int h, const float* x, float* out, void* wsp, size_t ws_bytes,
+                              void* stream) {
+    AID_REQUIRE(blk && x && out && blk->main0.w && blk->main1.w, AID_E_NULL, "aid_decoder_block_forward: null argument");
+    AID_REQUIRE(cin > 0 && cout > 0 && R > 0 && h >= 4 && h <= 168 && (size_t)R * cin * h * h < ((size_t)1 << 30) && (size_t)R * cout * 4 * h * h < ((size_t)1 << 30),
+                AID_E_SHAPE, "aid_decoder_block_forward: cin=%d cout=%d R=%d h=%d", cin, cout, R, h);
+    AID_REQUIRE(blk->res.w || (cin == cout && !upsample), AID_E_SHAPE, "aid_decoder_block_forward: a block that changes channels or upsamples needs its residual conv");
+    hipStream_t s = (hipStream_t)stream;
+    Workspace ws(wsp, ws_bytes);
+    const int up = upsample ? 1 : 0, ho = up ? 2 * h : h, c0 = up ? 4 * cout : cout;
+    ConvW m0, m1, rs;
+    AID_TRY(prep_weight(blk->main0, cin, c0, 3, ws, m0, s));
+    AID_TRY(prep_weight(blk->main1, cout, cout, 3, ws, m1, s));
+    if (blk->res.w) AID_TRY(prep_weight(blk->res, cin, c0, 1, ws, rs, s));
+    const size_t n_in = (size_t)R * cin * h * h, n_out = (size_t)R * cout * ho * ho, n_c0 = (size_t)R * c0 * h * h;
+    float* xc = ws.f32(n_in); float* cv = ws.f32(n_c0 > n_out ? n_c0 : n_out); float* y = ws.f32(n_out); float* cr = ws.f32(n_c0); float* rn = ws.f32(n_out); float* yc = ws.f32(n_out);
+    AID_WS_OK(ws);
+    L1D(nchw_cnhw_kernel, n_in, s, x, xc, cin, R, h * h, 1);
+    AID_TRY(conv3_fwd(m0, xc, R, h, cv, s));
+    AID_TRY(instnorm(cv, blk->main0.bias, (const float*)nullptr, y, cout, R, ho, ho, up, ACT_MISH, s));
+    AID_TRY(conv3_fwd(m1, y, R, ho, cv, s));
+    const float* resid = xc;
+    if (blk->res.w) {
+        AID_TRY(conv1_fwd(rs, xc, R, h, cr, s));
+        AID_TRY(instnorm(cr, blk->res.bias, (const float*)nullptr, rn, cout, R, ho, ho, up, ACT_NONE, s));
+        resid = rn;
+    }
+    AID_TRY(instnorm(cv, blk->main1.bias, resid, yc, cout, R, ho, ho, 0, ACT_MISH, s));
+    L1D(nchw_cnhw_kernel, n_out, s, yc, out, cout, R, ho * ho, 0);
+    return AID_OK;
+}
+}  // extern "C"
+
+namespace aid {
 // The decoder in three parts, so that a caller decoding many latents (the pixel estimator: z and four perturbed copies of every row, 16 images at a
 // time) prepares the spectral-norm weight images ONCE and streams latent_proj's 1.85 GB second Linear ONCE per <= 640 rows as an MFMA GEMM, instead of
 // once per 16-image decode through the weight-streaming skinny kernel (40 x 0.64 ms per 128 rows).

@@ -197,6 +197,30 @@ __global__ void randperm_blocks_kernel(const float* __restrict__ keys, int32_t* 
 
 // ---- MINE forward for one horizon step, all K trajectories: fills mine_out [K][4]
 struct PixelBackend { const AidConvDecoder* dec; const AidPixelEpistemicNet* epi; const float* attn_mask; uint64_t seed, offset; };
+// compute_jacobian_features (active_inference.py:940-993) for Rm rows: finite differences of the decoder along 4 given directions -> feature extractor (state) or
+// 5x5 convs + attention aggregator (pixels) -> jacobian_projector.  z_all holds the rows in [0, Rm) and (state branch) room for their 4 Rm perturbed copies behind
+// them; fz / f0 / f1 / jin / pj are the caller's scratch; out [Rm][ldout] gets jacobian_projector's jp4.out columns.
+static int jacobian_block(const AidDecoderNet& dec, const AidEpistemicNet& e, int Rm, float* z_all, float* fz, float* f0, float* f1, float* jin, const float* delta,
+                          const float* proj_mask, bool train, LlaSave& pj, float* out, int ldout, Workspace& ws, hipStream_t s, const PixelBackend* px) {
+    const size_t R = (size_t)Rm; const int L = e.L, O = px ? 1 : e.O, FE = e.fe4.out;
+    if (px) {   // pixel branch: ConvDecoder finite differences -> 5x5 convs -> attention aggregator (conv.hip)
+        AID_TRY(pixel_jacobian_features(*px->dec, *px->epi, Rm, z_all, delta, px->attn_mask, train, px->seed, px->offset, jin, ws, s));
+    } else {
+        AID_REQUIRE(5 * R < (size_t)1 << 30, AID_E_SHAPE, "mine_forward: %zu sample rows", R);
+        float* zp4 = z_all + R * L; float* fp4 = fz + R * O;
+        LAUNCH1D(perturb4_kernel, 4 * R, s, z_all, delta, e.perturbation_scale, zp4, R, L);
+        AID_TRY(decoder_fwd(dec, (int)(5 * R), z_all, L, nullptr, fz, O, ws, s));       // decoder in eval mode (:949)
+        LAUNCH1D(fd4_kernel, 4 * R * O, s, fp4, fz, e.perturbation_scale, R, O);
+        const int R4 = (int)(4 * R);
+        AID_TRY(linear_fwd(fp4, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, R4, e.fe0.out, O, ACT_RELU, s));
+        AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, R4, e.fe2.out, e.fe0.out, ACT_RELU, s));
+        AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin, FE, R4, FE, e.fe2.out, ACT_NONE, s));   // row 4 r + j of [4R, FE] == columns j FE.. of row r of [R, 4 FE]
+    }
+    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s, nullptr, false));   // gradient-free: nothing saved
+    AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, out, ldout, Rm, e.jp4.out, e.jp0.out, ACT_NONE, s));
+    return AID_OK;
+}
+
 static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int K, int S, int B, const float* next_mean,
                         const float* z_eps, const float* delta, const float* proj_mask, const float* mine_mask, const int32_t* perms,
                         bool train, float* mine_out, Workspace& ws, hipStream_t s, const PixelBackend* px = nullptr,
@@ -221,21 +245,7 @@ static int mine_forward(const AidDecoderNet& dec, const AidEpistemicNet& e, int 
     LAUNCH1D(mine_sample_kernel, R * L, s, next_mean, z_eps, expf(0.5f * logf(0.1f)), next_logvar, z_all, K, S, B, L);
     (void)sd;
     const int FE = e.fe4.out, CW = e.jp4.out + e.lp2.out;
-    if (px) {   // pixel branch: ConvDecoder finite differences -> 5x5 convs -> attention aggregator (conv.hip)
-        AID_TRY(pixel_jacobian_features(*px->dec, *px->epi, Rm, z_all, delta, px->attn_mask, train, px->seed, px->offset, jin, ws, s));
-    } else {
-        AID_REQUIRE(5 * R < (size_t)1 << 30, AID_E_SHAPE, "mine_forward: %zu sample rows", R);
-        float* zp4 = z_all + R * L; float* fp4 = fz + R * O;
-        LAUNCH1D(perturb4_kernel, 4 * R, s, z_all, delta, e.perturbation_scale, zp4, R, L);
-        AID_TRY(decoder_fwd(dec, (int)(5 * R), z_all, L, nullptr, fz, O, ws, s));       // decoder in eval mode (:949)
-        LAUNCH1D(fd4_kernel, 4 * R * O, s, fp4, fz, e.perturbation_scale, R, O);
-        const int R4 = (int)(4 * R);
-        AID_TRY(linear_fwd(fp4, O, e.fe0.w, e.fe0.b, f0, e.fe0.out, R4, e.fe0.out, O, ACT_RELU, s));
-        AID_TRY(linear_fwd(f0, e.fe0.out, e.fe2.w, e.fe2.b, f1, e.fe2.out, R4, e.fe2.out, e.fe0.out, ACT_RELU, s));
-        AID_TRY(linear_fwd(f1, e.fe2.out, e.fe4.w, e.fe4.b, jin, FE, R4, FE, e.fe2.out, ACT_NONE, s));   // row 4 r + j of [4R, FE] == columns j FE.. of row r of [R, 4 FE]
-    }
-    AID_TRY(lla_fwd(e.jp0, e.jp_ln, ACT_RELU, train ? proj_mask : nullptr, jin, 4 * FE, Rm, pj, s, nullptr, false));   // gradient-free: nothing saved
-    AID_TRY(linear_fwd(pj.y, e.jp0.out, e.jp4.w, e.jp4.b, comb, CW, Rm, e.jp4.out, e.jp0.out, ACT_NONE, s));
+    AID_TRY(jacobian_block(dec, e, Rm, z_all, fz, f0, f1, jin, delta, proj_mask, train, pj, comb, CW, ws, s, px));
     AID_TRY(linear_fwd(z_all, L, e.lp0.w, e.lp0.b, l0, e.lp0.out, Rm, e.lp0.out, L, ACT_RELU, s));
     AID_TRY(linear_fwd(l0, e.lp0.out, e.lp2.w, e.lp2.b, comb + e.jp4.out, CW, Rm, e.lp2.out, e.lp0.out, ACT_NONE, s));
     const size_t MSZ = R * e.mn0.out;
@@ -625,6 +635,62 @@ int aid_epistemic_value(const AidDecoderNet* dec, const AidEpistemicNet* epi, in
     hipLaunchKernelGGL(mine_train_finish_kernel, dim3(1), dim3(64), 0, s, red, alpha, running_mean, out4);
     AID_LAUNCH_CHECK();
     return AID_OK;
+}
+
+size_t aid_pixel_epistemic_workspace(const AidConvDecoder* dec, int K, int S, int B);
+// FunctionSpaceEpistemicEstimator.compute_jacobian_features (active_inference.py:940-993) as a call of its own: z [R][L] -> out [R][jp4.out].
+// delta [4][R][L]: the four standard-normal perturbation directions (normalised and scaled inside, F.normalize(randn) * epsilon :962; null => drawn from
+// (seed, offset));
+// proj_mask [R][jp0.out]: jacobian_projector's dropout mask in train mode (null => drawn).  State branch: `dec` is the observation decoder; pixel branch
+// (aid_pixel_jacobian_features): the ConvDecoder + the estimator's pixel processor and spatial aggregator.
+size_t aid_jacobian_features_workspace(const AidDecoderNet* dec, int R) {
+    if (!dec || R <= 0) return 0;
+    return mine_ws_bytes(*dec, 1, 1, R) + sizeof(float) * (size_t)R * (size_t)(5 * dec->L + 512) + (1 << 20);
+}
+static int jacobian_entry(const AidDecoderNet& dec, const AidEpistemicNet& e, int R, const float* z, const float* delta, const float* proj_mask, int train,
+                          uint64_t seed, uint64_t offset, float* out, Workspace& ws, hipStream_t s, const PixelBackend* px) {
+    const int L = e.L, O = px ? 1 : e.O;
+    const size_t Rz = (size_t)R, RB = px ? Rz : 5 * Rz;
+    uint64_t ctr = offset;
+    if (!delta) {
+        float* d = ws.f32(4 * Rz * L); AID_WS_OK(ws);
+        AID_TRY(philox_fill(d, 4 * Rz * L, 0, 0.f, seed, ctr, s)); ctr += (4 * Rz * L + 3) / 4;
+        delta = d;
+    }
+    if (train && !proj_mask) {
+        float* m = ws.f32(Rz * e.jp0.out); AID_WS_OK(ws);
+        AID_TRY(philox_fill(m, Rz * e.jp0.out, 2, 0.1f, seed, ctr, s)); ctr += (Rz * e.jp0.out + 3) / 4;
+        proj_mask = m;
+    }
+    float* z_all = ws.f32(RB * L); float* fz = px ? nullptr : ws.f32(RB * O);
+    float* f0 = px ? nullptr : ws.f32(4 * Rz * e.fe0.out); float* f1 = px ? nullptr : ws.f32(4 * Rz * e.fe2.out);
+    float* jin = ws.f32(Rz * 4 * e.fe4.out);
+    LlaSave pj; lla_alloc(R, e.jp0.out, ws, pj);
+    AID_WS_OK(ws);
+    AID_CHECK_HIP(hipMemcpyAsync(z_all, z, sizeof(float) * Rz * L, hipMemcpyDeviceToDevice, s));
+    PixelBackend pxl; if (px) { pxl = *px; pxl.offset = ctr + (1ull << 36); }
+    return jacobian_block(dec, e, R, z_all, fz, f0, f1, jin, delta, proj_mask, train != 0, pj, out, e.jp4.out, ws, s, px ? &pxl : nullptr);
+}
+int aid_jacobian_features(const AidDecoderNet* dec, const AidEpistemicNet* epi, int R, const float* z, const float* delta, const float* proj_mask, int train,
+                          uint64_t seed, uint64_t offset, float* out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dec && epi && z && out, AID_E_NULL, "aid_jacobian_features: null argument");
+    AID_REQUIRE(R > 0 && R <= (1 << 24), AID_E_SHAPE, "aid_jacobian_features: R=%d", R);
+    Workspace ws(wsp, ws_bytes);
+    return jacobian_entry(*dec, *epi, R, z, delta, proj_mask, train, seed, offset, out, ws, (hipStream_t)stream, nullptr);
+}
+size_t aid_pixel_jacobian_features_workspace(const AidConvDecoder* dec, int R) { return aid_pixel_epistemic_workspace(dec, 1, 1, R); }
+int aid_pixel_jacobian_features(const AidConvDecoder* dec, const AidPixelEpistemicNet* pe, int R, const float* z, const float* delta, const float* proj_mask,
+                                const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* out, void* wsp, size_t ws_bytes, void* stream) {
+    AID_REQUIRE(dec && pe && z && out, AID_E_NULL, "aid_pixel_jacobian_features: null argument");
+    AID_REQUIRE(R > 0 && R <= (1 << 20), AID_E_SHAPE, "aid_pixel_jacobian_features: R=%d", R);
+    Workspace ws(wsp, ws_bytes);
+    AidEpistemicNet e = {};
+    e.L = pe->L; e.O = 1; e.perturbation_scale = pe->perturbation_scale;
+    e.fe0.out = 1; e.fe2.out = 1; e.fe4.out = pe->agg3.out;
+    e.jp0 = pe->jp0; e.jp_ln = pe->jp_ln; e.jp4 = pe->jp4;
+    PixelBackend px = {dec, pe, attn_mask, seed, offset};
+    AidDecoderNet none = {};
+    return jacobian_entry(none, e, R, z, delta, proj_mask, train, seed, offset, out, ws, (hipStream_t)stream, &px);
 }
 
 size_t aid_pixel_epistemic_workspace(const AidConvDecoder* dec, int K, int S, int B) {

@@ -410,6 +410,20 @@ int aid_efe_step_ex(const AidPolicyNet* pol, const AidPolicyNet* pgrads, const A
                     const AidValueNet* val, const AidDecoderNet* dec, const AidEpistemicNet* epi, int B, const float* latents,
                     const AidEfeNoise* noise, const AidEfeCfg* cfg, float* running_mean, float* efe_out, float* info, float* next_means_out,
                     void* ws, size_t ws_bytes, void* stream);
+/* DecoderBlock.forward, eval mode (aid/encoder/visual_encoders.py:370-459) as a call of its own: x [R, cin, h, h] -> out [R, cout, ho, ho] (ho = 2h when
+ * `upsample`: sub-pixel conv + PixelShuffle(2) on both paths).  blk->res.w == NULL: identity residual (needs cin == cout, no upsampling).  Spectral-norm
+ * weights are W / (u . W v) of the stored vectors (eval mode: no power iteration); Dropout2d is the identity in eval mode. */
+size_t aid_decoder_block_workspace(int cin, int cout, int upsample, int R, int h);
+int aid_decoder_block_forward(const AidDecoderBlock* blk, int cin, int cout, int upsample, int R, int h, const float* x, float* out, void* ws, size_t ws_bytes,
+                              void* stream);
+
+/* FunctionSpaceEpistemicEstimator.compute_jacobian_features (active_inference.py:940-993) as a call of its own: z [R,L] -> out [R, jp4.out].
+ * delta [4,R,L]: standard-normal perturbation directions (normalised and scaled by perturbation_scale inside, :962; NULL => device Philox from
+ * (seed, offset)); proj_mask [R, jp0.out]: jacobian_projector dropout mask in train mode (NULL => drawn).  The decoder runs in eval mode (:949). */
+size_t aid_jacobian_features_workspace(const AidDecoderNet* dec, int R);
+int aid_jacobian_features(const AidDecoderNet* dec, const AidEpistemicNet* epi, int R, const float* z, const float* delta, const float* proj_mask, int train,
+                          uint64_t seed, uint64_t offset, float* out, void* ws, size_t ws_bytes, void* stream);
+
 /* Pixel-mode epistemic value for ONE horizon step of all K trajectories (gradient-free, active_inference.py:398-418 + the pixel estimator):
  * next_mean [K*B, L]; noise: mine_z_eps [K*S*B, L], mine_delta [4, K*S*B, L], proj_mask [K*S*B, 512], mine_mask [4, K*S*B, 512], perms [K*S, B];
  * attn_mask [4][K*S*B*8][16][441] scaled keep masks of the aggregator's attention dropout (NULL members => device Philox).
@@ -418,6 +432,11 @@ size_t aid_pixel_epistemic_workspace(const AidConvDecoder* dec, int K, int S, in
 int aid_pixel_epistemic_value(const AidConvDecoder* dec, const AidPixelEpistemicNet* epi, int K, int S, int B, const float* next_mean,
                               const AidEfeNoise* noise, const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* mine_out,
                               void* ws, size_t ws_bytes, void* stream);
+/* The pixel branch of compute_jacobian_features (:976-983): ConvDecoder finite differences -> pixel_processor -> spatial_aggregator -> jacobian_projector.
+ * attn_mask: the aggregator's attention-dropout mask in train mode (NULL => drawn). */
+size_t aid_pixel_jacobian_features_workspace(const AidConvDecoder* dec, int R);
+int aid_pixel_jacobian_features(const AidConvDecoder* dec, const AidPixelEpistemicNet* epi, int R, const float* z, const float* delta, const float* proj_mask,
+                                const float* attn_mask, int train, uint64_t seed, uint64_t offset, float* out, void* ws, size_t ws_bytes, void* stream);
 /* Adds the epistemic term to an EFE computed with skip_epistemic: efe[b] += sum_t discount^t * w * mean_k max(mi[t][k], 0); info[1,4,5,6]
  * (epistemic_mean and the last (k,t)'s mi / joint / marginal) and the running-mean EMA replayed in the reference's (k outer, t inner) order. */
 int aid_efe_add_epistemic(const float* mine_all /*[H][K][4]*/, int H, int K, int B, float epistemic_weight, float discount, float alpha,

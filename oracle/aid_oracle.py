@@ -441,6 +441,23 @@ def _mine_net(p: Params, x: Tensor, noise, train: bool) -> Tensor:
     return _lin(p, EPI + "mine_network.6", x)
 
 
+def jacobian_features(p: Params, z_all: Tensor, noise, train: bool = False, ntk_samples: int = 4) -> Tensor:
+    """FunctionSpaceEpistemicEstimator.compute_jacobian_features, state branch (:940-993): finite differences of the eval-mode decoder along `ntk_samples`
+    random unit directions scaled by perturbation_scale -> feature extractor -> concatenated -> jacobian_projector (Linear, LayerNorm, ReLU, Dropout, Linear).
+    Draw order: ntk_samples x randn[R, L]; projector dropout mask [R, 512] in train mode."""
+    with torch.no_grad():
+        eps_scale = p[EPI + "perturbation_scale"]
+        f_z = decode_observation(p, z_all, None, False)
+        feats = []
+        for _ in range(ntk_samples):
+            delta = F.normalize(_t(noise.randn(*z_all.shape)), dim=-1) * eps_scale
+            diff = (decode_observation(p, z_all + delta, None, False) - f_z) / eps_scale
+            feats.append(_feature_extractor(p, diff))
+        jf = torch.cat(feats, dim=1)
+        jf = F.relu(_ln(p, EPI + "jacobian_projector.1", _lin(p, EPI + "jacobian_projector.0", jf)))
+        return _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+
+
 def epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_mean: float,
                     noise, num_samples: int = 10, train: bool = True, ntk_samples: int = 4,
                     alpha: float = 0.01):
@@ -457,16 +474,7 @@ def epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_m
         zs = [next_mean + _t(noise.randn(*next_mean.shape)) * torch.exp(0.5 * next_logvar)
               for _ in range(num_samples)]
         z_all = torch.cat(zs, dim=0)
-        eps_scale = p[EPI + "perturbation_scale"]
-        f_z = decode_observation(p, z_all, None, False)
-        feats = []
-        for _ in range(ntk_samples):
-            delta = F.normalize(_t(noise.randn(*z_all.shape)), dim=-1) * eps_scale
-            diff = (decode_observation(p, z_all + delta, None, False) - f_z) / eps_scale
-            feats.append(_feature_extractor(p, diff))
-        jf = torch.cat(feats, dim=1)
-        jf = F.relu(_ln(p, EPI + "jacobian_projector.1", _lin(p, EPI + "jacobian_projector.0", jf)))
-        jf = _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+        jf = jacobian_features(p, z_all, noise, train, ntk_samples)
         lf = _lin(p, EPI + "latent_processor.2", F.relu(_lin(p, EPI + "latent_processor.0", z_all)))
         t_joint = _mine_net(p, torch.cat([jf, lf], dim=1), noise, train)
         marg = []
@@ -1171,14 +1179,10 @@ def spatial_attention_aggregator(p: Params, pre: str, x: Tensor, noise, train: b
     return _lin(p, pre + "output_proj.3", F.gelu(_ln(p, pre + "output_proj.1", _lin(p, pre + "output_proj.0", o))))
 
 
-def pixel_epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_mean: float, noise, num_samples: int = 10,
-                          train: bool = True, ntk_samples: int = 4, alpha: float = 0.01):
-    """FunctionSpaceEpistemicEstimator.forward in pixel mode under no_grad: ConvDecoder (eval) finite differences -> pixel_processor
-    (three 5x5 stride-2 convs + ReLU) -> SpatialAttentionAggregator -> the same projector / latent processor / MINE statistics as the
-    state branch.  Draw order = burn_pixel_epistemic_draws.  -> (clamped MI, mi, joint, marginal term, new running_mean)"""
+def pixel_jacobian_features(p: Params, z_all: Tensor, noise, train: bool = False, ntk_samples: int = 4) -> Tensor:
+    """compute_jacobian_features, pixel branch (:940-983, 989-993): ConvDecoder finite differences -> pixel_processor (three 5x5 stride-2 convs) ->
+    spatial_aggregator (attention dropout in train mode, per direction) -> concatenated -> jacobian_projector."""
     with torch.no_grad():
-        B = next_mean.shape[0]
-        z_all = torch.cat([next_mean + _t(noise.randn(*next_mean.shape)) * torch.exp(0.5 * next_logvar) for _ in range(num_samples)], dim=0)
         eps_scale = p[EPI + "perturbation_scale"]
         f_z = conv_decoder_forward(p, z_all, EPI + "decoder.")
         feats = []
@@ -1190,7 +1194,18 @@ def pixel_epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, run
             feats.append(spatial_attention_aggregator(p, EPI + "spatial_aggregator.", h, noise, train))
         jf = torch.cat(feats, dim=1)
         jf = F.relu(_ln(p, EPI + "jacobian_projector.1", _lin(p, EPI + "jacobian_projector.0", jf)))
-        jf = _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+        return _lin(p, EPI + "jacobian_projector.4", _drop(jf, noise, 0.1, train))
+
+
+def pixel_epistemic_value(p: Params, next_mean: Tensor, next_logvar: Tensor, running_mean: float, noise, num_samples: int = 10,
+                          train: bool = True, ntk_samples: int = 4, alpha: float = 0.01):
+    """FunctionSpaceEpistemicEstimator.forward in pixel mode under no_grad: ConvDecoder (eval) finite differences -> pixel_processor
+    (three 5x5 stride-2 convs + ReLU) -> SpatialAttentionAggregator -> the same projector / latent processor / MINE statistics as the
+    state branch.  Draw order = burn_pixel_epistemic_draws.  -> (clamped MI, mi, joint, marginal term, new running_mean)"""
+    with torch.no_grad():
+        B = next_mean.shape[0]
+        z_all = torch.cat([next_mean + _t(noise.randn(*next_mean.shape)) * torch.exp(0.5 * next_logvar) for _ in range(num_samples)], dim=0)
+        jf = pixel_jacobian_features(p, z_all, noise, train, ntk_samples)
         lf = _lin(p, EPI + "latent_processor.2", F.relu(_lin(p, EPI + "latent_processor.0", z_all)))
         t_joint = _mine_net(p, torch.cat([jf, lf], dim=1), noise, train)
         marg = []

@@ -226,3 +226,96 @@ def test_score_network_backward_vs_oracle_autograd(cont, train):
         assert float((got[k].cpu() - r).norm() / r.norm()) < 1e-3, k
         checked += 1
     assert checked > 40, checked
+
+
+def test_compute_jacobian_features_reference_golden(golden_dir):
+    """FunctionSpaceEpistemicEstimator.compute_jacobian_features (core/active_inference.py:940-993) as a call of its own (aid_jacobian_features), against the
+    REFERENCE's output for the same weights and draws (tests/golden/jacobian_features.npz, oracle/gen_golden_jac.py): eval and train mode (projector dropout).
+    Tolerance: SURVEY 8(c)'s forward bound; the finite difference divides a difference of two decoder outputs by epsilon = 0.1, which amplifies rounding ~10x."""
+    import aid_amd
+    from oracle.weights import draw_params, param_specs
+    g = np.load(os.path.join(golden_dir, "jacobian_features.npz"))
+    O, A, D, N, R = (int(g[k]) for k in ("O", "A", "D", "N", "R"))
+    cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=8, efe_horizon=1, latent_dim=O, hidden_dim=D)
+    cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+
+    class _B:
+        def __init__(self, shape): self.shape = shape
+
+    class Env:
+        observation_space, action_space = _B((O,)), _B((A,))
+    ai = aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=16)).active_inference
+    p = draw_params(param_specs(O, A, O, D, N), int(g["weights_key"]), orc.schedule_tables(N))
+    sd0 = ai.state_dict()
+    ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+    est = ai.epistemic_estimator
+    p64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in p.items()}
+    z = torch.from_numpy(NoiseStream(int(g["z_key"])).randn(R, O)).cuda()
+    for mode in ("eval", "train"):
+        est.train(mode == "train")
+        ns = NoiseStream(int(g[f"noise_key_{mode}"]))
+        delta = torch.from_numpy(np.stack([ns.randn(R, O) for _ in range(4)])).cuda()
+        mask = torch.from_numpy(ns.dropout_mask((R, 512), 0.1)).cuda() if mode == "train" else None
+        out = est.compute_jacobian_features(z, delta=delta, proj_mask=mask)
+        ref = g[f"jac_{mode}"]
+        # float64 truth of the same function: the reference's own float32 result is ~4e-5 away from it (the division by epsilon = 0.1 and the projector's gain
+        # amplify the decoder's rounding), so that - not SURVEY's 1e-6 - is the resolution of this comparison
+        exact = orc.jacobian_features(p64, z.cpu().double(), NoiseStream(int(g[f"noise_key_{mode}"])), mode == "train").numpy()
+        err, err_ref, err_hip = (float(np.abs(a - b).max()) for a, b in ((out.cpu().numpy(), ref), (ref, exact), (out.cpu().numpy(), exact)))
+        print(f"compute_jacobian_features [{mode}]: max |hip - reference| = {err:.3g}; vs float64: reference {err_ref:.3g}, hip {err_hip:.3g} (|ref| max {np.abs(ref).max():.3g})")
+        assert err_hip < 2.0 * err_ref + 1e-5, (err_hip, err_ref)
+        np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=1e-4, atol=2e-4)
+    # drawn directions (device Philox): deterministic per (seed, offset), finite, different from call to call
+    est.eval()
+    a, b = est.compute_jacobian_features(z), est.compute_jacobian_features(z)
+    assert a.shape == (R, 256) and bool(torch.isfinite(a).all()) and not torch.equal(a, b)
+    assert est.compute_jacobian_features(z[:0]).shape == (0, 256)
+
+
+def test_compute_jacobian_features_pixel_vs_oracle():
+    """The pixel branch (:976-983): ConvDecoder finite differences -> pixel_processor -> spatial_aggregator -> jacobian_projector (aid_pixel_jacobian_features),
+    eval mode, against the oracle restatement that gen_golden_pixel_estimator.py pins to the reference through the whole estimator."""
+    from aid_amd import _native as nat
+    from oracle.encoder_weights import conv_decoder_specs, draw_conv_decoder_params, draw_pixel_estimator_params, pixel_estimator_specs
+    L, R = 16, 3
+    pd = draw_conv_decoder_params(conv_decoder_specs(L), 6001); pe = draw_pixel_estimator_params(pixel_estimator_specs(L), 6002)
+    pd_dev = {"observation_decoder." + k: v.cuda().contiguous() for k, v in pd.items()}      # the tables hold raw pointers: keep the tensors alive
+    pe_dev = {"epistemic_estimator." + k: v.cuda().contiguous() for k, v in pe.items()}
+    dec, epi = nat.conv_decoder_table(pd_dev), nat.pixel_epistemic_table(pe_dev)
+    p = {"epistemic_estimator." + k: v.clone() for k, v in pe.items()}
+    p.update({"epistemic_estimator.decoder." + k: v.clone() for k, v in pd.items()})
+    z = NoiseStream(6003).randn(R, L)
+    ns = NoiseStream(6004)
+    delta = np.stack([ns.randn(R, L) for _ in range(4)])
+    out = nat.jacobian_features(dec, epi, torch.from_numpy(z).cuda(), delta=torch.from_numpy(delta).cuda(), train=False)
+    ref = orc.pixel_jacobian_features(p, torch.from_numpy(z), NoiseStream(6004), False)
+    err = float((out.cpu() - ref).abs().max())
+    print(f"pixel compute_jacobian_features: max |hip - oracle| = {err:.3g} (|ref| max {float(ref.abs().max()):.3g})")
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("cin,cout,up,h", [(64, 64, False, 21), (64, 32, True, 21), (64, 32, False, 12), (32, 32, True, 42)])
+def test_decoder_block_forward_vs_oracle(cin, cout, up, h):
+    """DecoderBlock.forward in eval mode as a module call (encoder/visual_encoders.py:370-459 -> aid_decoder_block_forward): identity residual, sub-pixel
+    upsampling on both paths, and the channel-changing residual conv without upsampling (a form ConvDecoder itself never instantiates).  The oracle's
+    `decoder_block` is pinned to the reference through the whole ConvDecoder (tests/golden/conv_decoder.npz)."""
+    from aid_amd.encoder.visual_encoders import DecoderBlock
+    torch.manual_seed(3)
+    blk = DecoderBlock(cin, cout, upsample=up).cuda().eval()
+    with torch.no_grad():
+        for q in blk.parameters():
+            if q.dim() == 1:
+                q.copy_(0.1 * torch.randn_like(q))         # non-zero biases
+    p = {"b." + k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    R = 3
+    x = torch.from_numpy(NoiseStream(31).randn(R, cin, h, h))
+    out = blk(x.cuda())
+    ref = orc.decoder_block(p, "b.", x, up, cin != cout or up)
+    assert out.shape == ref.shape == (R, cout, 2 * h if up else h, 2 * h if up else h)
+    err = float((out.cpu() - ref).abs().max())
+    print(f"DecoderBlock {cin}->{cout} up={up}: max |hip - oracle| = {err:.3g} (|ref| max {float(ref.abs().max()):.3g})")
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=2e-5)
+    assert blk(x[:0].cuda()).shape[0] == 0
+    blk.train()
+    with pytest.raises(NotImplementedError):
+        blk(x.cuda())

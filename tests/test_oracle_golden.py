@@ -289,3 +289,21 @@ def test_a5_forward_process_oracle_vs_reference_golden(golden_dir, L):
     close(orc.posterior_mean(tab, z, z_t, steps), "posterior_mean")
     assert "out_features" in str(g["uncond_reference_raises"])       # the reference's observation=None branch raises (recorded fact)
     assert orc.score_forward  # the oracle's zero-embedding branch is exercised on the GPU box (tests/test_hip_a5.py)
+
+
+def test_jacobian_features_oracle_vs_reference_golden(golden_dir):
+    """core/active_inference.py:940-993 (state branch): the oracle's `jacobian_features` against the reference's own compute_jacobian_features
+    (tests/golden/jacobian_features.npz, oracle/gen_golden_jac.py; bit-identical when written)."""
+    import os
+    import numpy as np
+    import torch
+    from oracle import aid_oracle as orc
+    from oracle.noise import NoiseStream
+    from oracle.weights import draw_params, param_specs
+    g = np.load(os.path.join(golden_dir, "jacobian_features.npz"))
+    O, A, D, N, R = (int(g[k]) for k in ("O", "A", "D", "N", "R"))
+    p = draw_params(param_specs(O, A, O, D, N), int(g["weights_key"]), orc.schedule_tables(N))
+    z = torch.from_numpy(NoiseStream(int(g["z_key"])).randn(R, O))
+    for mode in ("eval", "train"):
+        out = orc.jacobian_features(p, z, NoiseStream(int(g[f"noise_key_{mode}"])), mode == "train")
+        np.testing.assert_allclose(out.numpy(), g[f"jac_{mode}"], rtol=1e-5, atol=1e-6)

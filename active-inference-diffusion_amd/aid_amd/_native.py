@@ -145,6 +145,19 @@ class AidElboCfg(C.Structure):
                 ("defer_time_importance", C.c_int32), ("_pad", C.c_int32)]
 
 
+def _pins_params(fn):
+    """The parameter tables hold raw device pointers; keep the tensors they were built from alive for as long as the table object lives (a table built from a
+    temporary dict would otherwise point at freed - and soon reused - memory)."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(params, *a, **k):
+        t = fn(params, *a, **k)
+        t._keep = [v for v in params.values() if isinstance(v, torch.Tensor)]
+        return t
+    return wrapped
+
+
 def _lin(params, name) -> AidLinear:
     w = params[name + ".weight"]; b = params.get(name + ".bias")
     l = AidLinear(); l.w = _ptr(w).value; l.b = _ptr(b).value if b is not None else None
@@ -157,6 +170,7 @@ def _ln(params, name) -> AidLN:
     return n
 
 
+@_pins_params
 def policy_table(params, prefix="policy_network.") -> AidPolicyNet:
     t = AidPolicyNet()
     t.L = params[prefix + "latent_encoder.0.weight"].shape[1]; t.D = params[prefix + "latent_encoder.0.weight"].shape[0]
@@ -169,6 +183,7 @@ def policy_table(params, prefix="policy_network.") -> AidPolicyNet:
     return t
 
 
+@_pins_params
 def value_table(params, prefix="value_network.") -> AidValueNet:
     t = AidValueNet()
     t.TE = params[prefix + "time_embed.1.weight"].shape[0]; t.D = params[prefix + "network.0.weight"].shape[0]
@@ -181,6 +196,7 @@ def value_table(params, prefix="value_network.") -> AidValueNet:
     return t
 
 
+@_pins_params
 def dynamics_table(params, A: int, prefix="latent_dynamics.") -> AidDynamicsNet:
     t = AidDynamicsNet()
     t.D = params[prefix + "network.0.weight"].shape[0]; t.A = A; t.L = params[prefix + "network.0.weight"].shape[1] - A
@@ -190,6 +206,7 @@ def dynamics_table(params, A: int, prefix="latent_dynamics.") -> AidDynamicsNet:
     return t
 
 
+@_pins_params
 def reward_table(params, prefix="reward_predictor.") -> AidRewardNet:
     t = AidRewardNet()
     t.L = params[prefix + "0.weight"].shape[1]; t.D = params[prefix + "0.weight"].shape[0]
@@ -197,6 +214,7 @@ def reward_table(params, prefix="reward_predictor.") -> AidRewardNet:
     return t
 
 
+@_pins_params
 def decoder_table(params, prefix="observation_decoder.") -> AidDecoderNet:
     t = AidDecoderNet()
     t.L = params[prefix + "0.0.weight"].shape[1]; t.O = params[prefix + "3.weight"].shape[0]; t.D = params[prefix + "3.weight"].shape[1]
@@ -206,6 +224,7 @@ def decoder_table(params, prefix="observation_decoder.") -> AidDecoderNet:
     return t
 
 
+@_pins_params
 def epistemic_table(params, prefix="epistemic_estimator.") -> AidEpistemicNet:
     t = AidEpistemicNet()
     t.L = params[prefix + "latent_processor.0.weight"].shape[1]; t.O = params[prefix + "feature_extractor.0.weight"].shape[1]
@@ -217,6 +236,7 @@ def epistemic_table(params, prefix="epistemic_estimator.") -> AidEpistemicNet:
     return t
 
 
+@_pins_params
 def diffusion_table(params, prefix="latent_diffusion.") -> AidDiffusionParams:
     t = AidDiffusionParams()
     t.prior_mean = _ptr(params[prefix + "latent_prior_mean"]).value; t.prior_log_std = _ptr(params[prefix + "latent_prior_log_std"]).value
@@ -284,6 +304,7 @@ class Workspace:
         return self.buf
 
 
+@_pins_params
 def score_net_table(params: Dict[str, torch.Tensor], prefix: str, L: int, O: int, D: int, n_blocks: int = 6,
                     TE: int = 128) -> AidScoreNet:
     """Build the AidScoreNet pointer table from tensors keyed by reference state_dict names."""
@@ -908,6 +929,7 @@ def collector_sampling(table: AidScoreNet, coefs, obs, num_steps: int, max_index
     return out, cnt
 
 
+@_pins_params
 def encoder_table(params, feature_dim: int, in_ch: int = 9, hw: int = 84, prefix: str = "") -> AidEncoderNet:
     """Table over DrQV2Encoder state_dict tensors (or their gradient twins; missing u/v entries become NULL)."""
     t = AidEncoderNet(); t.feature_dim, t.in_ch, t.H, t.W = feature_dim, in_ch, hw, hw
@@ -1070,6 +1092,7 @@ class AidConvDecoder(C.Structure):
                 + [(n, C.c_void_p) for n in ("out0_w", "out0_b", "out3_w", "out3_b", "out6_w", "out6_b")])
 
 
+@_pins_params
 def conv_decoder_table(params, prefix: str = "observation_decoder.") -> AidConvDecoder:
     """Table over ConvDecoder state_dict tensors (visual_encoders.py:243-330; legacy spectral-norm keys weight_orig / weight_u / weight_v)."""
     t = AidConvDecoder()
@@ -1137,6 +1160,7 @@ class AidPixelEpistemicNet(C.Structure):
                    ("lp0", AidLinear), ("lp2", AidLinear), ("mn0", AidLinear), ("mn3", AidLinear), ("mn6", AidLinear)])
 
 
+@_pins_params
 def pixel_epistemic_table(params, prefix: str = "epistemic_estimator.") -> AidPixelEpistemicNet:
     t = AidPixelEpistemicNet()
     g = lambda k: _ptr(params[prefix + k]).value

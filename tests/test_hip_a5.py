@@ -319,3 +319,21 @@ def test_decoder_block_forward_vs_oracle(cin, cout, up, h):
     blk.train()
     with pytest.raises(NotImplementedError):
         blk(x.cuda())
+
+
+def test_parameter_tables_keep_their_tensors_alive():
+    """The ctypes parameter tables hold raw device pointers.  A table built from a temporary dict must keep those tensors alive itself: otherwise the caching
+    allocator hands their memory to the next allocation and the kernels read garbage weights (silently)."""
+    import gc
+    from aid_amd import _native as nat
+    from oracle.weights import draw_params, param_specs
+    O, A, D, N, B = 17, 6, 64, 4, 32
+    p = draw_params(param_specs(O, A, O, D, N), 77, orc.schedule_tables(N))
+    dec = nat.decoder_table({k: v.cuda().contiguous() for k, v in p.items() if k.startswith("observation_decoder.")})      # temporary dict, temporary tensors
+    gc.collect()
+    junk = [torch.full((1 << 20,), float("nan"), device="cuda") for _ in range(8)]      # would land on the freed weights
+    z = NoiseStream(78).randn(B, O)
+    out = nat.decode_observation(dec, torch.from_numpy(z).cuda())
+    ref = orc.decode_observation(p, torch.from_numpy(z), None, False)
+    np.testing.assert_allclose(out.cpu().numpy(), ref.numpy(), rtol=1e-4, atol=1e-6)
+    del junk

@@ -314,12 +314,13 @@ static inline bool mid_tall80(int M, int N, int ksplit) {
     const long wg = (long)(M / 80) * (N / MID_BN) * ksplit;
     return wg >= 192 && wg <= 512;      // (2 560 x 256 as 128 workgroups was measured: slower than the 64 x 64 tiling, 5.41 against 5.23 ms per rollout + BPTT)
 }
-static int g_mid_bmt_min = 1;
+static int g_mid_bmt_min = 1, g_mid_bmt_max = 4;
 template <int ACT, bool BKM>
 static int launch_mid_bm(const MidArgs& g, hipStream_t s) {
     if (mid_tall80(g.M, g.N, g.ksplit)) return launch_mid<5, 1, 4, 1, ACT, BKM>(g, s);
     int bmt = (g.M + 255) / 256;        // up to 1024 rows: 8 row tiles of BM = 32 ceil(M / 256); beyond: ceil(M / 128) tiles of 128 rows
     if (bmt < g_mid_bmt_min) bmt = g_mid_bmt_min;      // timing experiments (aid_mid_debug)
+    if (bmt > g_mid_bmt_max) bmt = g_mid_bmt_max;
     switch (bmt) {
         case 1: return launch_mid<1, 2, 2, 2, ACT, BKM>(g, s);
         case 2: return launch_mid<2, 2, 2, 2, ACT, BKM>(g, s);
@@ -803,7 +804,12 @@ int adaln_sum(const float* res, int ldres, const float* slab, int nslab, const f
 }  // namespace aid
 
 using namespace aid;
-extern "C" int aid_mid_debug(int bmt_min) { g_mid_bmt_min = bmt_min < 1 ? 1 : (bmt_min > 4 ? 4 : bmt_min); return AID_OK; }
+extern "C" int aid_mid_debug(int bmt_min) {      // > 0: lowest tile height (units of 32 rows); < 0: highest (-1 .. -4); 0: defaults
+    if (bmt_min < 0) g_mid_bmt_max = -bmt_min > 4 ? 4 : -bmt_min;
+    else if (bmt_min == 0) { g_mid_bmt_min = 1; g_mid_bmt_max = 4; }
+    else g_mid_bmt_min = bmt_min > 4 ? 4 : bmt_min;
+    return AID_OK;
+}
 extern "C" {
 int aid_gemm_mid(const float* A, int lda, const float* W, int ldw, const float* bias, int act, const float* residual, int ldr, float* C, int ldc,
                  float* slab, int M, int N, int K, int ksplit, void* stream) {

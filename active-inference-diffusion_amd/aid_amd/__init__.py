@@ -9,7 +9,18 @@ from .configs.config import (ActiveInferenceConfig, BeliefDynamicsConfig, Diffus
 __version__ = "0.1.0"
 __all__ = ["ActiveInferenceConfig", "BeliefDynamicsConfig", "DiffusionConfig", "PixelObservationConfig", "TrainingConfig",
            "DiffusionStateAgent", "StateBasedAgent", "DiffusionPixelAgent", "PixelBasedAgent", "DrQV2Encoder",
-           "RandomShiftAugmentation", "DiffusionActiveInference", "LatentDiffusionProcess", "BeliefDynamics", "FreeEnergyComputation"]
+           "RandomShiftAugmentation", "DiffusionActiveInference", "LatentDiffusionProcess", "BeliefDynamics", "FreeEnergyComputation", "set_float32_matmul_emulation"]
+
+
+def set_float32_matmul_emulation(mode: str = "off"):
+    """Arithmetic of the tall full-row GEMMs (the epistemic estimator's 128 000 / 640 000-row layers, the reverse loop's hoisted conditioning):
+    "off" (default): `v_mfma_f32_32x32x2_f32`; "bf16x6": every float32 operand split exactly into three bfloat16 values, the six leading partial products
+    accumulated in float32 on `v_mfma_f32_32x32x16_bf16` - measured closer to a float64 product than the float32 MFMA chain, at 2.67 x its rate per clock
+    (csrc/gemm_rowln_x6.hip).  Process-wide; the environment variable AID_GEMM_X6=1 sets the initial value."""
+    from . import _native
+    if mode not in ("off", "bf16x6"):
+        raise ValueError("set_float32_matmul_emulation: 'off' or 'bf16x6'")
+    _native.gemm_emulation(1 if mode == "bf16x6" else 0)
 
 
 def __getattr__(name):  # lazy: importing the package must not require the GPU library (build() imports it on CPU)

@@ -331,6 +331,12 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kmajor=0, b_kmajor=0, bias=None,
     return C_out
 
 
+def gemm_emulation(mode: int):
+    """aid_gemm_emulation: 0 = the tall full-row GEMMs (the estimator's layers, the reverse loop's hoisted conditioning) on the float32 MFMA pipe (default);
+    1 = on the bf16 pipe as six split products at float32 accuracy (csrc/gemm_rowln_x6.hip).  Process-wide."""
+    check(lib().aid_gemm_emulation(int(mode)), "aid_gemm_emulation")
+
+
 def gemm_scratch(device="cuda"):
     """Scratch for gemm(..., scratch=): K slices and tile counters of the mid-size split-K route."""
     return torch.empty((lib().aid_gemm_scratch_bytes() + 3) // 4, dtype=torch.float32, device=device)

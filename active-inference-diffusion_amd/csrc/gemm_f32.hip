@@ -25,6 +25,7 @@
 #include <atomic>
 #include <mutex>
 #include "aid_common.h"
+#include "rowln.h"
 #include "rowwise.h"
 
 namespace aid {
@@ -1302,6 +1303,7 @@ int gemm_f32(const GemmArgs& g, hipStream_t s) {
         linear_rows_ok(g.M, g.N, g.K, g.act, g.A, g.lda, g.B, g.ldb) ) {
         const bool d16 = g.K % 16 == 0 && (stream_hint_get(s) & 2);
         prof.m = g.M; prof.n = g.N; prof.k = g.K; prof.layout = g.act + 8 * (g.K % (d16 ? 16 : 32) != 0) + 32 * d16; prof.variant = 23; prof.id = PROF_GEMM_TILE;
+        if (rowln_x6_enabled() && rowln_x6_ok(g.N, g.K, false)) { prof.variant = 29; prof.layout = g.act; }      // the six-term bf16 form (gemm_rowln_x6.hip)
         return linear_rows(g.A, g.lda, g.B, g.ldb, g.bias, g.act, g.mask, g.ldc, g.residual, g.ldr, g.C, g.ldc, g.M, g.N, g.K, s);
     }
     // layers that one-workgroup-per-CU tiles fit exactly (gemm_mid.hip): K*B = 2 560 rows x 512 columns of the rollout / BPTT as 80 x 64 tiles,

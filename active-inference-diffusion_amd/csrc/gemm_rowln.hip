@@ -22,50 +22,9 @@
 //     row partials to one row per lane in 31 cross-lane moves, cross-wave sums through LDS; affine, activation, skip; one store.
 #include "aid_common.h"
 #include "rowwise.h"
+#include "rowln.h"
 
 namespace aid {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-struct RowLnArgs {
-    const float* A; int lda;             // [M][K] activations
-    const float* W; int ldw;             // [BN][K] torch Linear weight
-    const float* bias;                   // [BN] or null
-    const float* gamma; const float* beta;   // LayerNorm affine, [BN] each (null => 1 / 0)
-    const float* add; int ldadd;         // optional skip, added after the activation (and after the mask)
-    const float* mask; int ldmask;       // optional multiplicative (dropout) mask applied to the activation
-    float* Y; int ldy;
-    int M, K;
-    float eps;
-};
-
-template <int BKT> struct RowSw {
-    static constexpr int CPR = BKT / 4;          // 16-B chunks per row
-    static constexpr int RPB = 64 / BKT;         // rows per 256-B bank row
-    __device__ static __forceinline__ int off(int row, int chunk) { return row * BKT + (((chunk ^ ((row / RPB) % CPR))) << 2); }
-};
-
-template <int ACT> __device__ __forceinline__ float rowln_act(float x) {
-    if constexpr (ACT == ACT_RELU) return x > 0.f ? x : 0.f;
-    else if constexpr (ACT == ACT_GELU) return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
-    else if constexpr (ACT == ACT_SILU) return x * __builtin_amdgcn_rcpf(1.f + expf(-x));
-    else return x;
-}
-
-// 32 per-lane values (one per accumulator row) -> lane li (of each 32-lane half) ends with the half-wide sum of value li.
-__device__ __forceinline__ float fold32(float (&x)[32], int li) {
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { const bool up = li & 16; const float recv = __shfl_xor(up ? x[i] : x[i + 16], 16, 64); x[i] = (up ? x[i + 16] : x[i]) + recv; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { const bool up = li & 8; const float recv = __shfl_xor(up ? x[i] : x[i + 8], 8, 64); x[i] = (up ? x[i + 8] : x[i]) + recv; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { const bool up = li & 4; const float recv = __shfl_xor(up ? x[i] : x[i + 4], 4, 64); x[i] = (up ? x[i + 4] : x[i]) + recv; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { const bool up = li & 2; const float recv = __shfl_xor(up ? x[i] : x[i + 2], 2, 64); x[i] = (up ? x[i + 2] : x[i]) + recv; }
-    { const bool up = li & 1; const float recv = __shfl_xor(up ? x[0] : x[1], 1, 64); x[0] = (up ? x[1] : x[0]) + recv; }
-    return x[0];
-}
 
 typedef __attribute__((address_space(3))) void* rl_lds_vptr;
 typedef const __attribute__((address_space(1))) void* rl_gbl_vptr;
@@ -422,6 +381,7 @@ int linear_rows(const float* x, int ldx, const float* W, int ldw, const float* b
     RowLnArgs g; memset(&g, 0, sizeof(g));
     g.A = x; g.lda = ldx; g.W = W; g.ldw = ldw; g.bias = b; g.add = add; g.ldadd = ldadd; g.mask = mask; g.ldmask = ldmask; g.Y = y; g.ldy = ldy;
     g.M = M; g.K = K; g.eps = 1e-5f;
+    if (rowln_x6_enabled() && rowln_x6_ok(N, K, false)) return launch_rowln_x6(g, N, act, false, s);
     switch (act) {
         case ACT_RELU: return launch_rows_plain<ACT_RELU>(g, N, s);
         case ACT_SILU: return launch_rows_plain<ACT_SILU>(g, N, s);
@@ -447,6 +407,11 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
         // stream hint: 74 KB of LDS, shares its CU) + a separate LayerNorm / act / skip pass over the 1024-wide rows
         AID_TRY(linear_rows(x, ldx, W, K, b, ACT_NONE, nullptr, 0, nullptr, 0, y, ldy, M, N, K, s));
         return ln_act(y, ldy, gamma, beta, act, mask, y, ldy, nullptr, M, N, s, add);
+    }
+    if (rowln_x6_enabled() && rowln_x6_ok(N, K, true)) {      // opt-in: the product as six bf16 MFMA terms (gemm_rowln_x6.hip)
+        ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
+        prof.m = M; prof.n = N; prof.k = K; prof.variant = 28; prof.layout = act + 8 * (N == 1024);
+        return launch_rowln_x6(g, N, act, true, s);
     }
     ProfScope prof(PROF_GEMM_TILE, s, 2.0 * M * N * K, 4.0 * ((double)M * K + (double)N * K + (double)M * N));
     prof.m = M; prof.n = N; prof.k = K; prof.variant = N == 1024 ? 20 : 21;

@@ -1,0 +1,328 @@
+// The full-row Linear (-> LayerNorm -> activation) kernels of gemm_rowln.hip with the product formed on the bf16 matrix pipe at float32 accuracy.
+//
+// Why: v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate (MI355X_MICROARCH.md, matrix cores); the estimator's 128 000 / 640 000-row GEMMs
+// (reference: core/active_inference.py:940-1063, FunctionSpaceEpistemicEstimator) sit at 0.79 MFMA utilisation on it - there is nothing left in that pipe.
+// A float32 value is EXACTLY the sum of three bfloat16 values (8 + 8 + 8 significant bits, each split rounded to nearest): x = h + m + l.  Of the nine
+// partial products of two such operands the three smallest (m l, l m, l l: <= 2^-23 of |a||b| together) are below float32's own rounding step; the other six
+//   h h,  h m,  m h,  h l,  l h,  m m
+// are exact in float32 (8 x 8 bits) and are accumulated in float32 by v_mfma_f32_32x32x16_bf16.  Six bf16 MFMAs of 16 x the rate = 2.67 x the float32 MFMA
+// rate per clock.  Measured against a float64 product (tools/perf/native/bf16x6_probe.hip, K = 512 .. 16 384, Gaussian and all-positive operands): the
+// six-term sum is CLOSER to float64 than the float32 MFMA chain in every case (rms 2.4e-8 vs 2.8e-8 of sum |a||b| at K = 1024; all-positive 3.4e-7 vs
+// 5.0e-7) - fewer accumulation steps (K / 16 x 6 instead of K / 2) outweigh the dropped terms.  tests/test_hip_kernels.py::test_rowln_x6_* asserts exactly that.
+//
+// Layout (one workgroup = 64 complete rows x BN columns, 8 waves, wave w owns columns [w BN/8, (w+1) BN/8) - the epilogue is gemm_rowln's):
+//   * weights stay float32 in LDS ([BN][BKT], the swizzle of gemm_rowln): a lane reads its 8 consecutive k of a column (two ds_read_b128) and splits them in
+//     registers (v_cvt_pk_bf16_f32 + subtract, 44 VALU operations per 8 values) in the shadow of the previous column block's MFMAs; a split serves the
+//     wave's two row blocks = 12 MFMAs (384 cycles of the pipe against ~180 issue cycles of splitting);
+//   * the 64 x BKT activation stage is split ONCE by the thread that stages it and kept in LDS as three bf16 planes ([3][64][BKT], 16-B chunks swizzled by
+//     row so that fragment reads are conflict-free): all 8 waves read the same activation fragments, splitting them per wave would be 8 x the work;
+//   * a lane's operand of v_mfma_f32_32x32x16_bf16 is k = 16 G + 8 (lane >> 5) + {0..7} of row / column (lane & 31): the same k permutation on both operands;
+//   * term order inside a 16-deep step: m m, h l, l h, h m, m h, h h (smallest first), all into the one accumulator.
+// Opt-in (aid_gemm_emulation(1) / AID_GEMM_X6=1): the default build computes these layers on the float32 pipe.
+#include "aid_common.h"
+#include "rowwise.h"
+#include "rowln.h"
+
+namespace aid {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l, each the round-to-nearest bfloat16 of what the previous ones left (the two subtractions are exact in float32)
+__device__ __forceinline__ void split8(const f32x4& lo, const f32x4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float x = e < 4 ? lo[e] : hi[e - 4];
+        const __bf16 a = (__bf16)x; const float r1 = x - (float)a;
+        const __bf16 b = (__bf16)r1; const float r2 = r1 - (float)b;
+        h[e] = a; m[e] = b; l[e] = (__bf16)r2;
+    }
+}
+__device__ __forceinline__ void split4(const f32x4& x, bf16x4& h, bf16x4& m, bf16x4& l) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 a = (__bf16)x[e]; const float r1 = x[e] - (float)a;
+        const __bf16 b = (__bf16)r1; const float r2 = r1 - (float)b;
+        h[e] = a; m[e] = b; l[e] = (__bf16)r2;
+    }
+}
+
+template <int BN, int BKT, int ACT, bool LN>
+__global__ void __launch_bounds__(512) gemm_rowln_x6_kernel(RowLnArgs g) {
+    constexpr int NT = 512, BM = 64, TN = BN / 256, CPR = BKT / 4, NG = BKT / 16;
+    constexpr int B_FL = BN * BKT;                                   // floats per weight buffer
+    constexpr int RP = BKT * 2, NC = BKT / 8, RPBA = 256 / RP;       // activation planes: bytes per row, 16-B chunks per row, rows per 256 B
+    constexpr int A_PL = BM * RP, A_BUF = 3 * A_PL;                  // bytes per plane / per buffer
+    constexpr int F4A = BM * CPR, F4B = BN * CPR, PB = F4B / NT;
+    static_assert(F4B % NT == 0 && F4A <= NT, "stage shapes");
+    using SW = RowSw<BKT>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Bs = smem;                                                              // [2][BN][BKT] float32
+    unsigned char* As = reinterpret_cast<unsigned char*>(smem + 2 * B_FL);         // [2][3][BM][BKT] bfloat16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const int wn = wave * (BN / 8);
+    const int m0 = blockIdx.x * BM;
+    if constexpr (!LN) {
+        const int n0 = blockIdx.y * BN;
+        g.W += (size_t)n0 * g.ldw; g.Y += n0;
+        if (g.bias) g.bias += n0;
+        if (g.add) g.add += n0;
+        if (g.mask) g.mask += n0;
+    }
+    f32x16 acc[2][TN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // ---- staging maps
+    const bool a_owner = tid < F4A;
+    const int fa = a_owner ? tid : 0, a_row = fa / CPR, a_c4 = fa % CPR;          // float4 a_c4 of row a_row: k = 4 a_c4 .. + 3
+    const float* a_src = g.A + (size_t)min(m0 + a_row, g.M - 1) * g.lda + 4 * a_c4;
+    const int a_dst = a_row * RP + (((a_c4 >> 1) ^ ((a_row / RPBA) % NC)) << 4) + ((a_c4 & 1) << 3);      // byte offset inside a plane
+    const float* b_src[PB]; int b_dst[PB];
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        const int f = tid + NT * p, row = f / CPR, c = f % CPR;
+        b_src[p] = g.W + (size_t)row * g.ldw + 4 * c; b_dst[p] = SW::off(row, c);
+    }
+    const int nk = g.K / BKT;
+    f32x4 ra, rb[PB];
+    // piece p of stage kt: global -> registers (p < PB: weight pieces, p == PB: the activation piece); registers -> LDS buffer `buf` (the activation piece is
+    // split into its three bf16 planes here, once for all 8 waves)
+    auto load_piece = [&](int p, int kt) {
+        const int k0 = kt * BKT;
+        if (p == PB) ra = *reinterpret_cast<const f32x4*>(a_src + k0);
+        else rb[p] = *reinterpret_cast<const f32x4*>(b_src[p] + k0);
+    };
+    auto store_piece = [&](int p, int buf) {
+        if (p == PB) {
+            if (a_owner) {
+                bf16x4 ph, pm, pl; split4(ra, ph, pm, pl);
+                unsigned char* d = As + buf * A_BUF + a_dst;
+                *reinterpret_cast<bf16x4*>(d) = ph; *reinterpret_cast<bf16x4*>(d + A_PL) = pm; *reinterpret_cast<bf16x4*>(d + 2 * A_PL) = pl;
+            }
+        } else *reinterpret_cast<f32x4*>(Bs + buf * B_FL + b_dst[p]) = rb[p];
+    };
+    // fragment addresses (lane-constant parts)
+    int a_frag[2];                                    // byte offset of row 32 i + li in a plane
+#pragma unroll
+    for (int i = 0; i < 2; ++i) a_frag[i] = (32 * i + li) * RP;
+    const int a_swz = ((li / RPBA) % NC);             // (32 i + li) / RPBA % NC == li / RPBA % NC: 32 is a multiple of RPBA NC
+    // One stage = NB = NG x TN blocks (16-deep step G, column block j) of 2 row blocks x 6 terms = 12 MFMAs.  Everything a block needs is in registers BEFORE its
+    // MFMAs start: while block q is contracted, the weight fragment of block q + 1 is read from LDS and split, and (at a step boundary) the activation fragments of
+    // the next step are read.  The stage barrier sits in front of the LAST block's MFMAs: by then every LDS read of this stage has returned and every hand-over write
+    // of the next one has been issued, so behind the barrier the wave requests block 0 of the next stage and covers that round trip + split with the 12 MFMAs it
+    // still holds - the matrix pipe does not drain at a stage boundary.  As in gemm_rowln_kernel the hand-over of the next stage rides in this stage's MFMA stream:
+    // global loads behind the MFMAs of the first half, LDS writes (other buffer) behind the following ones, all before the barrier.
+    constexpr int NB = NG * TN, NM = NB * 12, NS = PB + 1, S0 = NM / 2, LSTEP = S0 / NS, STEP = (NM - 12 - S0) / NS;
+    static_assert(LSTEP >= 1 && STEP >= 1, "more hand-over pieces than MFMA slots");
+    bf16x8 ah[2], am[2], al[2], nah[2], nam[2], nal[2];        // activation fragments of the current / next 16-deep step
+    bf16x8 bh, bm, bl;                                          // split weight fragment of the current block
+    f32x4 blo, bhi;                                             // raw weight fragment of the next block
+    auto read_a = [&](const unsigned char* a_s, int G, bf16x8 (&xh)[2], bf16x8 (&xm)[2], bf16x8 (&xl)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned char* p = a_s + a_frag[i] + ((((2 * G + h) ^ a_swz)) << 4);
+            xh[i] = *reinterpret_cast<const bf16x8*>(p); xm[i] = *reinterpret_cast<const bf16x8*>(p + A_PL); xl[i] = *reinterpret_cast<const bf16x8*>(p + 2 * A_PL);
+        }
+    };
+    auto read_b = [&](const float* b_s, int G, int j) {
+        blo = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j + li, 4 * G + 2 * h));
+        bhi = *reinterpret_cast<const f32x4*>(b_s + SW::off(wn + 32 * j + li, 4 * G + 2 * h + 1));
+    };
+    auto stage = [&](int cur, int kt_next) {
+        const float* b_s = Bs + cur * B_FL;
+        const unsigned char* a_s = As + cur * A_BUF;
+        int idx = 0;
+        auto tick = [&]() {            // called after every MFMA
+            if (idx < S0 && idx % LSTEP == 0 && idx / LSTEP < NS) { load_piece(idx / LSTEP, kt_next); __builtin_amdgcn_sched_barrier(0); }
+            if (idx >= S0 && (idx - S0) % STEP == 0 && (idx - S0) / STEP < NS) { store_piece((idx - S0) / STEP, cur ^ 1); __builtin_amdgcn_sched_barrier(0); }
+            ++idx;
+        };
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int G = q / TN, j = q % TN;
+            const bool last = q + 1 == NB, new_step = last || (q + 1) / TN != G;
+            if (!last) {
+                read_b(b_s, (q + 1) / TN, (q + 1) % TN);
+                if (new_step) read_a(a_s, (q + 1) / TN, nah, nam, nal);
+            } else {
+                __syncthreads();                                    // every wave is done reading this stage; the next one is complete in the other buffer
+                read_b(Bs + (cur ^ 1) * B_FL, 0, 0);
+                read_a(As + (cur ^ 1) * A_BUF, 0, nah, nam, nal);
+            }
+            bf16x8 nbh, nbm, nbl;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bm, acc[i][j], 0, 0, 0); tick();
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i][j], 0, 0, 0); tick();
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i][j], 0, 0, 0); tick();
+                if (i == 0) split8(blo, bhi, nbh, nbm, nbl);        // the next block's weights, in the shadow of this block's MFMAs
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bm, acc[i][j], 0, 0, 0); tick();
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], bh, acc[i][j], 0, 0, 0); tick();
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i][j], 0, 0, 0); tick();
+            }
+            bh = nbh; bm = nbm; bl = nbl;
+            if (new_step) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; am[i] = nam[i]; al[i] = nal[i]; }
+            }
+        }
+    };
+#pragma unroll
+    for (int p = 0; p < NS; ++p) load_piece(p, 0);
+#pragma unroll
+    for (int p = 0; p < NS; ++p) store_piece(p, 0);
+    __syncthreads();
+    read_b(Bs, 0, 0); read_a(As, 0, ah, am, al);
+    split8(blo, bhi, bh, bm, bl);
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const int ktn = kt + 1 < nk ? kt + 1 : kt;       // the last iteration re-loads its own stage into the idle buffer: branch-free loop
+        stage(cur, ktn);
+    }
+    __syncthreads();                                     // the last stage's look-ahead reads are done before the epilogue reuses the buffers
+    // ---- epilogue (gemm_rowln_kernel's: bias, two-pass LayerNorm over the complete rows, affine, activation, mask, skip)
+    float* part = smem;                 // [8 waves][64 rows]
+    float* rowv = smem + 8 * BM;        // [64]: mean, then 1/std
+    float bcol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bcol[j] = g.bias ? g.bias[wn + 32 * j + li] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    if constexpr (LN) {
+        const int my_row = 32 * (li >> 4) + ((li & 15) & 3) + 8 * ((li & 15) >> 2) + 4 * h;
+        float x[32];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) s += acc[i][j][r];
+                x[16 * i + r] = s;
+            }
+        part[wave * BM + my_row] = fold32(x, li);
+        __syncthreads();
+        if (tid < BM) { float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[w * BM + tid];
+            rowv[tid] = s / (float)BN; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] -= m4[e];
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = 0.f;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) s += acc[i][j][r] * acc[i][j][r];
+                x[16 * i + r] = s;
+            }
+        __syncthreads();
+        part[wave * BM + my_row] = fold32(x, li);
+        __syncthreads();
+        if (tid < BM) { float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) s += part[w * BM + tid];
+            rowv[tid] = 1.0f / sqrtf(s / (float)BN + g.eps); }
+        __syncthreads();
+    }
+    float gcol[TN], becol[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gcol[j] = (LN && g.gamma) ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = (LN && g.beta) ? g.beta[wn + 32 * j + li] : 0.f; }
+    float sk[2][4][TN], mk[2][4][TN];
+    auto load_aux = [&](int gq, int pb) {
+        const int i = gq >> 2, rq = gq & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                if (g.add) sk[pb][e][j] = g.add[(size_t)row * g.ldadd + wn + 32 * j + li];
+                if (g.mask) mk[pb][e][j] = g.mask[(size_t)row * g.ldmask + wn + 32 * j + li];
+            }
+        }
+    };
+    const bool aux = g.add || g.mask;
+    if (aux) load_aux(0, 0);
+#pragma unroll
+    for (int gq = 0; gq < 8; ++gq) {
+        const int i = gq >> 2, rq = gq & 3, pb = gq & 1;
+        if (aux && gq + 1 < 8) load_aux(gq + 1, pb ^ 1);
+        f32x4 r4 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (LN) r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn + 32 * j + li;
+                float o = LN ? rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]) : rowln_act<ACT>(acc[i][j][4 * rq + e]);
+                if (g.mask) o *= mk[pb][e][j];
+                if (g.add) o += sk[pb][e][j];
+                if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
+            }
+        }
+    }
+}
+
+static int g_x6 = -1;       // -1: not decided (environment AID_GEMM_X6 read on first use), 0 off, 1 on
+bool rowln_x6_enabled() {
+    if (g_x6 < 0) { const char* e = getenv("AID_GEMM_X6"); g_x6 = (e && e[0] == '1') ? 1 : 0; }
+    return g_x6 != 0;
+}
+bool rowln_x6_ok(int N, int K, bool ln) {
+    if (ln) return (N == 1024 && K % 16 == 0) || (N == 512 && K % 32 == 0);
+    return N % 512 == 0 && K % 32 == 0;
+}
+template <int BN, int BKT, int ACT, bool LN>
+static int launch_x6(const RowLnArgs& g, int N, hipStream_t s) {
+    constexpr size_t lds = sizeof(float) * 2 * (size_t)BN * BKT + 2 * 3 * 64 * BKT * 2;
+    static bool attr_done = false;
+    if (!attr_done) {
+        AID_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_rowln_x6_kernel<BN, BKT, ACT, LN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_done = true;
+    }
+    const dim3 grid((g.M + 63) / 64, LN ? 1 : N / BN);
+    hipLaunchKernelGGL((gemm_rowln_x6_kernel<BN, BKT, ACT, LN>), grid, dim3(512), lds, s, g);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+template <int BN, int BKT, bool LN>
+static int launch_x6_act(const RowLnArgs& g, int N, int act, hipStream_t s) {
+    switch (act) {
+        case ACT_SILU: return launch_x6<BN, BKT, ACT_SILU, LN>(g, N, s);
+        case ACT_RELU: return launch_x6<BN, BKT, ACT_RELU, LN>(g, N, s);
+        case ACT_GELU: return launch_x6<BN, BKT, ACT_GELU, LN>(g, N, s);
+        default: return launch_x6<BN, BKT, ACT_NONE, LN>(g, N, s);
+    }
+}
+int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) {
+    AID_REQUIRE(rowln_x6_ok(N, g.K, ln), AID_E_SHAPE, "launch_rowln_x6: N=%d K=%d ln=%d", N, g.K, (int)ln);
+    if (ln && N == 1024) return launch_x6_act<1024, 16, true>(g, N, act, s);
+    if (ln) return launch_x6_act<512, 32, true>(g, N, act, s);
+    return launch_x6_act<512, 32, false>(g, N, act, s);
+}
+
+}  // namespace aid
+
+using namespace aid;
+// 0: the full-row GEMMs of the estimator run on v_mfma_f32_32x32x2_f32 (default); 1: on the bf16 pipe as six split products (float32 accuracy, see above)
+extern "C" int aid_gemm_emulation(int mode) { g_x6 = mode ? 1 : 0; return AID_OK; }

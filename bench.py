@@ -142,6 +142,10 @@ def kernel_name(variant, layout):
         return f"gemm_rowln_kernel<{1024 if variant == 20 else 512}, {16 if variant == 20 or layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, true, {b(layout & 16)}>"
     if variant == 23:
         return f"gemm_rowln_kernel<512, {16 if layout & 32 else 32}, {layout & 7}, {b(layout & 8)}, 0, false, false>"
+    if variant == 28:      # opt-in (aid_gemm_emulation(1)): the same layers as six bf16 MFMA terms (csrc/gemm_rowln_x6.hip); layout = act + 8 (1024-wide)
+        return f"gemm_rowln_x6_kernel<{1024 if layout & 8 else 512}, {16 if layout & 8 else 32}, {layout & 7}, true>"
+    if variant == 29:
+        return f"gemm_rowln_x6_kernel<512, 32, {layout & 7}, false>"
     if variant in (22, 24):      # layout = 8 BMF + act (+ 64: contraction-major W); the 32-row tile is the register-capped instantiation; 24 = K slices folded in the kernel
         bmf, act, bkm = (layout >> 3) & 7, layout & 7, b(layout & 64)
         if bmf == 5:
@@ -716,6 +720,28 @@ def main():
     for _ in range(2):                        # the first step still consumes a three-loop prefetch; the chain graphs of the two-loop form are captured here
         agent.train_step()
     elapsed_elided, own_elided = timed_steps(args.steps)
+    # Third and fourth timed regions, same process, same K: the tall full-row GEMMs (the estimator's layers, the hoisted conditioning of the reverse loops)
+    # on the bf16 matrix pipe as six split products - float32 operands split exactly three ways, float32 accumulation, measured CLOSER to float64 than the
+    # float32 MFMA kernels they replace (csrc/gemm_rowln_x6.hip; tests/test_hip_kernels.py::test_rowln_x6_*).  Opt-in (aid_amd.set_float32_matmul_emulation
+    # ("bf16x6")): `value` above is the all-float32-MFMA step; these are reported beside it, never instead of it.
+    x6 = None
+    if "x6" not in set(os.environ.get("AID_BENCH_SKIP", "").split(",")) and os.environ.get("AID_GEMM_X6") != "1":
+        nat.gemm_emulation(1)
+        try:
+            agent.elide_dead_next_belief = False
+            for _ in range(3):
+                agent.train_step()
+            el_x6, _ = timed_steps(args.steps)
+            agent.elide_dead_next_belief = True
+            for _ in range(2):
+                agent.train_step()
+            el_x6e, _ = timed_steps(args.steps)
+            x6 = (el_x6, el_x6e)
+        finally:
+            nat.gemm_emulation(0)
+            agent.elide_dead_next_belief = True
+        for _ in range(2):
+            agent.train_step()
     dp_info = None
     if world > 1:
         import torch.distributed as dist
@@ -872,6 +898,12 @@ def main():
         "dead_belief": {"flop_per_step": DEAD_BELIEF_FLOP_PER_STEP * rows / BATCH, "reference": "agents/state_agent.py:138-139 (overwritten at :195-196)",
                         "executed_in": "value / ms_per_step", "not_executed_in": "value_dead_belief_elided / ms_per_step_dead_belief_elided",
                         "note": "never part of the FLOP numerators below: they count live work only (SURVEY 8d: executed total minus dead work)"},
+        "value_bf16x6": (args.steps / x6[0] * agg) if x6 else None, "ms_per_step_bf16x6": (1e3 * x6[0] / args.steps) if x6 else None,
+        "value_bf16x6_dead_belief_elided": (args.steps / x6[1] * agg) if x6 else None, "ms_per_step_bf16x6_dead_belief_elided": (1e3 * x6[1] / args.steps) if x6 else None,
+        "bf16x6": {"what": "opt-in arithmetic of the tall full-row GEMMs (estimator layers, hoisted conditioning): float32 operands split exactly into three bfloat16 "
+                           "values, six partial products accumulated in float32 on v_mfma_f32_32x32x16_bf16; error against float64 not larger than the float32 MFMA "
+                           "kernels' (tests/test_hip_kernels.py::test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma)",
+                   "default": "off: `value` / `ms_per_step` are the all-float32-MFMA step", "switch": "aid_amd.set_float32_matmul_emulation('bf16x6') / AID_GEMM_X6=1"},
         "denoise_steps_per_s": NSTEPS / dn, "denoise_row_steps_per_s": NSTEPS * BATCH / dn,
         "denoise_algorithmic_tflops": ALGO_FLOP_PER_DENOISE_ROW_STEP * NSTEPS * BATCH / dn / 1e12,
         "train_step_live_flop": ALGO_FLOP_PER_STEP * rows / BATCH,
@@ -912,7 +944,8 @@ def main():
 # The driver parses ONE stdout line and keeps only a bounded tail of it (round 4's 25.9 KB line came back `parsed: null`): the line carries the
 # contract keys and the headline objects only; every other object goes to bench_detail.json (next to this file) and to stderr.
 LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-             "value_dead_belief_elided", "ms_per_step_dead_belief_elided", "denoise_steps_per_s", "train_step_live_flop", "train_step_frac_of_f32_mfma_peak",
+             "value_dead_belief_elided", "ms_per_step_dead_belief_elided", "value_bf16x6", "ms_per_step_bf16x6", "value_bf16x6_dead_belief_elided",
+             "ms_per_step_bf16x6_dead_belief_elided", "denoise_steps_per_s", "train_step_live_flop", "train_step_frac_of_f32_mfma_peak",
              "train_step_frac_of_f32_mfma_peak_dead_belief_elided", "roofline", "cpu_baseline", "speedup_vs_cpu_baseline", "data_parallel", "other_configs_ms",
              "detail")
 ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "flop_per_launch", "algorithmic_bytes_per_launch",

@@ -103,6 +103,11 @@ int aid_mid_debug(int bmt_min);
 int aid_denoise_debug(int chunk_cap);
 int aid_conv_debug(int mode);
 int aid_rowln_debug(int mode);
+/* Arithmetic of the estimator's full-row GEMMs (>= 2 048 rows x 512 / 1024 columns): 0 (default) v_mfma_f32_32x32x2_f32; 1: each float32 operand split into
+ * three bfloat16 values (exactly: 8 + 8 + 8 bits) and the six leading partial products accumulated in float32 on v_mfma_f32_32x32x16_bf16 - closer to the
+ * float64 product than the float32 MFMA chain (csrc/gemm_rowln_x6.hip, tools/perf/native/bf16x6_probe.hip), 2.67 x the MFMA rate per clock.  Process-wide;
+ * environment AID_GEMM_X6=1 sets the initial value. */
+int aid_gemm_emulation(int mode);
 int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
                   float* y, int ldy, int M, int D, void* stream);
 

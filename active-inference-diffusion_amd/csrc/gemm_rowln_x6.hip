@@ -22,10 +22,19 @@
 #include "aid_common.h"
 #include "rowwise.h"
 #include "rowln.h"
+#include <mutex>
+#include <type_traits>
 
 namespace aid {
 
+typedef __attribute__((address_space(3))) void* rl_lds_vptr;
+typedef const __attribute__((address_space(1))) void* rl_gbl_vptr;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// compile-time loop: the body sees its index as a constant expression (a `#pragma unroll` the compiler declines leaves register arrays dynamically indexed,
+// i.e. in scratch memory)
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 // x = h + m + l, each the round-to-nearest bfloat16 of what the previous ones left (the two subtractions are exact in float32)
@@ -283,6 +292,280 @@ __global__ void __launch_bounds__(512) gemm_rowln_x6_kernel(RowLnArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------------
+// Second form (the one the dispatcher prefers): weights pre-split ONCE per call into three bf16 planes stored FRAGMENT-MAJOR in global memory, one wave per
+// SIMD, 256 accumulator registers per wave.
+//   * 4 waves (one per SIMD: up to 512 registers, the accumulators in the AGPR half); a workgroup = 32 RB complete rows x 128 CB columns, wave w owns columns
+//     [32 CB w, 32 CB (w + 1)): RB x CB blocks of 32 x 32 with RB CB = 16 (RB = 4, CB = 4: 128 rows x 512 columns; RB = 2, CB = 8: 64 rows x 1024 columns, the
+//     estimator's 1024-wide LayerNorm'd stage), so a 16-deep stage is 16 x 6 = 96 MFMAs (3 072 cycles of the pipe) between two barriers;
+//   * the waves split the COLUMNS only, so a weight fragment is used by exactly one wave: it never goes through LDS.  split_planes_kernel writes the planes in
+//     the order the MFMA wants them - [plane][k / 16][n / 32][lane][8] - and a wave's fragment is one fully coalesced 1 KB global load straight into the
+//     registers the MFMA reads, re-requested for the next stage as soon as the column block's MFMAs are issued (CB - 1 column blocks = 1.1 - 1.3 us ahead);
+//     no conversion arithmetic, no LDS traffic, no DMA drain for the operand that is 4/5 of the bytes;
+//   * the activations (shared by the four waves) are split once per workgroup by the thread that stages them and kept in LDS as three bf16 planes
+//     (2 x 3 x 32 RB x 16: 12 - 24 KB); the stage barrier is a raw s_barrier behind lgkmcnt(0) - the weight loads in flight are not drained by it - and sits in
+//     front of the last column block: behind it the wave re-reads each activation fragment right after its last use, the pipe keeps running across the boundary.
+template <int RB, int CB, int ACT, bool LN>
+__global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16* __restrict__ Wp, size_t wplane, int ncb /* N / 32 of the whole weight */) {
+    static_assert(RB * CB == 16, "256 accumulator registers per wave");
+    constexpr int BM = 32 * RB, BN = 128 * CB, BKT = 16, NT = 256;
+    constexpr int A_PL = BM * BKT * 2, A_BUF = 3 * A_PL;           // bytes
+    constexpr int PA = BM * 4 / NT > 0 ? BM * 4 / NT : 1;          // float4 activation pieces per thread per stage (BM = 128: 2, BM = 64: 1)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned char* As = reinterpret_cast<unsigned char*>(smem);   // [2][3][BM][16] bf16
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int li = lane & 31, h = lane >> 5;
+    const int wn = wave * (32 * CB);
+    const int m0 = blockIdx.x * BM, n0 = LN ? 0 : blockIdx.y * BN;
+    if constexpr (!LN) {
+        g.Y += n0;
+        if (g.bias) g.bias += n0;
+        if (g.add) g.add += n0;
+        if (g.mask) g.mask += n0;
+    }
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int nk = g.K / BKT;
+    // ---- weight fragments: plane p, stage t, column block (n0 + wn) / 32 + j  ->  Wp + p wplane + (t ncb + cb) 512 + 8 lane
+    const __bf16* w_lane = Wp + ((size_t)((n0 >> 5) + wave_u * CB) << 9) + 8 * lane;
+    const size_t w_step = (size_t)ncb << 9;                        // one stage further
+    bf16x8 bh[CB], bm[CB], bl[CB];
+    auto b_load = [&](int j, int t) {                            // column block j of stage t -> its registers (the same ones stage t - 1 used for block j)
+        const __bf16* p = w_lane + (size_t)(t < nk ? t : nk - 1) * w_step + (j << 9);
+        bh[j] = *reinterpret_cast<const bf16x8*>(p); bm[j] = *reinterpret_cast<const bf16x8*>(p + wplane); bl[j] = *reinterpret_cast<const bf16x8*>(p + 2 * wplane);
+    };
+    // ---- activation staging: thread t stages float4 pieces f = t (+ 256): row f / 4, k = 4 (f % 4) .. + 3
+    const bool a_owner = PA * NT == BM * 4 || tid < BM * 4;
+    const float* a_src[PA]; int a_dst[PA];
+#pragma unroll
+    for (int e = 0; e < PA; ++e) {
+        const int f = (tid + NT * e) % (BM * 4), row = f >> 2, c4 = f & 3;
+        a_src[e] = g.A + (size_t)min(m0 + row, g.M - 1) * g.lda + 4 * c4;
+        a_dst[e] = row * 32 + (((c4 >> 1) ^ ((row >> 3) & 1)) << 4) + ((c4 & 1) << 3);
+    }
+    f32x4 ra[PA];
+    auto a_load = [&](int kt) {
+        const int k0 = (kt < nk ? kt : nk - 1) * BKT;
+#pragma unroll
+        for (int e = 0; e < PA; ++e) ra[e] = *reinterpret_cast<const f32x4*>(a_src[e] + k0);
+    };
+    auto a_store = [&](int buf) {
+        if (!a_owner) return;
+#pragma unroll
+        for (int e = 0; e < PA; ++e) {
+            bf16x4 ph, pm, pl; split4(ra[e], ph, pm, pl);
+            unsigned char* d = As + buf * A_BUF + a_dst[e];
+            *reinterpret_cast<bf16x4*>(d) = ph; *reinterpret_cast<bf16x4*>(d + A_PL) = pm; *reinterpret_cast<bf16x4*>(d + 2 * A_PL) = pl;
+        }
+    };
+    const int a_off = li * 32 + ((h ^ ((li >> 3) & 1)) << 4);                  // row 32 i + li: + 1024 i  (32 i / 8 is even: the swizzle term is li's)
+    bf16x8 ah[RB], am[RB], al[RB];
+    auto read_a = [&](int buf, int i) {
+        const unsigned char* p = As + buf * A_BUF + a_off + 1024 * i;
+        ah[i] = *reinterpret_cast<const bf16x8*>(p); am[i] = *reinterpret_cast<const bf16x8*>(p + A_PL); al[i] = *reinterpret_cast<const bf16x8*>(p + 2 * A_PL);
+    };
+    auto block6 = [&](int i, int j, const bf16x8& xh, const bf16x8& xm, const bf16x8& xl) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], xm, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], xl, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], xh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], xm, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[i], xh, acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], xh, acc[i][j], 0, 0, 0);
+    };
+    // stage t (activation buffer cur = t & 1).  A column block's weight registers are re-requested for stage t + 1 as soon as its MFMAs have been issued: the
+    // load has CB - 1 column blocks (>= 2 300 cycles) to arrive.  `ra` holds the float32 activations of stage t + 1 (loaded a stage ago): split and written to the
+    // other buffer early in the stage, then re-loaded for stage t + 2.
+    auto stage = [&](int t, int cur) {
+#pragma unroll
+        for (int j = 0; j < CB - 1; ++j) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) block6(i, j, bh[j], bm[j], bl[j]);
+            __builtin_amdgcn_sched_barrier(0);                      // pin the requests here: the scheduler otherwise sinks them to the end of the stage
+            b_load(j, t + 1);
+            if (j == 0) { a_store(cur ^ 1); a_load(t + 2); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // activations of stage t + 1 written by every wave, buffer `cur` read for the last time
+#pragma unroll
+        for (int i = 0; i < RB; ++i) { block6(i, CB - 1, bh[CB - 1], bm[CB - 1], bl[CB - 1]); read_a(cur ^ 1, i); }
+        __builtin_amdgcn_sched_barrier(0);
+        b_load(CB - 1, t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // ---- prologue
+    a_load(0);
+#pragma unroll
+    for (int j = 0; j < CB; ++j) b_load(j, 0);
+    a_store(0);
+    a_load(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < RB; ++i) read_a(0, i);
+    for (int t = 0; t < nk; t += 2) {                               // nk is even (K % 32 == 0, checked on the host)
+        stage(t, 0);
+        stage(t + 1, 1);
+    }
+    __syncthreads();                                                // look-ahead reads are done before the epilogue reuses the buffer
+    // ---- epilogue: bias, two-pass LayerNorm over the complete rows (4 waves x 32 CB columns), affine, activation, mask, skip
+    float* part = smem;                 // [4 waves][BM rows]
+    float* rowv = smem + 4 * BM;        // [BM]: mean, then 1/std
+    float bcol[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) bcol[j] = g.bias ? g.bias[wn + 32 * j + li] : 0.f;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    if constexpr (LN) {
+        // accumulator register r of row block i is row 32 i + (r & 3) + 8 (r >> 2) + 4 h; fold32 takes two row blocks at a time
+        const int my_row = 32 * (li >> 4) + ((li & 15) & 3) + 8 * ((li & 15) >> 2) + 4 * h;
+        float x[32];
+        static_for<0, RB / 2>([&](auto prc) {
+            constexpr int pr = decltype(prc)::value;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) s += acc[2 * pr + i2][j][r];
+                    x[16 * i2 + r] = s;
+                }
+            part[wave * BM + 64 * pr + my_row] = fold32(x, li);
+        });
+        __syncthreads();
+        if (tid < BM) rowv[tid] = (((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid]) / (float)BN;
+        __syncthreads();
+        static_for<0, RB>([&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const f32x4 m4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * rq + e] -= m4[e];
+            }
+        });
+        __syncthreads();                                     // every wave has read the means before `rowv` / `part` are reused
+        static_for<0, RB / 2>([&](auto prc) {
+            constexpr int pr = decltype(prc)::value;
+#pragma unroll
+            for (int i2 = 0; i2 < 2; ++i2)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) s += acc[2 * pr + i2][j][r] * acc[2 * pr + i2][j][r];
+                    x[16 * i2 + r] = s;
+                }
+            part[wave * BM + 64 * pr + my_row] = fold32(x, li);
+        });
+        __syncthreads();
+        if (tid < BM) rowv[tid] = 1.0f / sqrtf((((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid]) / (float)BN + g.eps);
+        __syncthreads();
+    }
+    float gcol[CB], becol[CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j) { gcol[j] = (LN && g.gamma) ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = (LN && g.beta) ? g.beta[wn + 32 * j + li] : 0.f; }
+    float sk[2][4][CB], mk[2][4][CB];
+    auto load_aux = [&](int gq, int pb) {
+        const int i = gq >> 2, rq = gq & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                if (g.add) sk[pb][e][j] = g.add[(size_t)row * g.ldadd + wn + 32 * j + li];
+                if (g.mask) mk[pb][e][j] = g.mask[(size_t)row * g.ldmask + wn + 32 * j + li];
+            }
+        }
+    };
+    const bool aux = g.add || g.mask;
+    if (aux) load_aux(0, 0);
+    static_for<0, 4 * RB>([&](auto gqc) {
+        constexpr int gq = decltype(gqc)::value, i = gq >> 2, rq = gq & 3, pb = gq & 1;
+        if (aux && gq + 1 < 4 * RB) load_aux(gq + 1, pb ^ 1);
+        f32x4 r4 = {1.f, 1.f, 1.f, 1.f};
+        if constexpr (LN) r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int col = wn + 32 * j + li;
+                float o = LN ? rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]) : rowln_act<ACT>(acc[i][j][4 * rq + e]);
+                if (g.mask) o *= mk[pb][e][j];
+                if (g.add) o += sk[pb][e][j];
+                if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
+            }
+        }
+    });
+}
+
+// W [N][K] float32 (row stride ldw) -> three bfloat16 planes h, m, l with W == h + m + l exactly, each stored fragment-major: [k / 16][n / 32][lane][8] with
+// lane = (n % 32) + 32 ((k % 16) / 8) - the 1 KB a wave loads for one 32-column block of one 16-deep step is contiguous, a lane's 8 values are its MFMA operand
+__global__ void split_planes_kernel(const float* __restrict__ W, int ldw, int N, int K, __bf16* __restrict__ out, size_t plane) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;                // one float4: k = 4 c .. + 3 of row n
+    const int k4 = K >> 2;
+    if (i >= (size_t)N * k4) return;
+    const int n = (int)(i / k4), c = (int)(i % k4), k = 4 * c;
+    const f32x4 x = *reinterpret_cast<const f32x4*>(W + (size_t)n * ldw + k);
+    bf16x4 ph, pm, pl; split4(x, ph, pm, pl);
+    __bf16* o = out + ((((size_t)(k >> 4) * (N >> 5) + (n >> 5)) << 9) + (((n & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7));
+    *reinterpret_cast<bf16x4*>(o) = ph; *reinterpret_cast<bf16x4*>(o + plane) = pm; *reinterpret_cast<bf16x4*>(o + 2 * plane) = pl;
+}
+
+// One split-weight buffer per stream (a stream runs its GEMMs in order, so the buffer of the previous call is free when the next one splits into it).  Grown on
+// demand, never during a stream capture (hipMalloc is not capturable): then, or when the allocation fails, the caller takes the first form.
+struct X6Buf { hipStream_t s; void* p; size_t bytes; };
+static X6Buf g_x6buf[16];
+static int g_x6nbuf = 0;
+static std::mutex g_x6mu;
+static void* x6_weight_buffer(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_x6mu);
+    X6Buf* e = nullptr;
+    for (int i = 0; i < g_x6nbuf; ++i) if (g_x6buf[i].s == s) e = &g_x6buf[i];
+    if (e && e->bytes >= bytes) return e->p;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
+    if (!e) { if (g_x6nbuf == 16) return nullptr; e = &g_x6buf[g_x6nbuf++]; e->s = s; e->p = nullptr; e->bytes = 0; }
+    // 48 MB holds every weight matrix of the path (13 312 x 512 x 6 B = 41 MB).  A buffer is never freed or regrown: captured graphs (the belief chains'
+    // conditioning GEMMs) keep its address; a larger request takes the first form instead.
+    if (e->p) return nullptr;
+    const size_t want = (size_t)48 << 20;
+    if (bytes > want) return nullptr;
+    if (hipMalloc(&e->p, want) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return nullptr; }
+    e->bytes = want;
+    return e->p;
+}
+template <int RB, int CB, int ACT, bool LN>
+static int launch_x6p(const RowLnArgs& g, int N, const __bf16* Wp, size_t plane, hipStream_t s) {
+    constexpr int BM = 32 * RB, BN = 128 * CB;
+    constexpr size_t lds_a = 2 * 3 * BM * 16 * 2, lds_e = sizeof(float) * 5 * BM, lds = lds_a > lds_e ? lds_a : lds_e;
+    hipLaunchKernelGGL((gemm_x6p_kernel<RB, CB, ACT, LN>), dim3((g.M + BM - 1) / BM, LN ? 1 : N / BN), dim3(256), lds, s, g, Wp, plane, N / 32);
+    AID_LAUNCH_CHECK();
+    return AID_OK;
+}
+template <int RB, int CB, bool LN>
+static int launch_x6p_act(const RowLnArgs& g, int N, int act, const __bf16* Wp, size_t plane, hipStream_t s) {
+    switch (act) {
+        case ACT_SILU: return launch_x6p<RB, CB, ACT_SILU, LN>(g, N, Wp, plane, s);
+        case ACT_RELU: return launch_x6p<RB, CB, ACT_RELU, LN>(g, N, Wp, plane, s);
+        case ACT_GELU: return launch_x6p<RB, CB, ACT_GELU, LN>(g, N, Wp, plane, s);
+        default: return launch_x6p<RB, CB, ACT_NONE, LN>(g, N, Wp, plane, s);
+    }
+}
+static int g_x6_form = 2;      // 2: pre-split weights + 128 x 128 wave tiles where the shape allows (aid_gemm_emulation(3) keeps the first form: A/B timing)
+
 static int g_x6 = -1;       // -1: not decided (environment AID_GEMM_X6 read on first use), 0 off, 1 on
 bool rowln_x6_enabled() {
     if (g_x6 < 0) { const char* e = getenv("AID_GEMM_X6"); g_x6 = (e && e[0] == '1') ? 1 : 0; }
@@ -316,6 +599,18 @@ static int launch_x6_act(const RowLnArgs& g, int N, int act, hipStream_t s) {
 }
 int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) {
     AID_REQUIRE(rowln_x6_ok(N, g.K, ln), AID_E_SHAPE, "launch_rowln_x6: N=%d K=%d ln=%d", N, g.K, (int)ln);
+    // the 1024-wide LayerNorm'd stage stays on the first form: 256 accumulator registers per wave cap a full-row workgroup at 64 rows there, and at 64 rows the
+    // pre-split weights (6 B per value instead of 4) are 64 GB/s of operand per CU - the CU's ingest limit (measured: 70 TF-equivalent against the first form's 137)
+    if (g_x6_form == 2 && !(ln && N == 1024) && g.K % 32 == 0 && ((uintptr_t)g.W & 15) == 0 && g.ldw % 4 == 0) {
+        const size_t plane = (size_t)N * g.K;
+        __bf16* Wp = (__bf16*)x6_weight_buffer(s, 3 * plane * sizeof(__bf16));
+        if (Wp) {
+            const size_t n4 = plane / 4;
+            hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g.W, g.ldw, N, g.K, Wp, plane);
+            AID_LAUNCH_CHECK();
+            return ln ? launch_x6p_act<4, 4, true>(g, N, act, Wp, plane, s) : launch_x6p_act<4, 4, false>(g, N, act, Wp, plane, s);
+        }
+    }
     if (ln && N == 1024) return launch_x6_act<1024, 16, true>(g, N, act, s);
     if (ln) return launch_x6_act<512, 32, true>(g, N, act, s);
     return launch_x6_act<512, 32, false>(g, N, act, s);
@@ -325,4 +620,4 @@ int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) 
 
 using namespace aid;
 // 0: the full-row GEMMs of the estimator run on v_mfma_f32_32x32x2_f32 (default); 1: on the bf16 pipe as six split products (float32 accuracy, see above)
-extern "C" int aid_gemm_emulation(int mode) { g_x6 = mode ? 1 : 0; return AID_OK; }
+extern "C" int aid_gemm_emulation(int mode) { g_x6 = mode ? 1 : 0; g_x6_form = mode == 3 ? 1 : 2; return AID_OK; }

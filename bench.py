@@ -458,6 +458,16 @@ def other_configs(device):
         res["cfg3_hopper_b1024"]["roofline_phases"] = roofline_phases(agent)
     except Exception as e:      # diagnostics must not cost the bench line
         res["cfg3_hopper_b1024"]["roofline_phases"] = {"error": repr(e)}
+    # the same step with the opt-in six-term bf16 arithmetic of the tall full-row GEMMs (see `bf16x6` in the bench line): cfg 3 is where the estimator dominates
+    try:
+        nat.gemm_emulation(1)
+        dtx, mx = timed(agent)
+        res["cfg3_hopper_b1024"]["ms_per_step_bf16x6"] = 1e3 * dtx
+        res["cfg3_hopper_b1024"]["finite_bf16x6"] = bool(all(np.isfinite(v) for v in mx.values()))
+    except Exception as e:
+        res["cfg3_hopper_b1024"]["ms_per_step_bf16x6"] = None; res["cfg3_hopper_b1024"]["bf16x6_error"] = repr(e)
+    finally:
+        nat.gemm_emulation(0)
     del agent; torch.cuda.empty_cache()
     l4, a4, b4 = 128, 6, 256
     cfg = aid_amd.ActiveInferenceConfig(device=str(device), batch_size=b4, efe_horizon=HORIZON, latent_dim=l4, hidden_dim=D, pixel_observation=True)
@@ -973,7 +983,8 @@ def compact_line(out):
         line["roofline"] = {k: out["roofline"][k] for k in ROOFLINE_KEYS if k in out["roofline"]}
     oc = out.get("other_configs")
     if isinstance(oc, dict):
-        line["other_configs_ms"] = {k: {"ms_per_step": v.get("ms_per_step"), "frac_of_f32_mfma_peak": v.get("frac_of_f32_mfma_peak")}
+        line["other_configs_ms"] = {k: {"ms_per_step": v.get("ms_per_step"), "frac_of_f32_mfma_peak": v.get("frac_of_f32_mfma_peak"),
+                                        **({"ms_per_step_bf16x6": v["ms_per_step_bf16x6"]} if v.get("ms_per_step_bf16x6") else {})}
                                     for k, v in oc.items() if isinstance(v, dict) and "ms_per_step" in v}
     line = _round(line)
     txt = json.dumps(line, allow_nan=False, separators=(",", ":"))

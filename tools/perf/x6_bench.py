@@ -39,3 +39,20 @@ for (M, N, K, skip) in shapes:
     nat.lib().aid_gemm_emulation(0)
     (t0, m0, r0), (t1, m1, r1) = out[0], out[1]
     print(f"M={M:6d} N={N:5d} K={K:5d}: f32 mfma {t0*1e6:8.1f} us ({fl/t0/1e12:6.1f} TF)  err max {m0:.2e} rms {r0:.2e} | bf16x6 {t1*1e6:8.1f} us ({fl/t1/1e12:6.1f} TF-eq)  err max {m1:.2e} rms {r1:.2e} | x{t0/t1:.2f}", flush=True)
+
+# plain Linear (+ bias, ReLU) through aid_gemm_f32's tall route: the MINE statistics layers and the reverse loop's hoisted conditioning GEMM
+for (M, N, K) in [(128000, 512, 384), (128000, 512, 512), (12800, 13312, 512)]:
+    torch.manual_seed(M + N + K)
+    x = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") / K ** 0.5; b = torch.randn(N, device="cuda"); y = torch.empty(M, N, device="cuda")
+    fl = 2.0 * M * N * K
+    RR = 2048
+    ref = torch.relu(x[:RR].double() @ W.double().t() + b.double())
+    out = {}
+    for mode in (0, 1):
+        nat.lib().aid_gemm_emulation(mode)
+        t = timeit(lambda: nat.gemm(x, W, y, M, N, K, K, K, N, bias=b, act="relu"), 5)
+        e = (y[:RR].double() - ref).abs()
+        out[mode] = (t, float(e.max()), float(e.pow(2).mean().sqrt()))
+    nat.lib().aid_gemm_emulation(0)
+    (t0, m0, r0), (t1, m1, r1) = out[0], out[1]
+    print(f"plain M={M:6d} N={N:5d} K={K:5d}: f32 mfma {t0*1e6:8.1f} us ({fl/t0/1e12:6.1f} TF)  err max {m0:.2e} rms {r0:.2e} | bf16x6 {t1*1e6:8.1f} us ({fl/t1/1e12:6.1f} TF-eq)  err max {m1:.2e} rms {r1:.2e} | x{t0/t1:.2f}", flush=True)

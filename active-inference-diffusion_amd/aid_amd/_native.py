@@ -337,6 +337,10 @@ def gemm_emulation(mode: int):
     check(lib().aid_gemm_emulation(int(mode)), "aid_gemm_emulation")
 
 
+def gemm_emulation_mode() -> int:
+    return int(lib().aid_gemm_emulation_mode())
+
+
 def gemm_scratch(device="cuda"):
     """Scratch for gemm(..., scratch=): K slices and tile counters of the mid-size split-K route."""
     return torch.empty((lib().aid_gemm_scratch_bytes() + 3) // 4, dtype=torch.float32, device=device)

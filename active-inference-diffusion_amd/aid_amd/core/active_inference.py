@@ -349,7 +349,7 @@ class DiffusionActiveInference(nn.Module):
         B, L, D = observation.shape[0], self.latent_dim, self.config.hidden_dim
         N, train = self.config.diffusion.num_diffusion_steps, self.latent_score_network.training
         tab = self.latent_score_network.table()
-        key = (B, N, train, ctypes_addressof(tab), torch.cuda.current_stream().cuda_stream)
+        key = (B, N, train, ctypes_addressof(tab), torch.cuda.current_stream().cuda_stream, nat.gemm_emulation_mode())
         cache = self.__dict__.setdefault("_denoise_graphs", {})
         g = cache.get(key)
         if g is None:
@@ -453,7 +453,7 @@ class DiffusionActiveInference(nn.Module):
         from ..streams import chain_streams
         tab = self.latent_score_network.table()
         stream = chain_streams(stream.device)[0]          # captured on a chain stream (never the default stream), replayed on whichever stream runs the chain
-        key = (slot, rows, N, train, ctypes_addressof(tab))
+        key = (slot, rows, N, train, ctypes_addressof(tab), nat.gemm_emulation_mode())      # a captured graph holds the kernels of the arithmetic it was captured under
         cache = self.__dict__.setdefault("_chain_graphs", {})
         g = cache.get(key)
         if g is None:

@@ -524,28 +524,27 @@ __global__ void split_planes_kernel(const float* __restrict__ W, int ldw, int N,
     *reinterpret_cast<bf16x4*>(o) = ph; *reinterpret_cast<bf16x4*>(o + plane) = pm; *reinterpret_cast<bf16x4*>(o + 2 * plane) = pl;
 }
 
-// One split-weight buffer per stream (a stream runs its GEMMs in order, so the buffer of the previous call is free when the next one splits into it).  Grown on
-// demand, never during a stream capture (hipMalloc is not capturable): then, or when the allocation fails, the caller takes the first form.
-struct X6Buf { hipStream_t s; void* p; size_t bytes; };
-static X6Buf g_x6buf[16];
+// Split-weight buffers: one per (stream, weight matrix).  A stream runs its GEMMs in order, so the planes a call writes are read by that call only; hipGraphs
+// captured on one stream and replayed concurrently on several (the belief chains) share the buffer of a weight - every replay writes the SAME bytes into it (the
+// weights are constant while the chains run), so the concurrent re-splits are idempotent, and different weights never share memory.  Buffers are allocated
+// outside stream capture only (hipMalloc is not capturable; the un-captured warm-up pass of a chain creates them) and never freed or moved: captured graphs keep
+// their addresses.  No buffer (capturing without a warm-up, table full, allocation failed): the caller takes the first form.
+struct X6Buf { hipStream_t s; const void* w; void* p; size_t bytes; };
+static X6Buf g_x6buf[128];
 static int g_x6nbuf = 0;
 static std::mutex g_x6mu;
-static void* x6_weight_buffer(hipStream_t s, size_t bytes) {
+static void* x6_weight_buffer(hipStream_t s, const void* w, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_x6mu);
-    X6Buf* e = nullptr;
-    for (int i = 0; i < g_x6nbuf; ++i) if (g_x6buf[i].s == s) e = &g_x6buf[i];
-    if (e && e->bytes >= bytes) return e->p;
+    for (int i = 0; i < g_x6nbuf; ++i)
+        if (g_x6buf[i].s == s && g_x6buf[i].w == w && g_x6buf[i].bytes >= bytes) return g_x6buf[i].p;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    if (!e) { if (g_x6nbuf == 16) return nullptr; e = &g_x6buf[g_x6nbuf++]; e->s = s; e->p = nullptr; e->bytes = 0; }
-    // 48 MB holds every weight matrix of the path (13 312 x 512 x 6 B = 41 MB).  A buffer is never freed or regrown: captured graphs (the belief chains'
-    // conditioning GEMMs) keep its address; a larger request takes the first form instead.
-    if (e->p) return nullptr;
-    const size_t want = (size_t)48 << 20;
-    if (bytes > want) return nullptr;
-    if (hipMalloc(&e->p, want) != hipSuccess) { (void)hipGetLastError(); e->p = nullptr; return nullptr; }
-    e->bytes = want;
-    return e->p;
+    if (g_x6nbuf == 128) return nullptr;
+    void* p = nullptr;
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    g_x6buf[g_x6nbuf++] = {s, w, p, want};
+    return p;
 }
 template <int RB, int CB, int ACT, bool LN>
 static int launch_x6p(const RowLnArgs& g, int N, const __bf16* Wp, size_t plane, hipStream_t s) {
@@ -603,7 +602,7 @@ int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) 
     // pre-split weights (6 B per value instead of 4) are 64 GB/s of operand per CU - the CU's ingest limit (measured: 70 TF-equivalent against the first form's 137)
     if (g_x6_form == 2 && !(ln && N == 1024) && g.K % 32 == 0 && ((uintptr_t)g.W & 15) == 0 && g.ldw % 4 == 0) {
         const size_t plane = (size_t)N * g.K;
-        __bf16* Wp = (__bf16*)x6_weight_buffer(s, 3 * plane * sizeof(__bf16));
+        __bf16* Wp = (__bf16*)x6_weight_buffer(s, g.W, 3 * plane * sizeof(__bf16));
         if (Wp) {
             const size_t n4 = plane / 4;
             hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g.W, g.ldw, N, g.K, Wp, plane);
@@ -621,3 +620,4 @@ int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) 
 using namespace aid;
 // 0: the full-row GEMMs of the estimator run on v_mfma_f32_32x32x2_f32 (default); 1: on the bf16 pipe as six split products (float32 accuracy, see above)
 extern "C" int aid_gemm_emulation(int mode) { g_x6 = mode ? 1 : 0; g_x6_form = mode == 3 ? 1 : 2; return AID_OK; }
+extern "C" int aid_gemm_emulation_mode(void) { return rowln_x6_enabled() ? 1 : 0; }

@@ -108,6 +108,7 @@ int aid_rowln_debug(int mode);
  * float64 product than the float32 MFMA chain (csrc/gemm_rowln_x6.hip, tools/perf/native/bf16x6_probe.hip), 2.67 x the MFMA rate per clock.  Process-wide;
  * environment AID_GEMM_X6=1 sets the initial value. */
 int aid_gemm_emulation(int mode);
+int aid_gemm_emulation_mode(void);      /* the current value (1 / 0) */
 int aid_adaln_sum(const float* res, int ldres, const float* slab, int nslab, const float* bias, const float* mod, int ldmod, float* xout, int ldxo,
                   float* y, int ldy, int M, int D, void* stream);
 

@@ -7,6 +7,7 @@ cfg 1 (B=32, H=1, N=10: the reference's CPU-runnable case) and cfg 3 (Hopper, B=
 (pixels, L=128, D=512, N=50, H=5) against the oracle at the largest batch its CPU step fits the budget for (B=32), and at B=256 under
 device Philox through properties: finite metrics, every reference metric key, exactly the trained groups move.
 Reference: agents/state_agent.py:110-243, agents/pixel_agent.py:273-411."""
+import os
 import numpy as np
 import pytest
 import torch

@@ -532,6 +532,7 @@ __global__ void split_planes_kernel(const float* __restrict__ W, int ldw, int N,
 struct X6Buf { hipStream_t s; const void* w; void* p; size_t bytes; };
 static X6Buf g_x6buf[128];
 static int g_x6nbuf = 0;
+static size_t g_x6total = 0;
 static std::mutex g_x6mu;
 static void* x6_weight_buffer(hipStream_t s, const void* w, size_t bytes) {
     std::lock_guard<std::mutex> lk(g_x6mu);
@@ -539,11 +540,12 @@ static void* x6_weight_buffer(hipStream_t s, const void* w, size_t bytes) {
         if (g_x6buf[i].s == s && g_x6buf[i].w == w && g_x6buf[i].bytes >= bytes) return g_x6buf[i].p;
     hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return nullptr; }
-    if (g_x6nbuf == 128) return nullptr;
-    void* p = nullptr;
     const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (g_x6nbuf == 128 || g_x6total + want > ((size_t)1 << 30)) return nullptr;      // at most 1 GB of split planes per process (a training process needs ~150 MB)
+    void* p = nullptr;
     if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     g_x6buf[g_x6nbuf++] = {s, w, p, want};
+    g_x6total += want;
     return p;
 }
 template <int RB, int CB, int ACT, bool LN>

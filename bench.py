@@ -414,6 +414,7 @@ def other_configs(device):
     reverse loop (2 x 50 x 256 x 46.4 MFLOP at L = 128 is within 1 % of the L = 17 figure), ELBO 0.12 TFLOP, rollout 0.2 TFLOP; the
     gradient-free ConvDecoder estimator is opt-in and off."""
     import aid_amd
+    from aid_amd import _native as nat
     res = {}
 
     def timed(agent, warm=3, steps=5):

@@ -22,6 +22,7 @@ w("| file | what |\n|---|---|\n"
   "| `r05_phase_<phase>_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/phase_profile.py <phase>_cold 5`: ONE phase of the train_step in a cold process (5 calls: the phase's kernels only).  Phases: `elbo`, `rollout_bptt`, `efe` (rollout + estimator + BPTT; estimator = efe - rollout_bptt), `chain1` (one 256-row reverse loop), `chains3` (three concurrent), `chains2` (two: the live belief updates of a step), `value_dynamics`, `optimiser`, `pixel_epistemic` (SURVEY 8(f)-1 at 64 belief rows, S = 2) |\n"
   "| `r05_pmc_chain_summary.json` | per-kernel averages of three PMC passes (`FETCH_SIZE`; `WRITE_SIZE`; `SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE`) over ONE 256-row reverse loop alone, launched directly: the kernels of the concurrent chains.  Counter collection on this pool does not survive concurrent streams; one chain alone runs exactly the kernels, shapes and launch geometry each of the three chains runs |\n"
   "| `r05_pmc_summary.json` | the same three passes over ONE policy phase alone (rollout + estimator + BPTT, `phase_profile.py efe_cold 1`): the estimator's tall full-row kernels (replaces `r02_pmc_summary.json`) |\n"
+  "| `r05_phase_efe_x6_kernel_stats.csv`, `r05_pmc_x6_summary.json` | the policy phase again with the OPT-IN six-term bf16 arithmetic (`AID_GEMM_X6=1`, `tools/perf/r05_profiles.sh x6`): kernel stats of 5 calls (23.8 ms per call against 29.0 on the float32 pipe) and the MFMA-busy / clock pass (`gemm_x6p_kernel<4, 4, ...>`: 0.54 busy at 1.89 GHz; `gemm_rowln_x6_kernel<1024, ...>`, the form that splits the weights in registers: 0.51 busy at 1.56 GHz - the chip lowers its clock under the bf16 pipe + conversion arithmetic) |\n"
   "| `r05_cfg3_kernel_stats*.csv`, `r05_cfg4_kernel_stats*.csv` (+ `*_ms_under_rocprof.txt`) | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/cfg{3,4}_profile.py 5`: 3 warm-up + 5 timed train_steps of BASELINE configs[2] / [3] at full size, overlapped and single-stream (`_no_overlap`) |\n"
   "| `r05_small_batch_b{1,32}_kernel_stats.csv` | `rocprofv3 --kernel-trace --stats -- python3 tools/perf/small_batch_prof.py B`: five 50-step reverse loops at B rows, eval mode, direct launches |\n"
   "| `r05_bench_under_rocprof.json`, `r05_bench_no_overlap_under_rocprof.json` | the bench lines printed by the two profiled runs (slower: the profiler serialises the small kernels) |\n"

@@ -3,7 +3,8 @@
 # (tools/perf/phase_profile.py), of one cfg-3 / cfg-4 process (tools/perf/cfg{3,4}_profile.py, both schedules) and of the small-batch loops; PMC passes
 # (separate runs, --kernel-trace only beside them) for ONE 256-row reverse loop alone - the kernels of the concurrent chains - and for one
 # policy phase alone - the estimator's tall full-row kernels (counter collection on this pool does not survive concurrent streams).
-# usage: r05_profiles.sh [part ...]   parts: stats phases cfg34 small pmc_chain pmc_tall   (default: all)
+# usage: r05_profiles.sh [part ...]   parts: stats phases cfg34 small pmc_chain pmc_tall x6   (default: all but x6)
+# x6: the policy phase (rollout + estimator + BPTT) with the opt-in six-term bf16 arithmetic (AID_GEMM_X6=1): kernel stats + the MFMA-busy / clock pass
 set -e
 cd /tmp; export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r05; mkdir -p $OUT
@@ -14,7 +15,7 @@ RP="rocprofv3 --kernel-trace --stats --output-format csv"
 if has stats; then
   # AID_BENCH_SKIP=phases,denoise,graphs: the traced process runs the two timed regions (+ warm-up, + the two single-stream profiled passes), not the untimed
   # per-phase / denoise-only / small-batch measurements, so that a kernel's share of kernel time is its share in the schedules the line times
-  export AID_BENCH_SKIP=phases,denoise,graphs
+  export AID_BENCH_SKIP=phases,denoise,graphs,x6
   $RP -d $OUT/stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/stats.log 2>&1; echo stats done
   $RP -d $OUT/stats_noov -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-extras --no-overlap > $OUT/stats_noov.log 2>&1; echo stats_noov done
   unset AID_BENCH_SKIP
@@ -46,6 +47,15 @@ pmc() {   # pmc <tag> <phase>: three counter passes over one call of the phase
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/$1/mfma -- python3 $P $2 1 > $OUT/$1_mfma.log 2>&1; echo $1 mfma done
   python3 tools/perf/pmc_reduce.py $OUT/$1 > $OUT/$1_reduce.log 2>&1
 }
+if has x6; then
+  export AID_GEMM_X6=1
+  $RP -d $OUT/phase_efe_x6 -- python3 $P efe_cold 5 > $OUT/phase_efe_x6.log 2>&1; echo phase efe x6 done
+  mkdir -p $OUT/pmc_tall_x6; pmc pmc_tall_x6 efe_cold
+  unset AID_GEMM_X6
+  mkdir -p $OUT/collect
+  f=$(find $OUT/phase_efe_x6 -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $OUT/collect/r05_phase_efe_x6_kernel_stats.csv
+  [ -f $OUT/pmc_tall_x6/pmc_summary.json ] && cp $OUT/pmc_tall_x6/pmc_summary.json $OUT/collect/r05_pmc_x6_summary.json
+fi
 if has pmc_chain; then mkdir -p $OUT/pmc_chain; pmc pmc_chain chain1_direct_cold; fi
 if has pmc_tall; then mkdir -p $OUT/pmc_tall; pmc pmc_tall efe_cold; fi
 find $OUT -name '*kernel_trace.csv' -delete; find $OUT -name '*counter_collection.csv' -delete

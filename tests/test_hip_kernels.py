@@ -819,8 +819,9 @@ def test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma(nat, M, N, K, ln, 
         exact = torch.relu(pre)
     out = {}
     try:
-        for mode in (0, 1):
+        for mode in (0, 1, 3):                           # 3: the first form (weights split in registers) for every shape - what a stream capture without a split buffer takes
             nat.gemm_emulation(mode)
+            assert nat.gemm_emulation_mode() == (1 if mode else 0)
             if ln:
                 y = nat.linear_ln_act(x, W, b, ga, be, "silu", add)
             else:
@@ -829,8 +830,51 @@ def test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma(nat, M, N, K, ln, 
             out[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()), y)
     finally:
         nat.gemm_emulation(0)
-    (m0, r0, y0), (m1, r1, y1) = out[0], out[1]
-    print(f"[{M} x {N} x {K} ln={ln}] vs float64: float32 MFMA max {m0:.3g} rms {r0:.3g} | six-term bf16 max {m1:.3g} rms {r1:.3g}")
+    (m0, r0, y0), (m1, r1, y1), (m3, r3, y3) = out[0], out[1], out[3]
+    print(f"[{M} x {N} x {K} ln={ln}] vs float64: float32 MFMA max {m0:.3g} rms {r0:.3g} | six-term bf16 max {m1:.3g} rms {r1:.3g} | first form max {m3:.3g} rms {r3:.3g}")
     assert not torch.equal(y0, y1)                       # the flag does switch kernels
-    assert r1 <= 1.05 * r0 and m1 <= 1.5 * m0, (m0, r0, m1, r1)
+    for m_, r_ in ((m1, r1), (m3, r3)):
+        assert r_ <= 1.05 * r0 and m_ <= 1.5 * m0, (m0, r0, m_, r_)
     np.testing.assert_allclose(y1.cpu().numpy(), exact.float().cpu().numpy(), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(y3.cpu().numpy(), exact.float().cpu().numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_set_float32_matmul_emulation_switch(nat):
+    """The public switch (aid_amd.set_float32_matmul_emulation) and what a belief-chain graph does with it: a graph captured under one arithmetic is not replayed
+    under the other (the caches are keyed by the mode), and the latents of the two modes agree to float32 rounding."""
+    import aid_amd
+    with pytest.raises(ValueError):
+        aid_amd.set_float32_matmul_emulation("tf32")
+    try:
+        aid_amd.set_float32_matmul_emulation("bf16x6"); assert nat.gemm_emulation_mode() == 1
+        aid_amd.set_float32_matmul_emulation("off"); assert nat.gemm_emulation_mode() == 0
+        O, A, D, N, B = 17, 6, 512, 50, 256
+        cfg = aid_amd.ActiveInferenceConfig(device="cuda", batch_size=B, efe_horizon=1, latent_dim=O, hidden_dim=D)
+        cfg.diffusion = aid_amd.DiffusionConfig(num_diffusion_steps=N)
+
+        class _B:
+            def __init__(self, shape): self.shape = shape
+
+        class Env:
+            observation_space, action_space = _B((O,)), _B((A,))
+        ai = aid_amd.DiffusionStateAgent(Env(), cfg, aid_amd.TrainingConfig(buffer_size=16)).active_inference
+        from parity_noise import ParityNoise
+        from oracle import aid_oracle as orc
+        from oracle.weights import draw_params, param_specs
+        p = draw_params(param_specs(O, A, O, D, N), 5, orc.schedule_tables(N))       # a fresh agent's score head is zero: its latents would not depend on the network
+        sd0 = ai.state_dict()
+        ai.load_state_dict({**p, **{k: p[k.replace("epistemic_estimator.decoder.", "observation_decoder.")] for k in sd0 if k.startswith("epistemic_estimator.decoder.")}})
+        obs = [torch.randn(B, O, device="cuda"), torch.randn(B, O, device="cuda")]
+        outs = {}
+        for mode in ("off", "bf16x6", "off"):
+            aid_amd.set_float32_matmul_emulation(mode)
+            ai.noise = ParityNoise(77)                    # the same explicit draws for every run
+            outs.setdefault(mode, []).append(ai.denoise_many(obs).clone())
+        keys = {k[-1] for k in ai.__dict__["_chain_graphs"]}
+        assert keys == {0, 1}, keys                      # one set of graphs per arithmetic
+        assert torch.equal(outs["off"][0], outs["off"][1])      # switching back replays the float32 graphs: bit-identical
+        a, b = outs["off"][0], outs["bf16x6"][0]
+        assert not torch.equal(a, b)
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=1e-5)      # SURVEY 8(c): a 50-step loop
+    finally:
+        aid_amd.set_float32_matmul_emulation("off")

@@ -32,6 +32,11 @@ w(f"* **{bench['value']:.2f} train steps/s** = {bench['ms_per_step']:.1f} ms/ste
   f"{bench['train_step_algorithmic_tflops']:.1f} TFLOP/s = {100*bench['train_step_frac_of_f32_mfma_peak']:.1f} % of the 157.3 TFLOP/s fp32-MFMA peak; reverse loop alone {bench['denoise_steps_per_s']:.0f} steps/s at B=256.")
 w(f"* `value_dead_belief_elided`: **{bench['value_dead_belief_elided']:.2f} train steps/s** = {bench['ms_per_step_dead_belief_elided']:.1f} ms/step (second timed region of the same run: the agent's default, "
   f"which does not run the belief update `state_agent.py:138-139` computes and `:195-196` overwrites) = {100*bench['train_step_frac_of_f32_mfma_peak_dead_belief_elided']:.1f} % of peak on the same live {bench['train_step_live_flop']/1e12:.2f} TFLOP.")
+if bench.get("value_bf16x6"):
+    w(f"* opt-in arithmetic (`aid_amd.set_float32_matmul_emulation('bf16x6')`; third and fourth timed regions of the same run): `value_bf16x6` **{bench['value_bf16x6']:.2f} train steps/s** = "
+      f"{bench['ms_per_step_bf16x6']:.1f} ms/step as the reference executes the step, `value_bf16x6_dead_belief_elided` **{bench['value_bf16x6_dead_belief_elided']:.2f}** = "
+      f"{bench['ms_per_step_bf16x6_dead_belief_elided']:.1f} ms/step in the default schedule: the tall full-row GEMMs as six bf16 MFMA terms of exactly split float32 operands "
+      "(float32 accumulation; error against float64 below the float32 MFMA kernels', `tests/test_hip_kernels.py::test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma`).  Never part of `value`.")
 for key in ("roofline", "roofline_second_kernel", "roofline_single_stream"):
     r = bench.get(key)
     if not r:

@@ -228,8 +228,11 @@ template <int CPG>
 __global__ void __launch_bounds__(256) gn_mish_bwd_reg_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
                                                               const float* __restrict__ mask, const float* __restrict__ stats, const float* __restrict__ dy,
                                                               float* __restrict__ dx, float* __restrict__ ppart /*[B][C][2]*/, int C, int B, int HW, int G) {
-    __shared__ float sh[16];
-    const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x, HW4 = HW >> 2;
+    // (round 5) ONE workgroup barrier instead of 3 x (2 CPG + 2): every partial sum (the two per channel, the two of the group) is folded over the wave at once
+    // and parked in LDS, wave by wave; after the one barrier the four waves' partials are added in wave order - the same order, hence the same bits, as the
+    // eighteen wg_sum256 calls this replaces (the kernel was 54 barriers of latency around 1.4 GB of traffic: 3.8 TB/s).
+    __shared__ float sh[(2 * CPG + 2) * 4];
+    const int b = blockIdx.x / G, g = blockIdx.x % G, tid = threadIdx.x, HW4 = HW >> 2, lane = tid & 63, wv = tid >> 6;
     const bool v0 = tid < HW4, v1 = tid + 256 < HW4;
     const float mean = stats[2 * blockIdx.x], rstd = stats[2 * blockIdx.x + 1];
     gn_f4 xh[CPG][2], e[CPG][2];
@@ -257,11 +260,24 @@ __global__ void __launch_bounds__(256) gn_mish_bwd_reg_kernel(const float* __res
             }
         }
         sg += pe * ga; sgx += pex * ga;
-        const float te = wg_sum256(pe, sh), tex = wg_sum256(pex, sh);     // per-(sample, channel) partials of dbeta / dgamma
-        if (tid == 0) { ppart[((size_t)b * C + c) * 2] = tex; ppart[((size_t)b * C + c) * 2 + 1] = te; }
+        const float wpe = wave_sum(pe), wpex = wave_sum(pex);
+        if (lane == 0) { sh[(2 * cc) * 4 + wv] = wpe; sh[(2 * cc + 1) * 4 + wv] = wpex; }
+    }
+    {
+        const float wsg = wave_sum(sg), wsgx = wave_sum(sgx);
+        if (lane == 0) { sh[(2 * CPG) * 4 + wv] = wsg; sh[(2 * CPG + 1) * 4 + wv] = wsgx; }
+    }
+    __syncthreads();
+    auto fold4 = [&](int slot) { float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += sh[slot * 4 + w];
+        return t; };
+    if (tid < CPG) {                                   // per-(sample, channel) partials of dgamma / dbeta
+        const int c = g * CPG + tid;
+        ppart[((size_t)b * C + c) * 2] = fold4(2 * tid + 1); ppart[((size_t)b * C + c) * 2 + 1] = fold4(2 * tid);
     }
     const float n = (float)(CPG * HW);
-    const float mg = wg_sum256(sg, sh) / n, mgx = wg_sum256(sgx, sh) / n;
+    const float mg = fold4(2 * CPG) / n, mgx = fold4(2 * CPG + 1) / n;
 #pragma unroll
     for (int cc = 0; cc < CPG; ++cc) {
         const int c = g * CPG + cc;
@@ -307,6 +323,47 @@ __global__ void attn_pool_kernel(const float* __restrict__ x /*CNHW*/, float* __
     for (int c = 0; c < C; ++c) { const float v = x[(size_t)c * B * HW + i]; s += v; if (v > m) { m = v; am = c; } }
     const int b = i / HW, p = i % HW;
     pool[((size_t)b * 2) * HW + p] = s / (float)C; pool[((size_t)b * 2 + 1) * HW + p] = m; amax[i] = am;
+}
+// (round 5) the same reduction for HW % 4 == 0 and C % 32 == 0: a thread owns FOUR consecutive pixels (16-byte loads) and a QUARTER of the channels, eight loads in
+// flight; the four channel quarters of a pixel quad meet in LDS and are combined in channel order (the sum in quarter order, the maximum with the strict > of the
+// serial loop: the first maximal channel wins).  The one-pixel-per-thread loop above was 4-byte loads with one dependent compare chain: 2.9 TB/s.
+__global__ void __launch_bounds__(256) attn_pool4_kernel(const float* __restrict__ x /*CNHW*/, float* __restrict__ pool /*[B][2][HW]*/, int32_t* __restrict__ amax /*[B][HW]*/,
+                                                         int C, int B, int HW) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float ssum[4][64][4], smax[4][64][4]; __shared__ int sarg[4][64][4];
+    const int ql = threadIdx.x & 63, cg = threadIdx.x >> 6;
+    const size_t nq = (size_t)B * HW / 4, q = (size_t)blockIdx.x * 64 + ql;
+    const bool ok = q < nq;
+    const size_t plane4 = (size_t)B * HW / 4;
+    const f4* xp = reinterpret_cast<const f4*>(x) + (ok ? q : 0);
+    const int c0 = cg * (C / 4), c1 = c0 + C / 4;
+    f4 s = {0.f, 0.f, 0.f, 0.f}, m = {-3.4e38f, -3.4e38f, -3.4e38f, -3.4e38f}; int am[4] = {c0, c0, c0, c0};
+    for (int c = c0; c < c1; c += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * plane4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s[j] += v[u][j]; if (v[u][j] > m[j]) { m[j] = v[u][j]; am[j] = c + u; } }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { ssum[cg][ql][j] = s[j]; smax[cg][ql][j] = m[j]; sarg[cg][ql][j] = am[j]; }
+    __syncthreads();
+    if (cg != 0 || !ok) return;
+    f4 ts, tm; int ta[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = ssum[0][ql][j], mm = smax[0][ql][j]; int aa = sarg[0][ql][j];
+#pragma unroll
+        for (int g2 = 1; g2 < 4; ++g2) { a += ssum[g2][ql][j]; if (smax[g2][ql][j] > mm) { mm = smax[g2][ql][j]; aa = sarg[g2][ql][j]; } }
+        ts[j] = a / (float)C; tm[j] = mm; ta[j] = aa;
+    }
+    const size_t i0 = 4 * q; const int b = (int)(i0 / HW), p = (int)(i0 % HW);          // HW % 4 == 0: a quad never straddles two images
+    *reinterpret_cast<f4*>(pool + ((size_t)b * 2) * HW + p) = ts;
+    *reinterpret_cast<f4*>(pool + ((size_t)b * 2 + 1) * HW + p) = tm;
+    typedef int i4 __attribute__((ext_vector_type(4)));
+    *reinterpret_cast<i4*>(amax + i0) = (i4){ta[0], ta[1], ta[2], ta[3]};
 }
 __global__ void attn_conv_kernel(const float* __restrict__ pool, const float* __restrict__ w /*[2][7][7]*/, const float* __restrict__ bias,
                                  const float* __restrict__ temp, float* __restrict__ apre, float* __restrict__ att, int B, int H, int W) {
@@ -356,6 +413,48 @@ __global__ void attn_bwd_b_kernel(const float* __restrict__ da, const float* __r
     const float avg = d0 / (float)C; const int am = amax[i];
     for (int c = 0; c < C; ++c) dx[(size_t)c * B * H * W + i] += avg + (c == am ? d1 : 0.f);
 }
+// (round 5) the same for H W % 4 == 0 and C % 32 == 0: a thread owns FOUR consecutive positions (16-byte accesses) and a QUARTER of the channels, eight
+// read-modify-writes in flight; the transposed 7 x 7 convolution of a position is computed once, by the channel-quarter thread with that position's number, and
+// shared through LDS (the one-position-per-thread loop above was a 4-byte load-add-store chain per channel: 4.1 TB/s over 925 MB).
+__global__ void __launch_bounds__(256) attn_bwd_b4_kernel(const float* __restrict__ da, const float* __restrict__ w, const int32_t* __restrict__ amax, float* __restrict__ dx,
+                                                          int C, int B, int H, int W) {
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    __shared__ float savg[64][4], smx[64][4]; __shared__ int sam[64][4];
+    const int ql = threadIdx.x & 63, cg = threadIdx.x >> 6, HW = H * W;
+    const size_t nq = (size_t)B * HW / 4, q = (size_t)blockIdx.x * 64 + ql;
+    const bool ok = q < nq;
+    {
+        const size_t i = 4 * (ok ? q : 0) + cg;                          // this thread's position of the quad
+        const int x0 = (int)(i % W), y0 = (int)((i / W) % H), b = (int)(i / HW);
+        float d0 = 0.f, d1 = 0.f;
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yy = y0 - ky + 3; if (yy < 0 || yy >= H) continue;
+            for (int kx = 0; kx < 7; ++kx) { const int xx = x0 - kx + 3; if (xx < 0 || xx >= W) continue;
+                const float g = da[((size_t)b * H + yy) * W + xx];
+                d0 += g * w[(0 * 7 + ky) * 7 + kx]; d1 += g * w[(1 * 7 + ky) * 7 + kx]; }
+        }
+        savg[ql][cg] = d0 / (float)C; smx[ql][cg] = d1; sam[ql][cg] = amax[i];
+    }
+    __syncthreads();
+    if (!ok) return;
+    f4 avg, mx; int am[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { avg[j] = savg[ql][j]; mx[j] = smx[ql][j]; am[j] = sam[ql][j]; }
+    const size_t plane4 = (size_t)B * HW / 4;
+    f4* xp = reinterpret_cast<f4*>(dx) + q;
+    const int c0 = cg * (C / 4), c1 = c0 + C / 4;
+    for (int c = c0; c < c1; c += 8) {
+        f4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * plane4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[u][j] += avg[j] + (c + u == am[j] ? mx[j] : 0.f);
+            xp[(size_t)(c + u) * plane4] = v[u];
+        }
+    }
+}
 // backward C: dW[2][7][7], dbias, dtemperature.  Stage 1: every workgroup reduces its slice of the B*H*W positions to 100 partial sums
 // (98 taps + dbias + dtemp); stage 2: one workgroup folds the partials in a fixed order (deterministic).
 constexpr int ATTN_C_PARTS = 512;
@@ -387,17 +486,30 @@ __global__ void __launch_bounds__(256) attn_bwd_c_part_kernel(const float* __res
             }
         }
     }
+    // (round 5) the 100 sums folded over the wave and parked per wave, ONE barrier, then added in wave order - the bits of the 100 wg_sum256 calls
+    // (300 barriers) this replaces
+    __shared__ float shp[100][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int t = 0; t < 98; ++t) { const float tot = wg_sum256(acc[t], sh); if (threadIdx.x == 0) part[(size_t)blockIdx.x * 100 + t] = tot; }
-    const float a0 = wg_sum256(s0, sh), a1 = wg_sum256(s1, sh);
-    if (threadIdx.x == 0) { part[(size_t)blockIdx.x * 100 + 98] = a0; part[(size_t)blockIdx.x * 100 + 99] = a1; }
+    for (int t = 0; t < 98; ++t) { const float ws_ = wave_sum(acc[t]); if (lane == 0) shp[t][wv] = ws_; }
+    { const float w0 = wave_sum(s0), w1 = wave_sum(s1); if (lane == 0) { shp[98][wv] = w0; shp[99][wv] = w1; } }
+    __syncthreads();
+    if (threadIdx.x < 100) {
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) tot += shp[threadIdx.x][w];
+        part[(size_t)blockIdx.x * 100 + threadIdx.x] = tot;
+    }
+    (void)sh;
 }
-__global__ void attn_bwd_c_fold_kernel(const float* __restrict__ part, int parts, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dtemp) {
-    const int t = threadIdx.x;
-    if (t >= 100) return;
+// one wave per output t (grid = 100): lane l adds partials l, l + 64, ... in that order, then the 64 lane sums are folded by the fixed butterfly of wave_sum -
+// deterministic, and 8 independent loads per lane instead of one thread's chain of 512 dependent ones (that single-workgroup form was 128 us of pure latency)
+__global__ void __launch_bounds__(64) attn_bwd_c_fold_kernel(const float* __restrict__ part, int parts, float* __restrict__ dw, float* __restrict__ dbias, float* __restrict__ dtemp) {
+    const int t = blockIdx.x, lane = threadIdx.x;
     float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += part[(size_t)p * 100 + t];
-    if (t < 98) dw[t] += s; else if (t == 98) dbias[0] += s; else dtemp[0] += s;
+    for (int p = lane; p < parts; p += 64) s += part[(size_t)p * 100 + t];
+    s = wave_sum(s);
+    if (lane == 0) { if (t < 98) dw[t] += s; else if (t == 98) dbias[0] += s; else dtemp[0] += s; }
 }
 
 // ---- LayerNorm over F = 451 584 features, one workgroup per row -----------------------------------------------------------------------
@@ -883,7 +995,10 @@ int aid_encoder_forward(const AidEncoderNet* enc, int B, const float* x, const i
         cur = sv.act[i];
     }
     const int HW = g.HW, Hh = g.ho[3];
-    L1D(attn_pool_kernel, B * HW, s, cur, sv.pool, sv.amax, 256, B, HW);
+    if (HW % 4 == 0 && ((((uintptr_t)cur | (uintptr_t)sv.pool | (uintptr_t)sv.amax) & 15) == 0)) {
+        const size_t nq = (size_t)B * HW / 4;
+        hipLaunchKernelGGL(attn_pool4_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, s, cur, sv.pool, sv.amax, 256, B, HW);
+    } else L1D(attn_pool_kernel, B * HW, s, cur, sv.pool, sv.amax, 256, B, HW);
     L1D(attn_conv_kernel, B * HW, s, sv.pool, e.att_conv_w, e.att_conv_b, e.att_temperature, sv.apre, sv.att, B, Hh, Hh);
     {   // LayerNorm(F) over x (1 + att), formed on the fly from the CNHW activation (no attn_apply pass, no [B, F] copy)
         const int vec = HW % 4 == 0 && ((((uintptr_t)cur | (uintptr_t)sv.att | (uintptr_t)e.ln_g | (uintptr_t)e.ln_b | (uintptr_t)sv.xln) & 15) == 0);
@@ -955,9 +1070,12 @@ static int encoder_backward_impl(const AidEncoderNet* enc, const AidEncoderNet* 
     L1D(attn_bwd_a_kernel, B * HW, s, dxf, sv.act[3], sv.att, sv.apre, e.att_temperature, dact, da, tpart, 256, B, HW);
     float* cpart = ws.f32((size_t)ATTN_C_PARTS * 100); AID_WS_OK(ws);
     hipLaunchKernelGGL(attn_bwd_c_part_kernel, dim3(ATTN_C_PARTS), dim3(256), 0, s, da, sv.pool, tpart, cpart, B, Hh, Hh);
-    hipLaunchKernelGGL(attn_bwd_c_fold_kernel, dim3(1), dim3(128), 0, s, cpart, ATTN_C_PARTS, gr.att_conv_w, gr.att_conv_b, gr.att_temperature);
+    hipLaunchKernelGGL(attn_bwd_c_fold_kernel, dim3(100), dim3(64), 0, s, cpart, ATTN_C_PARTS, gr.att_conv_w, gr.att_conv_b, gr.att_temperature);
     AID_LAUNCH_CHECK();
-    L1D(attn_bwd_b_kernel, B * HW, s, da, e.att_conv_w, sv.amax, dact, 256, B, Hh, Hh);
+    if (HW % 4 == 0 && (((uintptr_t)dact & 15) == 0)) {
+        const size_t nq = (size_t)B * HW / 4;
+        hipLaunchKernelGGL(attn_bwd_b4_kernel, dim3((unsigned)((nq + 63) / 64)), dim3(256), 0, s, da, e.att_conv_w, sv.amax, dact, 256, B, Hh, Hh);
+    } else L1D(attn_bwd_b_kernel, B * HW, s, da, e.att_conv_w, sv.amax, dact, 256, B, Hh, Hh);
     // ---- conv stack, reverse
     float* dcur = dact;      // gradient wrt act[i] (CNHW)
     for (int i = ENC_LAYERS - 1; i >= 0; --i) {

@@ -337,8 +337,9 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
     const size_t w_step = (size_t)ncb << 9;                        // one stage further
     bf16x8 bh[CB], bm[CB], bl[CB];
     auto b_load = [&](int j, int t) {                            // column block j of stage t -> its registers (the same ones stage t - 1 used for block j)
+        typedef const __attribute__((address_space(1))) bf16x8* gptr8;      // explicitly GLOBAL loads (see a_load)
         const __bf16* p = w_lane + (size_t)(t < nk ? t : nk - 1) * w_step + (j << 9);
-        bh[j] = *reinterpret_cast<const bf16x8*>(p); bm[j] = *reinterpret_cast<const bf16x8*>(p + wplane); bl[j] = *reinterpret_cast<const bf16x8*>(p + 2 * wplane);
+        bh[j] = *(gptr8)(p); bm[j] = *(gptr8)(p + wplane); bl[j] = *(gptr8)(p + 2 * wplane);
     };
     // ---- activation staging: thread t stages float4 pieces f = t (+ 256): row f / 4, k = 4 (f % 4) .. + 3
     const bool a_owner = PA * NT == BM * 4 || tid < BM * 4;
@@ -352,8 +353,12 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
     f32x4 ra[PA];
     auto a_load = [&](int kt) {
         const int k0 = (kt < nk ? kt : nk - 1) * BKT;
+        // explicitly GLOBAL loads: when the address is rematerialised from the kernel arguments under register pressure the compiler loses the address space and emits
+        // flat_load, whose completion it can only wait for with vmcnt(0) - draining every weight request in flight, once per stage (seen in the 2 x 8 form: 72 instead of
+        // 150 TFLOP/s-equivalent)
+        typedef const __attribute__((address_space(1))) f32x4* gptr4;
 #pragma unroll
-        for (int e = 0; e < PA; ++e) ra[e] = *reinterpret_cast<const f32x4*>(a_src[e] + k0);
+        for (int e = 0; e < PA; ++e) ra[e] = *(gptr4)(a_src[e] + k0);
     };
     auto a_store = [&](int buf) {
         if (!a_owner) return;
@@ -383,20 +388,15 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
     // other buffer early in the stage, then re-loaded for stage t + 2.
     auto stage = [&](int t, int cur) {
 #pragma unroll
-        for (int j = 0; j < CB - 1; ++j) {
+        for (int j = 0; j < CB; ++j) {
+            if (j == CB - 1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // activations of stage t + 1 written by every wave, buffer `cur` read for the last time
 #pragma unroll
-            for (int i = 0; i < RB; ++i) block6(i, j, bh[j], bm[j], bl[j]);
+            for (int i = 0; i < RB; ++i) { block6(i, j, bh[j], bm[j], bl[j]); if (j == CB - 1) read_a(cur ^ 1, i); }
             __builtin_amdgcn_sched_barrier(0);                      // pin the requests here: the scheduler otherwise sinks them to the end of the stage
             b_load(j, t + 1);
             if (j == 0) { a_store(cur ^ 1); a_load(t + 2); }
             __builtin_amdgcn_sched_barrier(0);
         }
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // activations of stage t + 1 written by every wave, buffer `cur` read for the last time
-#pragma unroll
-        for (int i = 0; i < RB; ++i) { block6(i, CB - 1, bh[CB - 1], bm[CB - 1], bl[CB - 1]); read_a(cur ^ 1, i); }
-        __builtin_amdgcn_sched_barrier(0);
-        b_load(CB - 1, t + 1);
-        __builtin_amdgcn_sched_barrier(0);
     };
     // ---- prologue
     a_load(0);
@@ -476,38 +476,44 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
     float gcol[CB], becol[CB];
 #pragma unroll
     for (int j = 0; j < CB; ++j) { gcol[j] = (LN && g.gamma) ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = (LN && g.beta) ? g.beta[wn + 32 * j + li] : 0.f; }
-    float sk[2][4][CB], mk[2][4][CB];
-    auto load_aux = [&](int gq, int pb) {
+    // the store loop walks the columns in groups of CJ = 4 column blocks (CB = 8: two passes over the rows): skip / mask values of 4 rows x 4 column blocks, the next
+    // group's prefetched - with all eight column blocks of a row group in flight the 256 accumulator values passing through the VGPRs no longer fit (spills: 2.5 ms)
+    constexpr int CJ = 4, NH = CB / CJ;
+    float sk[2][4][CJ], mk[2][4][CJ];
+    auto load_aux = [&](int gq, int jh, int pb) {
         const int i = gq >> 2, rq = gq & 3;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
 #pragma unroll
-            for (int j = 0; j < CB; ++j) {
-                if (g.add) sk[pb][e][j] = g.add[(size_t)row * g.ldadd + wn + 32 * j + li];
-                if (g.mask) mk[pb][e][j] = g.mask[(size_t)row * g.ldmask + wn + 32 * j + li];
+            for (int jj = 0; jj < CJ; ++jj) {
+                if (g.add) sk[pb][e][jj] = g.add[(size_t)row * g.ldadd + wn + 32 * (CJ * jh + jj) + li];
+                if (g.mask) mk[pb][e][jj] = g.mask[(size_t)row * g.ldmask + wn + 32 * (CJ * jh + jj) + li];
             }
         }
     };
     const bool aux = g.add || g.mask;
-    if (aux) load_aux(0, 0);
-    static_for<0, 4 * RB>([&](auto gqc) {
-        constexpr int gq = decltype(gqc)::value, i = gq >> 2, rq = gq & 3, pb = gq & 1;
-        if (aux && gq + 1 < 4 * RB) load_aux(gq + 1, pb ^ 1);
+    constexpr int NGQ = 4 * RB * NH;                                  // (column half, row group) pairs, column half outermost
+    if (aux) load_aux(0, 0, 0);
+    static_for<0, NGQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value, jh = q / (4 * RB), gq = q % (4 * RB), i = gq >> 2, rq = gq & 3, pb = q & 1;
+        if (aux && q + 1 < NGQ) load_aux((q + 1) % (4 * RB), (q + 1) / (4 * RB), pb ^ 1);
         f32x4 r4 = {1.f, 1.f, 1.f, 1.f};
         if constexpr (LN) r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int row = m0 + 32 * i + 8 * rq + 4 * h + e;
 #pragma unroll
-            for (int j = 0; j < CB; ++j) {
-                const int col = wn + 32 * j + li;
-                float o = LN ? rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]) : rowln_act<ACT>(acc[i][j][4 * rq + e]);
-                if (g.mask) o *= mk[pb][e][j];
-                if (g.add) o += sk[pb][e][j];
+            for (int jj = 0; jj < CJ; ++jj) {
+                constexpr int j0 = CJ * jh;
+                const int col = wn + 32 * (j0 + jj) + li;
+                float o = LN ? rowln_act<ACT>(acc[i][j0 + jj][4 * rq + e] * r4[e] * gcol[j0 + jj] + becol[j0 + jj]) : rowln_act<ACT>(acc[i][j0 + jj][4 * rq + e]);
+                if (g.mask) o *= mk[pb][e][jj];
+                if (g.add) o += sk[pb][e][jj];
                 if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
             }
         }
+        if constexpr (CB > 4) __builtin_amdgcn_sched_barrier(0);
     });
 }
 
@@ -565,7 +571,7 @@ static int launch_x6p_act(const RowLnArgs& g, int N, int act, const __bf16* Wp, 
         default: return launch_x6p<RB, CB, ACT_NONE, LN>(g, N, Wp, plane, s);
     }
 }
-static int g_x6_form = 2;      // 2: pre-split weights + 128 x 128 wave tiles where the shape allows (aid_gemm_emulation(3) keeps the first form: A/B timing)
+static int g_x6_form = 2;      // 2: pre-split weights, one wave per SIMD (128 x 128 / 64 x 256 wave tiles) where the shape allows (aid_gemm_emulation(3) keeps the first form: A/B timing)
 
 static int g_x6 = -1;       // -1: not decided (environment AID_GEMM_X6 read on first use), 0 off, 1 on
 bool rowln_x6_enabled() {
@@ -600,15 +606,15 @@ static int launch_x6_act(const RowLnArgs& g, int N, int act, hipStream_t s) {
 }
 int launch_rowln_x6(const RowLnArgs& g, int N, int act, bool ln, hipStream_t s) {
     AID_REQUIRE(rowln_x6_ok(N, g.K, ln), AID_E_SHAPE, "launch_rowln_x6: N=%d K=%d ln=%d", N, g.K, (int)ln);
-    // the 1024-wide LayerNorm'd stage stays on the first form: 256 accumulator registers per wave cap a full-row workgroup at 64 rows there, and at 64 rows the
-    // pre-split weights (6 B per value instead of 4) are 64 GB/s of operand per CU - the CU's ingest limit (measured: 70 TF-equivalent against the first form's 137)
-    if (g_x6_form == 2 && !(ln && N == 1024) && g.K % 32 == 0 && ((uintptr_t)g.W & 15) == 0 && g.ldw % 4 == 0) {
+    // LayerNorm'd 1024-wide rows: 64 rows x 1024 columns per workgroup (RB = 2, CB = 8 - what 256 accumulator registers per wave allow for complete rows)
+    if (g_x6_form == 2 && g.K % 32 == 0 && ((uintptr_t)g.W & 15) == 0 && g.ldw % 4 == 0) {
         const size_t plane = (size_t)N * g.K;
         __bf16* Wp = (__bf16*)x6_weight_buffer(s, g.W, 3 * plane * sizeof(__bf16));
         if (Wp) {
             const size_t n4 = plane / 4;
             hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, g.W, g.ldw, N, g.K, Wp, plane);
             AID_LAUNCH_CHECK();
+            if (ln && N == 1024) return launch_x6p_act<2, 8, true>(g, N, act, Wp, plane, s);
             return ln ? launch_x6p_act<4, 4, true>(g, N, act, Wp, plane, s) : launch_x6p_act<4, 4, false>(g, N, act, Wp, plane, s);
         }
     }

@@ -250,6 +250,13 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
     // 8 groups of 4 rows x TN columns per lane; the skip values of group gq + 1 are loaded before group gq is finished and stored, so
     // their latency hides behind the previous group's math and stores (one workgroup per CU: nothing else would cover it)
     float sk[2][4][TN], mk[2][4][TN];
+    // branch-free skip / mask operands: an absent one is read from a valid address (element 0 of the output's first row... of `Y`'s allocation: g.Y) and dropped by a
+    // select, so the loads are unconditional global loads the compiler can count (`vmcnt(N)`): behind `if (g.add)` branches it waited `vmcnt(0)` at every join and the
+    // next group's prefetch was drained with the current one
+    typedef const __attribute__((address_space(1))) float* gfp;
+    const int add_on = g.add ? 1 : 0, mask_on = g.mask ? 1 : 0;
+    const gfp addp = (gfp)(g.add ? g.add : g.Y), maskp = (gfp)(g.mask ? g.mask : g.Y);
+    const size_t add_ld = g.add ? (size_t)g.ldadd : 0, mask_ld = g.mask ? (size_t)g.ldmask : 0;
     auto load_aux = [&](int gq, int pb) {
         const int i = gq >> 2, rq = gq & 3;
 #pragma unroll
@@ -257,17 +264,16 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
             const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                if (g.add) sk[pb][e][j] = g.add[(size_t)row * g.ldadd + wn + 32 * j + li];
-                if (g.mask) mk[pb][e][j] = g.mask[(size_t)row * g.ldmask + wn + 32 * j + li];
+                sk[pb][e][j] = addp[(size_t)row * add_ld + (wn + 32 * j + li) * add_on];
+                mk[pb][e][j] = maskp[(size_t)row * mask_ld + (wn + 32 * j + li) * mask_on];
             }
         }
     };
-    const bool aux = g.add || g.mask;
-    if (aux) load_aux(0, 0);
+    load_aux(0, 0);
 #pragma unroll
     for (int gq = 0; gq < 8; ++gq) {
         const int i = gq >> 2, rq = gq & 3, pb = gq & 1;
-        if (aux && gq + 1 < 8) load_aux(gq + 1, pb ^ 1);
+        if (gq + 1 < 8) load_aux(gq + 1, pb ^ 1);
         f32x4 r4 = {1.f, 1.f, 1.f, 1.f};
         if constexpr (LN) r4 = *reinterpret_cast<const f32x4*>(rowv + 32 * i + 8 * rq + 4 * h);
 #pragma unroll
@@ -277,8 +283,8 @@ __global__ void __launch_bounds__(512) gemm_rowln_kernel(RowLnArgs g) {
             for (int j = 0; j < TN; ++j) {
                 const int col = wn + 32 * j + li;
                 float o = LN ? rowln_act<ACT>(acc[i][j][4 * rq + e] * r4[e] * gcol[j] + becol[j]) : rowln_act<ACT>(acc[i][j][4 * rq + e]);
-                if (g.mask) o *= mk[pb][e][j];
-                if (g.add) o += sk[pb][e][j];
+                o = mask_on ? o * mk[pb][e][j] : o;
+                o = add_on ? o + sk[pb][e][j] : o;
                 if (row < g.M) g.Y[(size_t)row * g.ldy + col] = o;
             }
         }

@@ -430,6 +430,32 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
         for (int j = 0; j < CB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    // (the first group's skip / mask values are requested BEFORE the LayerNorm reductions: their latency hides under the two passes)
+    // the store loop walks the columns in groups of CJ = 4 column blocks (CB = 8: two passes over the rows): skip / mask values of 4 rows x 4 column blocks, the next
+    // group's prefetched - with all eight column blocks of a row group in flight the 256 accumulator values passing through the VGPRs no longer fit (spills: 2.5 ms)
+    constexpr int CJ = 4, NH = CB / CJ;
+    float sk[2][4][CJ], mk[2][4][CJ];
+    // branch-free skip / mask operands: an absent one is read from a valid address (element 0 of the output's first row... of `Y`'s allocation: g.Y) and dropped by a
+    // select, so the loads are unconditional global loads the compiler can count (`vmcnt(N)`): behind `if (g.add)` branches it waited `vmcnt(0)` at every join and the
+    // next group's prefetch was drained with the current one
+    typedef const __attribute__((address_space(1))) float* gfp;
+    const int add_on = g.add ? 1 : 0, mask_on = g.mask ? 1 : 0;
+    const gfp addp = (gfp)(g.add ? g.add : g.Y), maskp = (gfp)(g.mask ? g.mask : g.Y);
+    const size_t add_ld = g.add ? (size_t)g.ldadd : 0, mask_ld = g.mask ? (size_t)g.ldmask : 0;
+    auto load_aux = [&](int gq, int jh, int pb) {
+        const int i = gq >> 2, rq = gq & 3;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
+#pragma unroll
+            for (int jj = 0; jj < CJ; ++jj) {
+                sk[pb][e][jj] = addp[(size_t)row * add_ld + (wn + 32 * (CJ * jh + jj) + li) * add_on];
+                mk[pb][e][jj] = maskp[(size_t)row * mask_ld + (wn + 32 * (CJ * jh + jj) + li) * mask_on];
+            }
+        }
+    };
+    constexpr int NGQ = 4 * RB * NH;                                  // (column half, row group) pairs, column half outermost
+    load_aux(0, 0, 0);
     if constexpr (LN) {
         // accumulator register r of row block i is row 32 i + (r & 3) + 8 (r >> 2) + 4 h; fold32 takes two row blocks at a time
         const int my_row = 32 * (li >> 4) + ((li & 15) & 3) + 8 * ((li & 15) >> 2) + 4 * h;
@@ -482,31 +508,6 @@ __global__ void __launch_bounds__(256) gemm_x6p_kernel(RowLnArgs g, const __bf16
     float gcol[CB], becol[CB];
 #pragma unroll
     for (int j = 0; j < CB; ++j) { gcol[j] = (LN && g.gamma) ? g.gamma[wn + 32 * j + li] : 1.f; becol[j] = (LN && g.beta) ? g.beta[wn + 32 * j + li] : 0.f; }
-    // the store loop walks the columns in groups of CJ = 4 column blocks (CB = 8: two passes over the rows): skip / mask values of 4 rows x 4 column blocks, the next
-    // group's prefetched - with all eight column blocks of a row group in flight the 256 accumulator values passing through the VGPRs no longer fit (spills: 2.5 ms)
-    constexpr int CJ = 4, NH = CB / CJ;
-    float sk[2][4][CJ], mk[2][4][CJ];
-    // branch-free skip / mask operands: an absent one is read from a valid address (element 0 of the output's first row... of `Y`'s allocation: g.Y) and dropped by a
-    // select, so the loads are unconditional global loads the compiler can count (`vmcnt(N)`): behind `if (g.add)` branches it waited `vmcnt(0)` at every join and the
-    // next group's prefetch was drained with the current one
-    typedef const __attribute__((address_space(1))) float* gfp;
-    const int add_on = g.add ? 1 : 0, mask_on = g.mask ? 1 : 0;
-    const gfp addp = (gfp)(g.add ? g.add : g.Y), maskp = (gfp)(g.mask ? g.mask : g.Y);
-    const size_t add_ld = g.add ? (size_t)g.ldadd : 0, mask_ld = g.mask ? (size_t)g.ldmask : 0;
-    auto load_aux = [&](int gq, int jh, int pb) {
-        const int i = gq >> 2, rq = gq & 3;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int row = min(m0 + 32 * i + 8 * rq + 4 * h + e, g.M - 1);
-#pragma unroll
-            for (int jj = 0; jj < CJ; ++jj) {
-                sk[pb][e][jj] = addp[(size_t)row * add_ld + (wn + 32 * (CJ * jh + jj) + li) * add_on];
-                mk[pb][e][jj] = maskp[(size_t)row * mask_ld + (wn + 32 * (CJ * jh + jj) + li) * mask_on];
-            }
-        }
-    };
-    constexpr int NGQ = 4 * RB * NH;                                  // (column half, row group) pairs, column half outermost
-    load_aux(0, 0, 0);
     static_for<0, NGQ>([&](auto qc) {
         constexpr int q = decltype(qc)::value, jh = q / (4 * RB), gq = q % (4 * RB), i = gq >> 2, rq = gq & 3, pb = q & 1;
         if (q + 1 < NGQ) load_aux((q + 1) % (4 * RB), (q + 1) / (4 * RB), pb ^ 1);

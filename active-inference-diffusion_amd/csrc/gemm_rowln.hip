@@ -334,11 +334,15 @@ static int launch_rowln_dbg(const RowLnArgs& g, hipStream_t s) {
 // reverse loop running underneath the step is 0.7 ms shorter (tools/perf/README.md).  Chosen per STREAM: aid_stream_hint bit 1, which the agent sets on its
 // main stream while the side stream is in use.  aid_rowln_debug(34 / 35) forces it on / off process-wide for A/B timing.
 static int g_rowln_bkt16 = -1;
+static int g_rowln_bkt8 = 0;       // experiment (aid_rowln_debug(37 / 38)): under the stream hint the 512-wide kernels take 8-deep stages (36 KB of LDS: TWO chain workgroups fit beside one)
 static int g_rowln_split1024 = 0;
 static inline bool rowln_bkt16(hipStream_t s) { return g_rowln_bkt16 >= 0 ? g_rowln_bkt16 != 0 : (stream_hint_flags(s) & 2) != 0; }
 template <int BN, int BKT, int ACT>
 static int launch_rowln(const RowLnArgs& g, hipStream_t s) {
-    if constexpr (BN == 512 && BKT == 32) { if (rowln_bkt16(s) && g.K % 16 == 0) return launch_rowln_t<512, 16, ACT, false>(g, s); }
+    if constexpr (BN == 512 && BKT == 32) {
+        if (rowln_bkt16(s) && g_rowln_bkt8 && g.K % 8 == 0) return launch_rowln_t<512, 8, ACT, false>(g, s);
+        if (rowln_bkt16(s) && g.K % 16 == 0) return launch_rowln_t<512, 16, ACT, false>(g, s);
+    }
     if constexpr (ACT == ACT_SILU) {
         switch (g_rowln_dbg) {
             case 1: return launch_rowln_dbg<BN, BKT, ACT, 1>(g, s);
@@ -362,6 +366,12 @@ static int launch_rows_plain(const RowLnArgs& g, int N, hipStream_t s) {
         attr_done = true;
     }
     const dim3 grid((g.M + 63) / 64, N / BN);
+    if (rowln_bkt16(s) && g_rowln_bkt8 && g.K % 8 == 0) {
+        constexpr size_t lds8 = sizeof(float) * 2 * (64 * 8 + (size_t)BN * 8);
+        hipLaunchKernelGGL((gemm_rowln_kernel<BN, 8, ACT, false, 0, false>), grid, dim3(512), lds8, s, g);
+        AID_LAUNCH_CHECK();
+        return AID_OK;
+    }
     if (rowln_bkt16(s) && g.K % 16 == 0) {
         constexpr size_t lds16 = sizeof(float) * 2 * (64 * 16 + (size_t)BN * 16);
         static bool a16 = false;
@@ -436,7 +446,7 @@ int linear_ln_act_rows(const float* x, int ldx, const float* W, const float* b, 
 }  // namespace aid
 
 using namespace aid;
-extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else if (mode == 34) g_rowln_bkt16 = 1; else if (mode == 35) g_rowln_bkt16 = 0; else if (mode == 36) g_rowln_bkt16 = -1; else if (mode == 40) g_rowln_split1024 = 1; else if (mode == 41) g_rowln_split1024 = 0; else g_rowln_dbg = mode; return AID_OK; }
+extern "C" int aid_rowln_debug(int mode) { if (mode == 16) g_rowln_dma = 0; else if (mode == 17) g_rowln_dma = 1; else if (mode == 34) g_rowln_bkt16 = 1; else if (mode == 35) g_rowln_bkt16 = 0; else if (mode == 36) g_rowln_bkt16 = -1; else if (mode == 37) g_rowln_bkt8 = 1; else if (mode == 38) g_rowln_bkt8 = 0; else if (mode == 40) g_rowln_split1024 = 1; else if (mode == 41) g_rowln_split1024 = 0; else g_rowln_dbg = mode; return AID_OK; }
 extern "C" int aid_linear_ln_act(const float* x, int ldx, const float* W, const float* b, const float* gamma, const float* beta, int act,
                                  const float* mask, const float* add, int ldadd, float* y, int ldy, int M, int N, int K, void* stream) {
     AID_REQUIRE(x && W && y, AID_E_NULL, "aid_linear_ln_act: null tensor");

@@ -130,11 +130,13 @@ def test_cfg1_train_steps_vs_oracle_with_the_six_term_arithmetic():
     """The same three steps with `aid_amd.set_float32_matmul_emulation("bf16x6")`: the estimator's tall full-row GEMMs (16 000 decoder rows at this size) run on the bf16
     pipe as six split products (csrc/gemm_rowln_x6.hip) inside a whole train_step, against the float32 oracle at the SAME tolerances as the default arithmetic."""
     import aid_amd
+    from aid_amd import _native as nat
+    mode0 = nat.gemm_emulation_mode()                    # restored afterwards: the suite may be running with AID_GEMM_X6=1
     try:
         aid_amd.set_float32_matmul_emulation("bf16x6")
         _train_steps_vs_oracle(17, 6, 512, 10, 1, 32, 1024, steps=3, wkey=2023, skey=11, key=60606)
     finally:
-        aid_amd.set_float32_matmul_emulation("off")
+        nat.gemm_emulation(mode0)
 
 
 def test_cfg2_headline_train_steps_vs_oracle():

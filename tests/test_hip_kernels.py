@@ -818,6 +818,7 @@ def test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma(nat, M, N, K, ln, 
     else:
         exact = torch.relu(pre)
     out = {}
+    mode0 = nat.gemm_emulation_mode()                    # restored afterwards: the suite may be running with AID_GEMM_X6=1
     try:
         for mode in (0, 1, 3):                           # 3: the first form (weights split in registers) for every shape - what a stream capture without a split buffer takes
             nat.gemm_emulation(mode)
@@ -829,7 +830,7 @@ def test_rowln_x6_is_at_least_as_accurate_as_the_float32_mfma(nat, M, N, K, ln, 
             e = (y.double() - exact).abs()
             out[mode] = (float(e.max()), float(e.pow(2).mean().sqrt()), y)
     finally:
-        nat.gemm_emulation(0)
+        nat.gemm_emulation(mode0)
     (m0, r0, y0), (m1, r1, y1), (m3, r3, y3) = out[0], out[1], out[3]
     print(f"[{M} x {N} x {K} ln={ln}] vs float64: float32 MFMA max {m0:.3g} rms {r0:.3g} | six-term bf16 max {m1:.3g} rms {r1:.3g} | first form max {m3:.3g} rms {r3:.3g}")
     assert not torch.equal(y0, y1)                       # the flag does switch kernels
@@ -843,6 +844,7 @@ def test_set_float32_matmul_emulation_switch(nat):
     """The public switch (aid_amd.set_float32_matmul_emulation) and what a belief-chain graph does with it: a graph captured under one arithmetic is not replayed
     under the other (the caches are keyed by the mode), and the latents of the two modes agree to float32 rounding."""
     import aid_amd
+    mode0 = nat.gemm_emulation_mode()                    # restored afterwards: the suite may be running with AID_GEMM_X6=1
     with pytest.raises(ValueError):
         aid_amd.set_float32_matmul_emulation("tf32")
     try:
@@ -877,4 +879,4 @@ def test_set_float32_matmul_emulation_switch(nat):
         assert not torch.equal(a, b)
         np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=1e-3, atol=1e-5)      # a 50-step loop
     finally:
-        aid_amd.set_float32_matmul_emulation("off")
+        nat.gemm_emulation(mode0)

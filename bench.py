@@ -736,7 +736,7 @@ def main():
     # float32 MFMA kernels they replace (csrc/gemm_rowln_x6.hip; tests/test_hip_kernels.py::test_rowln_x6_*).  Opt-in (aid_amd.set_float32_matmul_emulation
     # ("bf16x6")): `value` above is the all-float32-MFMA step; these are reported beside it, never instead of it.
     x6 = None
-    if "x6" not in set(os.environ.get("AID_BENCH_SKIP", "").split(",")) and os.environ.get("AID_GEMM_X6") != "1":
+    if world == 1 and "x6" not in set(os.environ.get("AID_BENCH_SKIP", "").split(",")) and os.environ.get("AID_GEMM_X6") != "1":      # one GPU only: the scaling runs time the default
         nat.gemm_emulation(1)
         try:
             agent.elide_dead_next_belief = False
